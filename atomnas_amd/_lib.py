@@ -1,0 +1,79 @@
+"""ctypes binding of libatomnas_hip.so (C ABI in include/atomnas_hip.h).
+
+The product path has no CPU fallback: if the shared object is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libatomnas_hip.so")
+
+vp, i32, i64, f32, f64, u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double,
+                               ctypes.c_ulonglong)
+
+# name -> argument ctypes (all return int status)
+SIGNATURES = {
+    "atomnas_dwconv_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "atomnas_dwconv_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
+                           i32, i32, i32, vp],
+    "atomnas_pw_gemm_nt": [i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp,
+                           vp, i32, i64, i32, i32, i32, vp],
+    "atomnas_pw_gemm_tn": [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i64,
+                           i64, i64, i32, vp],
+    "atomnas_bn_finalize_fwd": [vp, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
+    "atomnas_bn_finalize_bwd": [vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "atomnas_bn_apply": [vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
+    "atomnas_bn_act_pool": [vp, i32, vp, vp, i32, vp, i32, vp, f32, u64, vp, i32, i32, i32, i32, vp],
+    "atomnas_pool_act_bwd": [vp, i32, vp, f32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
+    "atomnas_act_bwd_stats": [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i64, i32, i32, vp],
+    "atomnas_im2col_stem": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "atomnas_ce_smooth": [vp, i32, vp, f32, i32, i32, vp, vp, vp, i32, f32, vp, i32, vp],
+    "atomnas_colsum": [vp, i32, vp, i64, i32, i32, vp],
+    "atomnas_fused_rmsprop_ema": [vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, i32, f64, vp],
+    "atomnas_ema_update": [vp, vp, i64, vp, vp],
+    "atomnas_weighted_norm": [vp, vp, i64, i32, vp, vp],
+    "atomnas_pack_weights": [vp, vp, vp, i32, i32, vp],
+    "atomnas_gamma_mask": [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp],
+    "atomnas_channel_repack": [vp, vp, i32, vp, i32, vp, vp],
+}
+NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version": (i32, []),
+             "atomnas_runtime_version": (i32, [])}
+
+_lib = None
+
+
+class AtomnasHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(list(SIGNATURES) + list(NO_STATUS))
+
+
+def load():
+    """Loads the library (once).  torch must already be imported so that its HIP runtime is the one in the process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AtomnasHipError(
+            "libatomnas_hip.so is missing (%s). Build it with `python -m atomnas_amd.build`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    for name, (res, args) in NO_STATUS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise AtomnasHipError("%s failed (rc=%d): %s" % (name, rc, lib.atomnas_last_error().decode()))

@@ -1,0 +1,74 @@
+"""Builds libatomnas_hip.so (gfx950) in-tree with hipcc.  `python -m atomnas_amd.build` or `build_library()`.
+
+The library is a plain C-ABI shared object (include/atomnas_hip.h); it does not link against torch.
+"""
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libatomnas_hip.so")
+OBJ_DIR = os.path.join(HERE, "csrc", "build")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the AtomNAS HIP kernels cannot be built")
+    return exe
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path):
+    h = hashlib.sha1()
+    for p in [path, os.path.join(CSRC, "common.h")]:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    stamp = obj + ".sha1"
+    dig = _digest(src)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return obj, True
+
+
+def build_library(verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(_compile, srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or not os.path.exists(LIB_PATH):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    if verbose:
+        print("built" if rebuilt else "up to date", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(verbose=True)
+    sys.exit(0)

@@ -1,0 +1,389 @@
+// BatchNorm pieces that are not fused into a convolution: the per-channel "finalize" steps between the producing
+// kernel's statistics epilogue and the consuming kernel's apply prologue, and the few stand-alone element-wise passes.
+//
+// Semantics follow torch.nn.BatchNorm2d as instantiated by the reference (models/mobilenet_base.py:142,342 with
+// momentum/eps from models/mobilenet_supernet.py:95-98): biased variance for normalisation, unbiased variance for the
+// running estimate, running = (1-m)*running + m*batch, m = 1/num_batches_tracked in cumulative mode (momentum=None, used
+// by utils/common.py:214-226 for calibration).  The backward finalize also adds the resource-weighted L1 sub-gradient
+// rho*penalty*sign(gamma) of utils/prune.py:161-167 to dgamma.
+#include "common.h"
+
+namespace atomnas {
+
+__global__ void k_bn_finalize_fwd(const float* __restrict__ stats, float inv_count, float unbias, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                                  float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ scale,
+                                  float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int C,
+                                  int Cpad) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cpad) return;
+  if (c >= C) {  // padding lanes of the channel vectors stay neutral
+    scale[c] = 0.f; shift[c] = 0.f;
+    if (save_mean) { save_mean[c] = 0.f; save_invstd[c] = 0.f; }
+    return;
+  }
+  const float mean = stats[c] * inv_count;
+  float var = stats[C + c] * inv_count - mean * mean;
+  var = fmaxf(var, 0.f);
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float s = g * invstd;
+  scale[c] = s;
+  shift[c] = b - mean * s;
+  if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
+  if (running_mean) {
+    float m = momentum;
+    if (m < 0.f) m = 1.0f / (float)(nbt[0] + 1);  // cumulative moving average; nbt is bumped by thread 0 below
+    running_mean[c] = (1.f - m) * running_mean[c] + m * mean;
+    running_var[c] = (1.f - m) * running_var[c] + m * var * unbias;
+  }
+}
+
+__global__ void k_bump(long long* nbt) { nbt[0] += 1; }
+
+__global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                 const float* __restrict__ rv, float eps, float* __restrict__ scale, float* __restrict__ shift, int C,
+                                 int Cpad) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cpad) return;
+  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; return; }
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  const float s = (gamma ? gamma[c] : 1.f) * invstd;
+  scale[c] = s;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
+}
+
+// stats2 = [sum g, sum g*x];  dgamma = invstd*(sum g*x - mean*sum g), dbeta = sum g,
+// dx = c1*g + c2*x + c3 with c1 = gamma*invstd, c2 = -gamma*invstd^2*dgamma/M, c3 = gamma*invstd*(mean*invstd*dgamma - dbeta)/M
+__global__ void k_bn_finalize_bwd(const float* __restrict__ stats2, float inv_count, const float* __restrict__ gamma,
+                                  const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                  const float* __restrict__ rho_ptr, const float* __restrict__ penalty, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
+                                  int C, int Cpad) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cpad) return;
+  if (c >= C) { c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
+  const float sg = stats2[c], sgx = stats2[C + c];
+  const float mean = save_mean[c], r = save_invstd[c];
+  const float g = gamma ? gamma[c] : 1.f;
+  const float dg = r * (sgx - mean * sg);
+  const float db = sg;
+  c1[c] = g * r;
+  c2[c] = -g * r * r * dg * inv_count;
+  c3[c] = g * r * (mean * r * dg - db) * inv_count;
+  if (dgamma) {
+    float l1 = 0.f;
+    if (rho_ptr && penalty) {
+      const float s = (g > 0.f) ? 1.f : ((g < 0.f) ? -1.f : 0.f);
+      l1 = rho_ptr[0] * penalty[c] * s;
+    }
+    dgamma[c] = dg + l1;
+  }
+  if (dbeta) dbeta[c] = db;
+}
+
+// y = act(x*scale + shift) (+ res), 8 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, int relu, const T* __restrict__ res, int ldres,
+                                                  T* __restrict__ y, int ldy, long M, int C) {
+  const int cg = (C + 7) / 8;
+  const long total = M * cg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / cg;
+    const int c0 = (int)(i % cg) * 8;
+    float v[8], s[8], h[8];
+    VecIO<T, 8>::load(x + m * ldx + c0, v);
+    VecIO<float, 8>::load(scale + c0, s);
+    VecIO<float, 8>::load(shift + c0, h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = v[e] * s[e] + h[e];
+      if (relu) a = fmaxf(a, 0.f);
+      v[e] = a;
+    }
+    if (res) {
+      float r[8];
+      VecIO<T, 8>::load(res + m * ldres + c0, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c0 + e >= C) v[e] = 0.f;
+    VecIO<T, 8>::store(y + m * ldy + c0, v);
+  }
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned long long key) {
+  // splitmix64 finaliser; counter-based so that backward can regenerate nothing: the keep mask is stored
+  key += 0x9E3779B97F4A7C15ull;
+  key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
+  key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
+  key = key ^ (key >> 31);
+  return (unsigned)(key >> 32);
+}
+
+// pooled[n][c] = dropout( mean_hw act(x[n,hw,c]*scale+shift) ); one thread per (n, 8 channels)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_act_pool(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int relu, T* __restrict__ pooled, int ldp,
+                                                     unsigned char* __restrict__ keep, float drop_p, unsigned long long seed,
+                                                     const long long* __restrict__ step_ptr, int N, int HW, int C) {
+  const int cg = (C + 7) / 8;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * cg) return;
+  const int n = i / cg, c0 = (i % cg) * 8;
+  float s[8], h[8], acc[8];
+  VecIO<float, 8>::load(scale + c0, s);
+  VecIO<float, 8>::load(shift + c0, h);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const T* xp = x + (long)n * HW * ldx + c0;
+  for (int p = 0; p < HW; ++p) {
+    float v[8];
+    VecIO<T, 8>::load(xp + (long)p * ldx, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = v[e] * s[e] + h[e];
+      acc[e] += relu ? fmaxf(a, 0.f) : a;
+    }
+  }
+  const float inv = 1.0f / (float)HW;
+  const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.f;
+  const unsigned long long step = step_ptr ? (unsigned long long)step_ptr[0] : 0ull;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float a = (c0 + e < C) ? acc[e] * inv : 0.f;
+    if (drop_p > 0.f) {
+      const unsigned r = hash32(seed ^ (step * 0x100000001B3ull) ^ ((unsigned long long)(n * (long)C + c0 + e) << 20));
+      const bool k = ((float)(r >> 8) * (1.0f / 16777216.0f)) >= drop_p;
+      if (keep && c0 + e < C) keep[(long)n * C + c0 + e] = k ? 1 : 0;
+      a = k ? a * keep_scale : 0.f;
+    }
+    o[e] = a;
+  }
+  VecIO<T, 8>::store(pooled + (long)n * ldp + c0, o);
+}
+
+// g[n,hw,c] = dpooled[n][c] * keep * keep_scale / HW * [x*scale+shift > 0];  stats2 += [sum g, sum g*x]
+// block = 256 threads = 32 channel-groups (8 ch) x 8 pixel lanes; grid.x over (n, hw chunks), grid.y over channel groups
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool_act_bwd(const T* __restrict__ dpooled, int ldp, const unsigned char* __restrict__ keep,
+                                                      float drop_p, const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu, T* __restrict__ g, int ldg,
+                                                      float* __restrict__ stats2, int N, int HW, int C) {
+  __shared__ float s_red[32 * 8 * 2];
+  const int tid = threadIdx.x;
+  const int cgl = tid & 31, pl = tid >> 5;
+  const int c0 = (blockIdx.y * 32 + cgl) * 8;
+  for (int i = tid; i < 512; i += 256) s_red[i] = 0.f;
+  __syncthreads();
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  if (c0 < C) {
+    float s[8], h[8];
+    VecIO<float, 8>::load(scale + c0, s);
+    VecIO<float, 8>::load(shift + c0, h);
+    const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.f;
+    const float inv = 1.0f / (float)HW;
+    const long total = (long)N * HW;
+    for (long p = (long)blockIdx.x * 8 + pl; p < total; p += (long)gridDim.x * 8) {
+      const int n = (int)(p / HW);
+      float d[8], v[8], o[8];
+      VecIO<T, 8>::load(dpooled + (long)n * ldp + c0, d);
+      VecIO<T, 8>::load(x + p * ldx + c0, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float gg = d[e] * inv;
+        if (drop_p > 0.f && keep) gg = (c0 + e < C && keep[(long)n * C + c0 + e]) ? gg * keep_scale : 0.f;
+        const float a = v[e] * s[e] + h[e];
+        if (relu && !(a > 0.f)) gg = 0.f;
+        if (c0 + e >= C) gg = 0.f;
+        gg = to_f32(from_f32<T>(gg));
+        o[e] = gg;
+        s0[e] += gg;
+        s1[e] += gg * v[e];
+      }
+      VecIO<T, 8>::store(g + p * ldg + c0, o);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&s_red[(cgl * 8 + e) * 2], s0[e]);
+      atomicAdd(&s_red[(cgl * 8 + e) * 2 + 1], s1[e]);
+    }
+  }
+  __syncthreads();
+  if (stats2) {
+    for (int i = tid; i < 256; i += 256) {
+      const int c = blockIdx.y * 256 + i;
+      if (c < C) {
+        atomicAdd(&stats2[c], s_red[i * 2]);
+        atomicAdd(&stats2[C + c], s_red[i * 2 + 1]);
+      }
+    }
+  }
+}
+
+// generic "masked gradient + statistics" pass:  g = dy * [z*scale+shift > 0];  stats2 += [sum g, sum g*z]
+template <typename T>
+__global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                       T* __restrict__ g, int ldg, float* __restrict__ stats2, long M, int C) {
+  __shared__ float s_red[512];
+  const int tid = threadIdx.x;
+  const int cgl = tid & 31, pl = tid >> 5;
+  const int c0 = (blockIdx.y * 32 + cgl) * 8;
+  for (int i = tid; i < 512; i += 256) s_red[i] = 0.f;
+  __syncthreads();
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  if (c0 < C) {
+    float s[8], h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 1.f; h[e] = 0.f; }
+    if (scale) { VecIO<float, 8>::load(scale + c0, s); VecIO<float, 8>::load(shift + c0, h); }
+    for (long p = (long)blockIdx.x * 8 + pl; p < M; p += (long)gridDim.x * 8) {
+      float d[8], v[8];
+      VecIO<T, 8>::load(dy + p * lddy + c0, d);
+      VecIO<T, 8>::load(z + p * ldz + c0, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = v[e] * s[e] + h[e];
+        float gg = d[e];
+        if (relu && !(a > 0.f)) gg = 0.f;
+        if (c0 + e >= C) gg = 0.f;
+        d[e] = gg;
+        s0[e] += gg;
+        s1[e] += gg * v[e];
+      }
+      if (g) VecIO<T, 8>::store(g + p * ldg + c0, d);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&s_red[(cgl * 8 + e) * 2], s0[e]);
+      atomicAdd(&s_red[(cgl * 8 + e) * 2 + 1], s1[e]);
+    }
+  }
+  __syncthreads();
+  if (stats2) {
+    for (int i = tid; i < 256; i += 256) {
+      const int c = blockIdx.y * 256 + i;
+      if (c < C) {
+        atomicAdd(&stats2[c], s_red[i * 2]);
+        atomicAdd(&stats2[C + c], s_red[i * 2 + 1]);
+      }
+    }
+  }
+}
+
+}  // namespace atomnas
+
+using namespace atomnas;
+
+extern "C" int atomnas_bn_finalize_fwd(const float* stats, double count, const float* gamma, const float* beta, float eps,
+                                       float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                       float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
+  ATOMNAS_REQUIRE(stats && scale && shift && C > 0 && count > 0, "bn_finalize_fwd: bad arguments");
+  ATOMNAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_fwd: running stats must come together");
+  ATOMNAS_REQUIRE(!(momentum < 0.f && running_mean) || num_batches_tracked, "bn_finalize_fwd: cumulative mode needs the batch counter");
+  const int Cpad = (C + 7) / 8 * 8;
+  const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 255) / 256), dim3(256), 0, st, stats, (float)(1.0 / count), unbias, gamma, beta,
+                     eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C, Cpad);
+  if (num_batches_tracked && running_mean) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, st, num_batches_tracked);
+  return check_launch("bn_finalize_fwd");
+}
+
+extern "C" int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                      float eps, float* scale, float* shift, int C, void* stream) {
+  ATOMNAS_REQUIRE(running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad arguments");
+  const int Cpad = (C + 7) / 8 * 8;
+  hipLaunchKernelGGL(k_bn_eval_coeffs, dim3((Cpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, eps, scale, shift, C, Cpad);
+  return check_launch("bn_eval_coeffs");
+}
+
+extern "C" int atomnas_bn_finalize_bwd(const float* stats2, double count, const float* gamma, const float* save_mean,
+                                       const float* save_invstd, const float* rho_ptr, const float* penalty, float* dgamma,
+                                       float* dbeta, float* c1, float* c2, float* c3, int C, void* stream) {
+  ATOMNAS_REQUIRE(stats2 && save_mean && save_invstd && c1 && c2 && c3 && C > 0 && count > 0, "bn_finalize_bwd: bad arguments");
+  const int Cpad = (C + 7) / 8 * 8;
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats2, (float)(1.0 / count),
+                     gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, Cpad);
+  return check_launch("bn_finalize_bwd");
+}
+
+extern "C" int atomnas_bn_apply(const void* x, int ldx, const float* scale, const float* shift, int relu, const void* res, int ldres,
+                                void* y, int ldy, long M, int C, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(x && y && scale && shift && M > 0 && C > 0, "bn_apply: bad arguments");
+  ATOMNAS_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C && (!res || (ldres % 8 == 0 && ldres >= C)), "bn_apply: bad pitch");
+  const long total = M * ((C + 7) / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(k_bn_apply<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ldx, scale, shift, relu,
+                       (const float*)res, ldres, (float*)y, ldy, M, C);
+  else
+    hipLaunchKernelGGL(k_bn_apply<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, scale, shift, relu,
+                       (const bf16_t*)res, ldres, (bf16_t*)y, ldy, M, C);
+  return check_launch("bn_apply");
+}
+
+extern "C" int atomnas_bn_act_pool(const void* x, int ldx, const float* scale, const float* shift, int relu, void* pooled, int ldp,
+                                   unsigned char* keep, float drop_p, unsigned long long seed, const long long* step_ptr, int N,
+                                   int HW, int C, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(x && pooled && scale && shift && N > 0 && HW > 0 && C > 0, "bn_act_pool: bad arguments");
+  ATOMNAS_REQUIRE(ldx % 8 == 0 && ldp % 8 == 0 && ldx >= C && ldp >= C, "bn_act_pool: bad pitch");
+  ATOMNAS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "bn_act_pool: bad dropout ratio");
+  const int total = N * ((C + 7) / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(k_bn_act_pool<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)x, ldx, scale, shift, relu,
+                       (float*)pooled, ldp, keep, drop_p, seed, step_ptr, N, HW, C);
+  else
+    hipLaunchKernelGGL(k_bn_act_pool<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, ldx, scale, shift, relu,
+                       (bf16_t*)pooled, ldp, keep, drop_p, seed, step_ptr, N, HW, C);
+  return check_launch("bn_act_pool");
+}
+
+extern "C" int atomnas_pool_act_bwd(const void* dpooled, int ldp, const unsigned char* keep, float drop_p, const void* x, int ldx,
+                                    const float* scale, const float* shift, int relu, void* g, int ldg, float* stats2, int N, int HW,
+                                    int C, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(dpooled && x && g && scale && shift && N > 0 && HW > 0 && C > 0, "pool_act_bwd: bad arguments");
+  ATOMNAS_REQUIRE(ldx % 8 == 0 && ldp % 8 == 0 && ldg % 8 == 0 && ldx >= C && ldp >= C && ldg >= C, "pool_act_bwd: bad pitch");
+  long gx = ((long)N * HW + 7) / 8;
+  if (gx > 1024) gx = 1024;
+  dim3 grid((unsigned)gx, (C + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(k_pool_act_bwd<float>, grid, dim3(256), 0, st, (const float*)dpooled, ldp, keep, drop_p, (const float*)x, ldx,
+                       scale, shift, relu, (float*)g, ldg, stats2, N, HW, C);
+  else
+    hipLaunchKernelGGL(k_pool_act_bwd<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dpooled, ldp, keep, drop_p, (const bf16_t*)x,
+                       ldx, scale, shift, relu, (bf16_t*)g, ldg, stats2, N, HW, C);
+  return check_launch("pool_act_bwd");
+}
+
+extern "C" int atomnas_act_bwd_stats(const void* dy, int lddy, const void* z, int ldz, const float* scale, const float* shift,
+                                     int relu, void* g, int ldg, float* stats2, long M, int C, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(dy && z && M > 0 && C > 0, "act_bwd_stats: bad arguments");
+  ATOMNAS_REQUIRE(lddy % 8 == 0 && ldz % 8 == 0 && lddy >= C && ldz >= C && (!g || (ldg % 8 == 0 && ldg >= C)), "act_bwd_stats: bad pitch");
+  ATOMNAS_REQUIRE((scale == nullptr) == (shift == nullptr), "act_bwd_stats: scale/shift must come together");
+  long gx = (M + 7) / 8;
+  if (gx > 1024) gx = 1024;
+  dim3 grid((unsigned)gx, (C + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(k_act_bwd_stats<float>, grid, dim3(256), 0, st, (const float*)dy, lddy, (const float*)z, ldz, scale, shift,
+                       relu, (float*)g, ldg, stats2, M, C);
+  else
+    hipLaunchKernelGGL(k_act_bwd_stats<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)z, ldz, scale, shift,
+                       relu, (bf16_t*)g, ldg, stats2, M, C);
+  return check_launch("act_bwd_stats");
+}

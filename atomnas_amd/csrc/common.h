@@ -1,0 +1,124 @@
+// Shared device helpers for the AtomNAS gfx950 kernels (CDNA4, wave64).
+// Activations are NHWC with an explicit channel pitch `ld` (elements, multiple of 8 so that
+// every pixel row starts 16-byte aligned for bf16); storage type T is float or bf16_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace atomnas {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32)
+
+// Load / store V consecutive channels of storage type T as fp32 registers.
+template <typename T, int V> struct VecIO;
+
+template <int V> struct VecIO<float, V> {
+  static __device__ __forceinline__ void load(const float* p, float (&o)[V]) {
+    if constexpr (V % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * i);
+        o[4 * i] = t[0]; o[4 * i + 1] = t[1]; o[4 * i + 2] = t[2]; o[4 * i + 3] = t[3];
+      }
+    } else if constexpr (V % 2 == 0) {
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) {
+        f32x2 t = *reinterpret_cast<const f32x2*>(p + 2 * i);
+        o[2 * i] = t[0]; o[2 * i + 1] = t[1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = p[i];
+    }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&o)[V]) {
+    if constexpr (V % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) {
+        f32x4 t = {o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+        *reinterpret_cast<f32x4*>(p + 4 * i) = t;
+      }
+    } else if constexpr (V % 2 == 0) {
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) {
+        f32x2 t = {o[2 * i], o[2 * i + 1]};
+        *reinterpret_cast<f32x2*>(p + 2 * i) = t;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) p[i] = o[i];
+    }
+  }
+};
+
+template <int V> struct VecIO<bf16_t, V> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&o)[V]) {
+    if constexpr (V == 8) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (float)t[i];
+    } else if constexpr (V == 4) {
+      bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (float)t[i];
+    } else if constexpr (V == 2) {
+      bf16x2 t = *reinterpret_cast<const bf16x2*>(p);
+      o[0] = (float)t[0]; o[1] = (float)t[1];
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = (float)p[i];
+    }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&o)[V]) {
+    if constexpr (V == 8) {
+      bf16x8 t;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = (bf16_t)o[i];
+      *reinterpret_cast<bf16x8*>(p) = t;
+    } else if constexpr (V == 4) {
+      bf16x4 t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = (bf16_t)o[i];
+      *reinterpret_cast<bf16x4*>(p) = t;
+    } else if constexpr (V == 2) {
+      bf16x2 t; t[0] = (bf16_t)o[0]; t[1] = (bf16_t)o[1];
+      *reinterpret_cast<bf16x2*>(p) = t;
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) p[i] = (bf16_t)o[i];
+    }
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// status plumbing shared by all translation units of the C-ABI library
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define ATOMNAS_REQUIRE(cond, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::atomnas::set_error(__VA_ARGS__);      \
+      return 1;                               \
+    }                                         \
+  } while (0)
+
+}  // namespace atomnas

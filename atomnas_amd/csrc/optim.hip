@@ -1,0 +1,138 @@
+// Optimizer tail of the training step on flat fp32 arenas: one launch replaces the ~12k tiny ATen dispatches of
+//   cal_l2_loss 'mnas'        (utils/optim.py:226-243,249)   grad += wd * p on conv/fc weights and the classifier bias
+//   RMSprop.step              (utils/rmsprop.py:70-132)      TF-style, eps inside the sqrt, momentum buffer, lr outside
+//   ExponentialMovingAverage  (utils/optim.py:54-65)         shadow = d*shadow + (1-d)*p, d = min(decay, (1+n)/(10+n))
+// plus the re-packing of the updated weights into the layouts the convolution kernels consume.
+// Scalars that change every iteration (lr, EMA decay, 1/world) are read from device memory so that the launch can sit
+// inside a replayed hipGraph.
+#include "common.h"
+
+namespace atomnas {
+
+enum { HYP_LR = 0, HYP_RHO = 1, HYP_EMA_DECAY = 2, HYP_GRAD_SCALE = 3 };
+
+// arithmetic order follows the reference: sq.mul_(alpha).addcmul_(1-alpha, g, g); avg = sqrt(sq+eps);
+// buf.mul_(mom).addcdiv_(g, avg); p.add_(-lr, buf)
+__global__ __launch_bounds__(256) void k_rmsprop_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                     float* __restrict__ buf, float* __restrict__ ema,
+                                                     const float* __restrict__ wd_chunk, long n, const float* __restrict__ hyper,
+                                                     float alpha, float one_minus_alpha, float eps, int eps_inside_sqrt,
+                                                     float momentum) {
+#pragma clang fp contract(off)  // keep the reference's separate roundings (no fused multiply-add)
+  const float lr = hyper[HYP_LR], d = hyper[HYP_EMA_DECAY], gs = hyper[HYP_GRAD_SCALE];
+  const long nchunks = (n + 255) / 256;
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const long i = ch * 256 + threadIdx.x;
+    if (i >= n) continue;
+    const float wd = wd_chunk ? wd_chunk[ch] : 0.f;
+    float pv = p[i];
+    float gv = g[i] * gs;
+    gv = gv + wd * pv;
+    float s = sq[i] * alpha;
+    s = s + (one_minus_alpha * gv) * gv;
+    sq[i] = s;
+    const float avg = eps_inside_sqrt ? sqrtf(s + eps) : (sqrtf(s) + eps);
+    if (buf) {
+      float b = buf[i] * momentum;
+      b = b + gv / avg;
+      buf[i] = b;
+      pv = pv - lr * b;
+    } else {
+      pv = pv - lr * (gv / avg);
+    }
+    p[i] = pv;
+    if (ema && d >= 0.f) ema[i] = ema[i] * d + (1.0f - d) * pv;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ema(float* __restrict__ shadow, const float* __restrict__ x, long n,
+                                             const float* __restrict__ hyper) {
+#pragma clang fp contract(off)
+  const float d = hyper[HYP_EMA_DECAY];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) shadow[i] = shadow[i] * d + (1.0f - d) * x[i];
+}
+
+// sum over the arena of coef[chunk] * f(p): f = p^2 (L2 value) or |p| (L1 value); only needed for logging
+__global__ __launch_bounds__(256) void k_weighted_norm(const float* __restrict__ p, const float* __restrict__ coef_chunk, long n,
+                                                       int use_abs, float* __restrict__ out) {
+  __shared__ float s_part[4];
+  const long nchunks = (n + 255) / 256;
+  float acc = 0.f;
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const long i = ch * 256 + threadIdx.x;
+    if (i < n) {
+      const float c = coef_chunk[ch];
+      const float v = p[i];
+      acc += c * (use_abs ? fabsf(v) : v * v);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// Weight packing jobs.  src is fp32 in the parameter arena with logical shape [rows][cols] (row pitch src_ld).
+//   mode 0 (PW):   dst[r*dst_ld + c_off + c] = src[r][c]            (storage T)   -> gemm_nt weight  [N][K]
+//   mode 1 (PW_T): dst[(c_off + c)*dst_ld + r] = src[r][c]          (storage T)   -> gemm_nt weight of the transposed product
+//   mode 2 (DW):   dst[c*dst_ld + c_off + r] = src[r][c]            (fp32)        -> depthwise taps [k*k][C]
+struct PackJob {
+  long src_off, dst_off;
+  int rows, cols, src_ld, dst_ld, c_off, mode;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ arena, void* __restrict__ packbuf, const PackJob* __restrict__ jobs) {
+  const PackJob jb = jobs[blockIdx.y];
+  const long total = (long)jb.rows * jb.cols;
+  const float* src = arena + jb.src_off;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / jb.cols), c = (int)(i % jb.cols);
+    const float v = src[(long)r * jb.src_ld + c];
+    if (jb.mode == 0) reinterpret_cast<T*>(packbuf)[jb.dst_off + (long)r * jb.dst_ld + jb.c_off + c] = from_f32<T>(v);
+    else if (jb.mode == 1) reinterpret_cast<T*>(packbuf)[jb.dst_off + (long)(jb.c_off + c) * jb.dst_ld + r] = from_f32<T>(v);
+    else reinterpret_cast<float*>(packbuf)[jb.dst_off + (long)c * jb.dst_ld + jb.c_off + r] = v;
+  }
+}
+
+}  // namespace atomnas
+
+using namespace atomnas;
+
+extern "C" int atomnas_fused_rmsprop_ema(float* p, const float* g, float* sq, float* buf, float* ema, const float* wd_chunk, long n,
+                                         const float* hyper, double alpha, double eps, int eps_inside_sqrt, double momentum,
+                                         void* stream) {
+  ATOMNAS_REQUIRE(p && g && sq && hyper && n > 0, "fused_rmsprop_ema: bad arguments");
+  ATOMNAS_REQUIRE(momentum >= 0.0 && alpha >= 0.0 && eps >= 0.0, "fused_rmsprop_ema: bad hyper-parameters");
+  ATOMNAS_REQUIRE((momentum > 0.0) == (buf != nullptr), "fused_rmsprop_ema: momentum buffer must be given iff momentum > 0");
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_rmsprop_ema, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, buf, ema, wd_chunk, n, hyper,
+                     (float)alpha, (float)(1.0 - alpha), (float)eps, eps_inside_sqrt, (float)momentum);
+  return check_launch("fused_rmsprop_ema");
+}
+
+extern "C" int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper, void* stream) {
+  ATOMNAS_REQUIRE(shadow && x && hyper && n > 0, "ema_update: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_ema, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shadow, x, n, hyper);
+  return check_launch("ema_update");
+}
+
+extern "C" int atomnas_weighted_norm(const float* p, const float* coef_chunk, long n, int use_abs, float* out, void* stream) {
+  ATOMNAS_REQUIRE(p && coef_chunk && out && n > 0, "weighted_norm: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_weighted_norm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, coef_chunk, n, use_abs, out);
+  return check_launch("weighted_norm");
+}
+
+extern "C" int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(arena && packbuf && jobs_dev && njobs > 0, "pack_weights: bad arguments");
+  dim3 grid(32, njobs);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32) hipLaunchKernelGGL(k_pack<float>, grid, dim3(256), 0, st, arena, packbuf, (const PackJob*)jobs_dev);
+  else hipLaunchKernelGGL(k_pack<bf16_t>, grid, dim3(256), 0, st, arena, packbuf, (const PackJob*)jobs_dev);
+  return check_launch("pack_weights");
+}

@@ -1,0 +1,448 @@
+// Pointwise (1x1) convolutions of the atomic block as MFMA GEMMs on gfx950.
+//
+// Replaces the ATen conv2d/1x1 calls behind ConvBNReLU(inp, hid, 1) (models/mobilenet_base.py:316-320), the linear
+// projection nn.Conv2d(hid, oup, 1) (:338), the last 1x1 conv (models/mobilenet_supernet.py:148-153) and the classifier
+// (:160-163), forward and backward.  All three branches of a block are concatenated along the hidden dimension
+// (sum_i W_i h_i == [W_1 W_2 W_3][h_1;h_2;h_3], mobilenet_base.py:378), so a block is one expand and one project GEMM.
+//
+//   gemm_nt  : C[M,N] = epi( pro(A)[M,K] * Wp[N,K]^T )               (forward and input-gradient form)
+//   gemm_tn  : Out[i,j] += sum_m pro(U)[m,i] * pro(V)[m,j]            (weight-gradient form, reduction over M)
+//
+// These GEMMs are extremely skinny (min(K,N) is 16..320 while M = batch*H*W is up to 3.2e6): they are HBM-bound, so the
+// design goal is to stream A / C exactly once with 16-byte accesses and hide everything else behind it:
+//   * prologue fusions on the A side: BatchNorm-apply + ReLU (forward) or the BatchNorm-backward affine
+//     dX = c1*g + c2*x + c3 of two streams, so normalised / differentiated activations never round-trip through HBM;
+//   * epilogue fusions: residual add, ReLU mask of the producer, and the per-channel sums the next BatchNorm
+//     (forward: sum c, sum c^2; backward: sum g, sum g*x) needs;
+//   * mfma_f32_16x16x32_bf16 with the weight matrix as the MFMA "A" operand: the accumulator layout then gives every lane
+//     16 consecutive output channels of one pixel, i.e. whole 32-byte runs, with no LDS transpose.
+// fp32 storage uses mfma_f32_16x16x4f32 through the same code (exact f32; for parity tests, not for speed).
+#include "common.h"
+
+namespace atomnas {
+
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_BNBWD = 2 };
+enum { STAT_NONE = 0, STAT_SQ = 1, STAT_Z = 2 };
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int EPL = 8;  // k-elements per lane per MFMA
+  using frag = bf16x8;
+  static __device__ __forceinline__ frag pack(const float (&v)[8]) {
+    frag f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (bf16_t)v[i];
+    return f;
+  }
+  static __device__ __forceinline__ frag raw(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int EPL = 1;
+  using frag = float;
+  static __device__ __forceinline__ frag pack(const float (&v)[1]) { return v[0]; }
+  static __device__ __forceinline__ frag raw(const float* p) { return *p; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// Operand description with its prologue.
+struct Operand {
+  const void* p1; int ld1;   // main stream
+  const void* p2; int ld2;   // second stream (PRO_BNBWD: the raw activation x)
+  const float* c1;           // BNRELU: scale   | BNBWD: c1
+  const float* c2;           // BNRELU: shift   | BNBWD: c2
+  const float* c3;           //                 | BNBWD: c3
+  int relu;                  // BNRELU: apply max(.,0)
+};
+
+// Loads EPL consecutive channels starting at channel k of row `row`, applies the prologue, zeroes channels >= K.
+template <typename T, int MODE>
+__device__ __forceinline__ void load_pro(const Operand& o, long row, bool rowvalid, int k, int K, float (&v)[Mma<T>::EPL]) {
+  constexpr int E = Mma<T>::EPL;
+  if (!rowvalid || k >= K) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = 0.f;
+    return;
+  }
+  VecIO<T, E>::load(reinterpret_cast<const T*>(o.p1) + row * o.ld1 + k, v);
+  if constexpr (MODE == PRO_BNRELU) {
+    float s[E], h[E];
+    VecIO<float, E>::load(o.c1 + k, s);
+    VecIO<float, E>::load(o.c2 + k, h);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float a = v[e] * s[e] + h[e];
+      v[e] = o.relu ? fmaxf(a, 0.f) : a;
+    }
+  } else if constexpr (MODE == PRO_BNBWD) {
+    float x[E], a1[E], a2[E], a3[E];
+    VecIO<T, E>::load(reinterpret_cast<const T*>(o.p2) + row * o.ld2 + k, x);
+    VecIO<float, E>::load(o.c1 + k, a1);
+    VecIO<float, E>::load(o.c2 + k, a2);
+    VecIO<float, E>::load(o.c3 + k, a3);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = a1[e] * v[e] + a2[e] * x[e] + a3[e];
+  }
+  if constexpr (E > 1) {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (k + e >= K) v[e] = 0.f;
+  }
+}
+
+struct Epilogue {
+  void* c; int ldc; int out_f32;       // output [M, N] (storage T, or fp32 when out_f32)
+  const void* add; int ldadd;          // optional residual stream (storage T)
+  const void* z; int ldz;              // optional raw activation stream (storage T) for mask / STAT_Z
+  const float* zscale; const float* zshift; int mask;  // mask: c *= [z*zscale+zshift > 0]
+  const float* bias;                   // optional per-output-channel bias
+  float* stats; int stat_mode;         // [2][N] fp32, accumulated atomically
+};
+
+constexpr int NT_MAX_STAT = 3520;  // largest hidden width of the supernet (3*1152) rounded up to 64
+
+// ------------------------------------------------------------------------------------------------ gemm_nt
+// One wave owns 16 rows of A per step and produces 64 output channels at a time with 4 MFMA tiles whose weight rows
+// are interleaved (row i of tile t is channel nc + 16*(i>>2) + 4*t + (i&3)) so that lane (q = lane>>4, j = lane&15)
+// ends up with channels nc+16q .. nc+16q+15 of pixel m0+j.
+template <typename T, int MODE, int NCG>
+__global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K,
+                                                 int Kpad) {
+  using MM = Mma<T>;
+  constexpr int E = MM::EPL;
+  constexpr int KS = 4 * E;
+  __shared__ float s_stat[2 * NT_MAX_STAT];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int wrow = 16 * (j >> 2) + (j & 3);  // weight row of this lane inside a 64-channel chunk, before the +4*t
+  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+
+  if (do_stats) {
+    for (int i = tid; i < 2 * N; i += 256) s_stat[i] = 0.f;
+    __syncthreads();
+  }
+
+  const long mtiles = (M + 15) / 16;
+  for (long mt = (long)blockIdx.x * 4 + wave; mt < mtiles; mt += (long)gridDim.x * 4) {
+    const long m0 = mt * 16;
+    const long row = m0 + j;
+    const bool rowvalid = row < M;
+    for (int nc0 = 0; nc0 < N; nc0 += 64 * NCG) {
+      f32x4 acc[NCG][4];
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      for (int k0 = 0; k0 < Kpad; k0 += KS) {
+        const int k = k0 + q * E;
+        float av[E];
+        load_pro<T, MODE>(A, row, rowvalid, k, K, av);
+        const typename MM::frag af = MM::pack(av);
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+          const int nc = nc0 + 64 * g;
+          if (nc < N) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const typename MM::frag wf = MM::raw(Wp + (long)(nc + wrow + 4 * t) * ldw + k);
+              acc[g][t] = MM::mma(wf, af, acc[g][t]);
+            }
+          }
+        }
+      }
+
+      // epilogue: lane holds channels nb .. nb+15 of pixel `row`, ordered [t][r]
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const int nb = nc0 + 64 * g + 16 * q;
+        if (nc0 + 64 * g >= N) continue;
+        float c[16], zv[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[4 * t + r] = acc[g][t][r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zv[i] = 0.f;
+
+        if (rowvalid) {
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            const int n8 = nb + 8 * h8;
+            if (n8 >= N) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) c[8 * h8 + i] = 0.f;
+              continue;
+            }
+            float tmp[8];
+            if (ep.bias) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) c[8 * h8 + i] += (n8 + i < N) ? ep.bias[n8 + i] : 0.f;
+            }
+            if (ep.add) {
+              VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.add) + row * ep.ldadd + n8, tmp);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
+            }
+            if (ep.z) {
+              VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + row * ep.ldz + n8, tmp);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) zv[8 * h8 + i] = tmp[i];
+              if (ep.mask) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                  const int n = n8 + i;
+                  const float a = (n < N) ? tmp[i] * ep.zscale[n] + ep.zshift[n] : 0.f;
+                  if (!(a > 0.f)) c[8 * h8 + i] = 0.f;
+                }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (n8 + i >= N) c[8 * h8 + i] = 0.f;
+            if (ep.out_f32) {
+              float* cp = reinterpret_cast<float*>(ep.c) + row * ep.ldc + n8;
+              float o8[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
+              VecIO<float, 8>::store(cp, o8);
+            } else {
+              float o8[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
+                c[8 * h8 + i] = o8[i];  // statistics see the stored value
+              }
+              VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + row * ep.ldc + n8, o8);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) c[i] = 0.f;
+        }
+
+        if (do_stats) {
+          // reduce over the 16 pixels (lanes with equal q), then one LDS atomic per channel from lane j == 0
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float s1 = c[i];
+            float s2 = (ep.stat_mode == STAT_SQ) ? c[i] * c[i] : c[i] * zv[i];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+              s1 += __shfl_xor(s1, o, 64);
+              s2 += __shfl_xor(s2, o, 64);
+            }
+            if (j == 0 && nb + i < N) {
+              atomicAdd(&s_stat[nb + i], s1);
+              atomicAdd(&s_stat[N + nb + i], s2);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (do_stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * N; i += 256) {
+      const float v = s_stat[i];
+      if (v != 0.f) atomicAdd(&ep.stats[i], v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gemm_tn
+// Out[i*si + j*sj] += sum_m U[m][i] * V[m][j].  A block owns up to 16*UT_MAX columns of U (all four waves use all of
+// them) and 64 columns of V (one 16-column tile per wave) and a contiguous chunk of rows; 32-row slabs of both operands
+// are staged (after their prologues) in LDS and read back column-wise as MFMA fragments.
+constexpr int UT_MAX = 20;  // 320 channels
+constexpr int TN_ROWS = 32;
+
+template <typename T, int UMODE, int VMODE>
+__global__ __launch_bounds__(256) void k_gemm_tn(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj,
+                                                 long M, long rows_per_block) {
+  using MM = Mma<T>;
+  constexpr int E = MM::EPL;
+  constexpr int SUB = TN_ROWS / (4 * E);     // MFMA k-steps per 32-row slab (1 for bf16, 8 for fp32)
+  constexpr int UP = 16 * UT_MAX + 2;        // LDS pitches (elements); +2 keeps the 8-row groups on distinct banks
+  constexpr int VP = 64 + 2;
+  __shared__ T s_u[TN_ROWS * UP];
+  __shared__ T s_v[TN_ROWS * VP];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+
+  const int u0 = blockIdx.z * (16 * UT_MAX);
+  const int nu = min(NU - u0, 16 * UT_MAX);       // U columns of this block
+  const int ut = (nu + 15) / 16;
+  const int v0 = blockIdx.y * 64;
+  const int nv = min(NV - v0, 64);
+  const long r_beg = (long)blockIdx.x * rows_per_block;
+  const long r_end = min(M, r_beg + rows_per_block);
+
+  f32x4 acc[UT_MAX];
+#pragma unroll
+  for (int t = 0; t < UT_MAX; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ugroups = (ut * 16) / E;  // E-wide channel groups per row in the U slab
+  const int vgroups = 64 / E;
+
+  for (long r0 = r_beg; r0 < r_end; r0 += TN_ROWS) {
+    // stage U slab [32][ut*16] and V slab [32][64]
+    for (int idx = tid; idx < TN_ROWS * ugroups; idx += 256) {
+      const int rr = idx / ugroups, cg = (idx % ugroups) * E;
+      float v[E];
+      load_pro<T, UMODE>(U, r0 + rr, (r0 + rr) < r_end, u0 + cg, NU, v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s_u[rr * UP + cg + e] = from_f32<T>(v[e]);
+    }
+    for (int idx = tid; idx < TN_ROWS * vgroups; idx += 256) {
+      const int rr = idx / vgroups, cg = (idx % vgroups) * E;
+      float v[E];
+      load_pro<T, VMODE>(V, r0 + rr, (r0 + rr) < r_end, v0 + cg, NV, v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s_v[rr * VP + cg + e] = from_f32<T>(v[e]);
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) {
+      // B operand: V[m = 4E*sb + E*q + e][col = 16*wave + j]
+      float bv[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) bv[e] = to_f32(s_v[(4 * E * sb + E * q + e) * VP + 16 * wave + j]);
+      const typename MM::frag bf = MM::pack(bv);
+#pragma unroll
+      for (int t = 0; t < UT_MAX; ++t) {
+        if (t < ut) {
+          float uv[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) uv[e] = to_f32(s_u[(4 * E * sb + E * q + e) * UP + 16 * t + j]);
+          acc[t] = MM::mma(MM::pack(uv), bf, acc[t]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // D[i = 4q + r][jj = j]: i indexes U columns of tile t, jj the V column 16*wave + j
+  const int vc = v0 + 16 * wave + j;
+  if (vc < NV) {
+#pragma unroll
+    for (int t = 0; t < UT_MAX; ++t) {
+      if (t < ut) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int uc = u0 + 16 * t + 4 * q + r;
+          if (uc < NU) atomicAdd(&out[uc * si + vc * sj], acc[t][r]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <typename T>
+static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
+  constexpr int KS = 4 * Mma<T>::EPL;
+  const int Kpad = (K + KS - 1) / KS * KS;
+  const long mtiles = (M + 15) / 16;
+  long blocks = (mtiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  dim3 grid((unsigned)blocks), block(256);
+  const T* W = (const T*)Wp;
+  const bool wide = N > 64;  // keep two 64-channel chunks live when there is more than one
+#define NT_CASE(MODE)                                                                                           \
+  if (wide) hipLaunchKernelGGL((k_gemm_nt<T, MODE, 2>), grid, block, 0, st, A, W, ldw, ep, M, N, K, Kpad);       \
+  else hipLaunchKernelGGL((k_gemm_nt<T, MODE, 1>), grid, block, 0, st, A, W, ldw, ep, M, N, K, Kpad);
+  if (mode == PRO_NONE) { NT_CASE(PRO_NONE) }
+  else if (mode == PRO_BNRELU) { NT_CASE(PRO_BNRELU) }
+  else { NT_CASE(PRO_BNBWD) }
+#undef NT_CASE
+  return check_launch("gemm_nt");
+}
+
+template <typename T>
+static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
+                     hipStream_t st) {
+  const int vt = (NV + 63) / 64, uz = (NU + 16 * UT_MAX - 1) / (16 * UT_MAX);
+  // enough row chunks to fill the chip, but at least 8 slabs of 32 rows per block
+  long chunks = (1024 + (long)vt * uz - 1) / ((long)vt * uz);
+  long rows = (M + chunks - 1) / chunks;
+  if (rows < 8 * TN_ROWS) rows = 8 * TN_ROWS;
+  rows = (rows + TN_ROWS - 1) / TN_ROWS * TN_ROWS;
+  chunks = (M + rows - 1) / rows;
+  dim3 grid((unsigned)chunks, vt, uz), block(256);
+#define TN_CASE(UM, VM) hipLaunchKernelGGL((k_gemm_tn<T, UM, VM>), grid, block, 0, st, U, NU, V, NV, out, si, sj, M, rows)
+  if (umode == PRO_NONE && vmode == PRO_NONE) TN_CASE(PRO_NONE, PRO_NONE);
+  else if (umode == PRO_NONE && vmode == PRO_BNBWD) TN_CASE(PRO_NONE, PRO_BNBWD);
+  else if (umode == PRO_BNBWD && vmode == PRO_BNRELU) TN_CASE(PRO_BNBWD, PRO_BNRELU);
+  else if (umode == PRO_BNRELU && vmode == PRO_BNBWD) TN_CASE(PRO_BNRELU, PRO_BNBWD);
+  else if (umode == PRO_BNBWD && vmode == PRO_NONE) TN_CASE(PRO_BNBWD, PRO_NONE);
+  else { set_error("gemm_tn: unsupported prologue pair (%d,%d)", umode, vmode); return 1; }
+#undef TN_CASE
+  return check_launch("gemm_tn");
+}
+
+static int check_operand(const char* who, const Operand& o, int mode, int C) {
+  ATOMNAS_REQUIRE(o.p1 != nullptr && o.ld1 >= C && o.ld1 % 8 == 0, "%s: bad main stream (ld=%d, C=%d)", who, o.ld1, C);
+  if (mode == PRO_BNRELU) ATOMNAS_REQUIRE(o.c1 && o.c2, "%s: BNRELU prologue needs scale and shift", who);
+  if (mode == PRO_BNBWD) ATOMNAS_REQUIRE(o.p2 && o.ld2 >= C && o.ld2 % 8 == 0 && o.c1 && o.c2 && o.c3, "%s: BNBWD prologue needs x, c1, c2, c3", who);
+  return 0;
+}
+
+}  // namespace atomnas
+
+using namespace atomnas;
+
+// C[M,N] = epilogue( prologue(A)[M,K] x Wp[N,K]^T ).  Wp is the packed weight (storage dtype, row pitch ldw >= K rounded
+// up to the MFMA k-step, rows padded to a multiple of 64, padding zero) produced by atomnas_pack_weights.
+extern "C" int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void* a2, int lda2, const float* ac1, const float* ac2,
+                                  const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, int out_f32,
+                                  const void* add, int ldadd, const void* z, int ldz, const float* zscale, const float* zshift,
+                                  int mask, const float* bias, float* stats, int stat_mode, long M, int N, int K, int dtype,
+                                  void* stream) {
+  ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pw_gemm_nt: bad dtype %d", dtype);
+  ATOMNAS_REQUIRE(a_mode >= PRO_NONE && a_mode <= PRO_BNBWD, "pw_gemm_nt: bad prologue %d", a_mode);
+  ATOMNAS_REQUIRE(M > 0 && N > 0 && K > 0, "pw_gemm_nt: empty shape");
+  ATOMNAS_REQUIRE(wp && c && ldc >= N && ldc % 8 == 0, "pw_gemm_nt: bad output/weights");
+  {
+    const int ks = (dtype == DT_BF16) ? 32 : 4;
+    ATOMNAS_REQUIRE(ldw >= (K + ks - 1) / ks * ks && ldw % 8 == 0, "pw_gemm_nt: packed weight pitch %d too small for K=%d", ldw, K);
+  }
+  ATOMNAS_REQUIRE(!stats || N <= NT_MAX_STAT, "pw_gemm_nt: N=%d too wide for fused statistics", N);
+  ATOMNAS_REQUIRE(!add || (ldadd >= N && ldadd % 8 == 0), "pw_gemm_nt: bad residual pitch");
+  ATOMNAS_REQUIRE(!z || (ldz >= N && ldz % 8 == 0), "pw_gemm_nt: bad z pitch");
+  ATOMNAS_REQUIRE(!mask || (z && zscale && zshift), "pw_gemm_nt: mask needs z, zscale, zshift");
+  ATOMNAS_REQUIRE(stat_mode != STAT_Z || z, "pw_gemm_nt: STAT_Z needs z");
+  Operand A{a, lda, a2, lda2, ac1, ac2, ac3, a_relu};
+  if (check_operand("pw_gemm_nt", A, a_mode, K)) return 1;
+  Epilogue ep{c, ldc, out_f32, add, ldadd, z, ldz, zscale, zshift, mask, bias, stats, stat_mode};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32) return launch_nt<float>(a_mode, A, wp, ldw, ep, M, N, K, st);
+  return launch_nt<bf16_t>(a_mode, A, wp, ldw, ep, M, N, K, st);
+}
+
+// out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]   (fp32 accumulation into `out`, caller zeroes it)
+extern "C" int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void* u2, int ldu2, const float* uc1, const float* uc2,
+                                  const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, const void* v2,
+                                  int ldv2, const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out,
+                                  long si, long sj, long M, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pw_gemm_tn: bad dtype %d", dtype);
+  ATOMNAS_REQUIRE(M > 0 && NU > 0 && NV > 0 && out, "pw_gemm_tn: empty shape");
+  Operand U{u, ldu, u2, ldu2, uc1, uc2, uc3, u_relu};
+  Operand V{v, ldv, v2, ldv2, vc1, vc2, vc3, v_relu};
+  if (check_operand("pw_gemm_tn(U)", U, u_mode, NU)) return 1;
+  if (check_operand("pw_gemm_tn(V)", V, v_mode, NV)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32) return launch_tn<float>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, st);
+  return launch_tn<bf16_t>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, st);
+}

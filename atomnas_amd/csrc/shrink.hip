@@ -1,0 +1,97 @@
+// Dynamic network shrinkage on device: alive masks of the atomic blocks and the index-packed channel repack that
+// rebuilds weights, optimizer state and EMA shadows after a shrink.
+//   masks : train.py:46-63 and utils/prune.py:190-195   mask = |gamma| > thr  (optionally OR / replaced by the EMA gamma)
+//   repack: models/compress_utils.py:31-37 (_mask_along_dim) applied by compress_conv/compress_bn (:73-119) and mirrored
+//           into RMSprop state (utils/rmsprop.py:134-165) and EMA shadows (utils/optim.py:134-153)
+// Masks, counts and gather indices are integer results and are bit-exact with the reference by construction
+// (plain fp32 compare against the threshold rounded to fp32, as torch does for `tensor > python_float`).
+#include "common.h"
+
+namespace atomnas {
+
+struct MaskJob {
+  long off;      // offset of this gamma vector inside the parameter arena (and the EMA arena)
+  int count;     // channels
+  int out_off;   // offset into the mask / index outputs
+};
+
+// one block per job: mask, kept count, and the gather index (ascending channel order) via a block-wide scan
+__global__ __launch_bounds__(256) void k_gamma_mask(const float* __restrict__ p, const float* __restrict__ ema,
+                                                    const MaskJob* __restrict__ jobs, float thr, int mode /*0 cur, 1 cur|ema, 2 ema*/,
+                                                    unsigned char* __restrict__ mask, int* __restrict__ index, int* __restrict__ kept) {
+  __shared__ int s_scan[256];
+  __shared__ int s_base;
+  const MaskJob jb = jobs[blockIdx.x];
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < jb.count; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    int alive = 0;
+    if (c < jb.count) {
+      const bool a = fabsf(p[jb.off + c]) > thr;
+      const bool b = ema ? (fabsf(ema[jb.off + c]) > thr) : false;
+      alive = (mode == 0) ? a : ((mode == 1) ? (a || b) : b);
+      mask[jb.out_off + c] = (unsigned char)alive;
+    }
+    s_scan[threadIdx.x] = alive;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan
+      int v = (threadIdx.x >= o) ? s_scan[threadIdx.x - o] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int incl = s_scan[threadIdx.x];
+    const int base = s_base;
+    if (alive) index[jb.out_off + base + incl - 1] = c;
+    __syncthreads();
+    if (threadIdx.x == 255) s_base = base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) kept[blockIdx.x] = s_base;
+}
+
+// dst[o*dst_os + j*dst_ds + i] = src[o*src_os + idx[j]*src_ds + i],  o < outer, j < n_kept, i < inner (idx == null: identity)
+struct RepackJob {
+  long src_off, dst_off;
+  long src_os, src_ds, dst_os, dst_ds;
+  int outer, n_kept, inner;
+  int idx_off;  // offset into the index buffer, -1 for a plain copy
+};
+
+__global__ __launch_bounds__(256) void k_repack(const float* const* __restrict__ srcs, float* const* __restrict__ dsts, int narenas,
+                                                const RepackJob* __restrict__ jobs, const int* __restrict__ index) {
+  const RepackJob jb = jobs[blockIdx.y];
+  const long total = (long)jb.outer * jb.n_kept * jb.inner;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e % jb.inner);
+    const int j = (int)((e / jb.inner) % jb.n_kept);
+    const int o = (int)(e / ((long)jb.inner * jb.n_kept));
+    const int sj = (jb.idx_off >= 0) ? index[jb.idx_off + j] : j;
+    const long s = jb.src_off + o * jb.src_os + sj * jb.src_ds + i;
+    const long d = jb.dst_off + o * jb.dst_os + j * jb.dst_ds + i;
+    for (int a = 0; a < narenas; ++a) dsts[a][d] = srcs[a][s];
+  }
+}
+
+}  // namespace atomnas
+
+using namespace atomnas;
+
+extern "C" int atomnas_gamma_mask(const float* params, const float* ema, const void* jobs_dev, int njobs, float threshold, int mode,
+                                  unsigned char* mask, int* index, int* kept, void* stream) {
+  ATOMNAS_REQUIRE(params && jobs_dev && njobs > 0 && mask && index && kept, "gamma_mask: bad arguments");
+  ATOMNAS_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || ema), "gamma_mask: mode %d needs the EMA arena", mode);
+  hipLaunchKernelGGL(k_gamma_mask, dim3(njobs), dim3(256), 0, (hipStream_t)stream, params, ema, (const MaskJob*)jobs_dev, threshold, mode,
+                     mask, index, kept);
+  return check_launch("gamma_mask");
+}
+
+extern "C" int atomnas_channel_repack(const void* src_ptrs_dev, const void* dst_ptrs_dev, int narenas, const void* jobs_dev, int njobs,
+                                      const int* index, void* stream) {
+  ATOMNAS_REQUIRE(src_ptrs_dev && dst_ptrs_dev && narenas > 0 && jobs_dev && njobs > 0, "channel_repack: bad arguments");
+  dim3 grid(16, njobs);
+  hipLaunchKernelGGL(k_repack, grid, dim3(256), 0, (hipStream_t)stream, (const float* const*)src_ptrs_dev, (float* const*)dst_ptrs_dev,
+                     narenas, (const RepackJob*)jobs_dev, index);
+  return check_launch("channel_repack");
+}

@@ -1,0 +1,156 @@
+"""Thin tensor-level wrappers over the C ABI (pointers + shapes out of torch tensors, current torch stream).
+
+Activations are 2-D tensors [M, ld] (NHWC flattened, ld % 8 == 0) of dtype float32 or bfloat16.
+Nothing here computes on the host; a missing library or a failed launch raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+PRO_NONE, PRO_BNRELU, PRO_BNBWD = 0, 1, 2
+STAT_NONE, STAT_SQ, STAT_Z = 0, 1, 2
+HYP_LR, HYP_RHO, HYP_EMA_DECAY, HYP_GRAD_SCALE = 0, 1, 2, 3
+
+
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.bfloat16:
+        return 1
+    raise TypeError("activations must be float32 or bfloat16, got %s" % dtype)
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "activation must be [M, ld] with unit channel stride"
+    return t.stride(0)
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _chk_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.AtomnasHipError("atomnas_amd kernels run on the GPU only (got a %s tensor)" % t.device)
+
+
+def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, N, H, W, C, k, stride):
+    _chk_cuda(x, y, w_taps)
+    call("atomnas_dwconv_fwd", _p(x), _ld(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(y), _ld(y),
+         _p(stats), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
+
+
+def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, dw, stats, N, H, W, C, k, stride):
+    _chk_cuda(g, x, h, w_taps)
+    call("atomnas_dwconv_bwd", _p(g), _ld(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _p(c1), _p(c2), _p(c3), _p(x), _ld(x),
+         _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _p(dw), _p(stats), N, H, W, C, k,
+         stride, dt_code(x.dtype), _stream())
+
+
+def gemm_nt(a, wp, c, M, N, K, a_mode=PRO_NONE, a2=None, ac1=None, ac2=None, ac3=None, a_relu=False, add=None, z=None,
+            zscale=None, zshift=None, mask=False, bias=None, stats=None, stat_mode=STAT_NONE):
+    _chk_cuda(a, wp, c)
+    out_f32 = 1 if (c.dtype == torch.float32 and a.dtype != torch.float32) else 0
+    call("atomnas_pw_gemm_nt", a_mode, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, _p(ac1), _p(ac2), _p(ac3),
+         int(a_relu), _p(wp), wp.stride(0), _p(c), _ld(c), out_f32, _p(add), _ld(add) if add is not None else 0, _p(z),
+         _ld(z) if z is not None else 0, _p(zscale), _p(zshift), int(mask), _p(bias), _p(stats), stat_mode, M, N, K,
+         dt_code(a.dtype), _stream())
+
+
+def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc2=None, uc3=None, u_relu=False, v_mode=PRO_NONE,
+            v2=None, vc1=None, vc2=None, vc3=None, v_relu=False):
+    _chk_cuda(u, v, out)
+    call("atomnas_pw_gemm_tn", u_mode, _p(u), _ld(u), _p(u2), _ld(u2) if u2 is not None else 0, _p(uc1), _p(uc2), _p(uc3),
+         int(u_relu), NU, v_mode, _p(v), _ld(v), _p(v2), _ld(v2) if v2 is not None else 0, _p(vc1), _p(vc2), _p(vc3), int(v_relu),
+         NV, _p(out), si, sj, M, dt_code(u.dtype), _stream())
+
+
+def bn_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, save_mean,
+                    save_invstd, C):
+    call("atomnas_bn_finalize_fwd", _p(stats), float(count), _p(gamma), _p(beta), eps, -1.0 if momentum is None else momentum,
+         _p(running_mean), _p(running_var), _p(nbt), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), C, _stream())
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, scale, shift, C):
+    call("atomnas_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(scale), _p(shift), C, _stream())
+
+
+def bn_finalize_bwd(stats2, count, gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C):
+    call("atomnas_bn_finalize_bwd", _p(stats2), float(count), _p(gamma), _p(save_mean), _p(save_invstd), _p(rho_ptr), _p(penalty),
+         _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), C, _stream())
+
+
+def bn_apply(x, scale, shift, relu, res, y, M, C):
+    call("atomnas_bn_apply", _p(x), _ld(x), _p(scale), _p(shift), int(relu), _p(res), _ld(res) if res is not None else 0, _p(y),
+         _ld(y), M, C, dt_code(x.dtype), _stream())
+
+
+def bn_act_pool(x, scale, shift, relu, pooled, keep, drop_p, seed, step_ptr, N, HW, C):
+    call("atomnas_bn_act_pool", _p(x), _ld(x), _p(scale), _p(shift), int(relu), _p(pooled), _ld(pooled), _p(keep), float(drop_p),
+         int(seed) & 0xFFFFFFFFFFFFFFFF, _p(step_ptr), N, HW, C, dt_code(x.dtype), _stream())
+
+
+def pool_act_bwd(dpooled, keep, drop_p, x, scale, shift, relu, g, stats2, N, HW, C):
+    call("atomnas_pool_act_bwd", _p(dpooled), _ld(dpooled), _p(keep), float(drop_p), _p(x), _ld(x), _p(scale), _p(shift), int(relu),
+         _p(g), _ld(g), _p(stats2), N, HW, C, dt_code(x.dtype), _stream())
+
+
+def act_bwd_stats(dy, z, scale, shift, relu, g, stats2, M, C):
+    call("atomnas_act_bwd_stats", _p(dy), _ld(dy), _p(z), _ld(z), _p(scale), _p(shift), int(relu), _p(g),
+         _ld(g) if g is not None else 0, _p(stats2), M, C, dt_code(dy.dtype), _stream())
+
+
+def im2col_stem(img, col, N, H, W):
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    call("atomnas_im2col_stem", _p(img), _p(col), _ld(col), N, H, W, dt_code(col.dtype), _stream())
+
+
+def ce_smooth(logits, target, eps, B, K, loss_per_sample, loss_sum, dlogits, gscale, topk):
+    assert logits.dtype == torch.float32 and target.dtype == torch.int64
+    call("atomnas_ce_smooth", _p(logits), _ld(logits), _p(target), float(eps), B, K, _p(loss_per_sample), _p(loss_sum), _p(dlogits),
+         _ld(dlogits) if dlogits is not None else 0, float(gscale), _p(topk),
+         dt_code(dlogits.dtype) if dlogits is not None else 0, _stream())
+
+
+def colsum(x, out, M, C):
+    call("atomnas_colsum", _p(x), _ld(x), _p(out), M, C, dt_code(x.dtype), _stream())
+
+
+def fused_rmsprop_ema(p, g, sq, buf, ema, wd_chunk, n, hyper, alpha, eps, eps_inside_sqrt, momentum):
+    call("atomnas_fused_rmsprop_ema", _p(p), _p(g), _p(sq), _p(buf), _p(ema), _p(wd_chunk), n, _p(hyper), float(alpha), float(eps),
+         int(eps_inside_sqrt), float(momentum), _stream())
+
+
+def ema_update(shadow, x, n, hyper):
+    call("atomnas_ema_update", _p(shadow), _p(x), n, _p(hyper), _stream())
+
+
+def weighted_norm(p, coef_chunk, n, use_abs, out):
+    call("atomnas_weighted_norm", _p(p), _p(coef_chunk), n, int(use_abs), _p(out), _stream())
+
+
+def pack_weights(arena, packbuf, jobs_dev, njobs, dtype):
+    call("atomnas_pack_weights", _p(arena), _p(packbuf), _p(jobs_dev), njobs, dt_code(dtype), _stream())
+
+
+def gamma_mask(params, ema, jobs_dev, njobs, threshold, mode, mask, index, kept):
+    call("atomnas_gamma_mask", _p(params), _p(ema), _p(jobs_dev), njobs, float(threshold), mode, _p(mask), _p(index), _p(kept),
+         _stream())
+
+
+def channel_repack(src_ptrs_dev, dst_ptrs_dev, narenas, jobs_dev, njobs, index):
+    call("atomnas_channel_repack", _p(src_ptrs_dev), _p(dst_ptrs_dev), narenas, _p(jobs_dev), njobs, _p(index), _stream())

@@ -1,0 +1,149 @@
+/*
+ * atomnas_hip.h -- C ABI of libatomnas_hip.so, the gfx950 (MI355X) kernels behind the AtomNAS supernet-training hot path.
+ *
+ * The reference (meijieru/AtomNAS) has no native code: every FLOP of this path runs inside ATen.  Each entry point
+ * below therefore replaces the ATen call(s) that a reference Python line makes; the line is cited as
+ * <reference file>:<line>.  A reference maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - plain C: device pointers, ints, floats; no torch / C++ types.  `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success, non-zero on failure; atomnas_last_error() returns the message.
+ *   - nothing is allocated or freed by the library; workspaces are caller-owned.  Functions are asynchronous on `stream`,
+ *     re-entrant per stream, and contain no host synchronisation (they can be captured into a hipGraph).
+ *   - activations are NHWC viewed as [M = N*H*W rows][C channels] with an explicit channel pitch ld (elements);
+ *     ld is a multiple of 8 and channels C..ld-1 hold zeros.  dtype: 0 = fp32, 1 = bf16 storage (fp32 accumulation).
+ *   - per-channel fp32 vectors (scale, shift, c1..c3, gamma, ...) are readable up to C rounded up to 8.
+ *   - "stats" outputs are accumulated atomically into zero-initialised fp32 buffers of shape [2][C].
+ */
+#ifndef ATOMNAS_HIP_H
+#define ATOMNAS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATOMNAS_DT_F32 0
+#define ATOMNAS_DT_BF16 1
+
+/* prologue applied to a GEMM operand while it is loaded */
+#define ATOMNAS_PRO_NONE 0   /* a                                   */
+#define ATOMNAS_PRO_BNRELU 1 /* act(a * c1[k] + c2[k])              BatchNorm apply (+ReLU) of the producer */
+#define ATOMNAS_PRO_BNBWD 2  /* c1[k]*a + c2[k]*a2 + c3[k]          BatchNorm backward, a = masked grad, a2 = raw activation */
+
+/* statistics taken in a GEMM epilogue */
+#define ATOMNAS_STAT_NONE 0
+#define ATOMNAS_STAT_SQ 1 /* [sum c, sum c^2]   -> forward BatchNorm of the output           */
+#define ATOMNAS_STAT_Z 2  /* [sum c, sum c*z]   -> backward BatchNorm of the tensor z        */
+
+/* indices into the device-resident hyper-parameter vector (float[4]) */
+#define ATOMNAS_HYP_LR 0
+#define ATOMNAS_HYP_RHO 1
+#define ATOMNAS_HYP_EMA_DECAY 2
+#define ATOMNAS_HYP_GRAD_SCALE 3
+
+const char* atomnas_last_error(void);
+int atomnas_abi_version(void);
+int atomnas_runtime_version(void);
+
+/* ---- depthwise k x k convolution: nn.Conv2d(C, C, k, stride, (k-1)/2, groups=C, bias=False)
+ *      models/mobilenet_base.py:330-336 (built through ConvBNReLU :120-142); k in {3,5,7}, stride in {1,2}.
+ * forward: y = dwconv(act(x*in_scale+in_shift));  stats += [sum y, sum y^2]   (in_scale == NULL: x used as is)
+ *   w: fp32 taps [k*k][ldw] (tap-major, see atomnas_pack_weights mode 2). */
+int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
+                       void* y, int ldy, float* stats, int N, int H, int W, int C, int k, int stride, int dtype, void* stream);
+
+/* backward (input gradient and weight gradient in one pass over the data):
+ *   dYraw = c1*g + c2*yraw + c3  (yraw == NULL: dYraw = g)      -- BatchNorm backward of the BN after the conv
+ *   h     = dwconv^T(dYraw) * [x*in_scale+in_shift > 0]         -- ReLU backward of the producer (if in_relu)
+ *   dw[c][k*k] += corr(act(x*in_scale+in_shift), dYraw)         -- torch layout [C,1,k,k], fp32, atomically accumulated
+ *   stats += [sum h, sum h*x]                                   -- for the producer's BatchNorm backward */
+int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
+                       const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
+                       void* h, int ldh, float* dw, float* stats, int N, int H, int W, int C, int k, int stride, int dtype,
+                       void* stream);
+
+/* ---- pointwise (1x1) convolutions as MFMA GEMMs: models/mobilenet_base.py:316-320 (expand), :338 (project),
+ *      models/mobilenet_supernet.py:148-153 (last conv), :160-163 (classifier); branches concatenated (:378).
+ * C[M,N] = epilogue( prologue(A)[M,K] x Wp[N,K]^T )
+ *   prologue: a_mode (ATOMNAS_PRO_*), second stream a2, coefficient vectors ac1..ac3, a_relu for BNRELU
+ *   wp: packed weights, storage dtype, [N rounded up to 64][ldw], ldw >= K rounded up to 32 (bf16) / 4 (fp32), padding zero
+ *   epilogue: + bias[n]; + add[m][n]; if mask: c = 0 where z*zscale+zshift <= 0; store (fp32 if out_f32);
+ *             stats per stat_mode on the stored value. */
+int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void* a2, int lda2, const float* ac1, const float* ac2,
+                       const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, int out_f32, const void* add,
+                       int ldadd, const void* z, int ldz, const float* zscale, const float* zshift, int mask, const float* bias,
+                       float* stats, int stat_mode, long M, int N, int K, int dtype, void* stream);
+
+/* weight gradient: out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]  (fp32, atomically accumulated) */
+int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void* u2, int ldu2, const float* uc1, const float* uc2,
+                       const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, const void* v2, int ldv2,
+                       const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out, long si, long sj, long M,
+                       int dtype, void* stream);
+
+/* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;
+ *      kwargs from models/mobilenet_supernet.py:95-98; calibration mode utils/common.py:214-226.
+ * finalize forward: stats=[sum x, sum x^2] over `count` elements -> scale = gamma*invstd, shift = beta - mean*scale,
+ *   save_mean / save_invstd for backward, running statistics update (momentum < 0: cumulative average, counter bumped). */
+int atomnas_bn_finalize_fwd(const float* stats, double count, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
+                            float* save_mean, float* save_invstd, int C, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                           float* scale, float* shift, int C, void* stream);
+/* finalize backward: stats2=[sum g, sum g*x] -> dgamma (+ rho*penalty*sign(gamma), utils/prune.py:161-167), dbeta and the
+ *   coefficients of dx = c1*g + c2*x + c3.  rho is read from device memory (rho_ptr, may be NULL). */
+int atomnas_bn_finalize_bwd(const float* stats2, double count, const float* gamma, const float* save_mean, const float* save_invstd,
+                            const float* rho_ptr, const float* penalty, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
+                            int C, void* stream);
+/* y = act(x*scale+shift) (+ res): the shared pw_bn + residual of a block, models/mobilenet_base.py:379-381 */
+int atomnas_bn_apply(const void* x, int ldx, const float* scale, const float* shift, int relu, const void* res, int ldres, void* y,
+                     int ldy, long M, int C, int dtype, void* stream);
+/* pooled[n][c] = dropout(mean_hw act(x*scale+shift)): last ConvBNReLU activation + AvgPool2d + Dropout,
+ *   models/mobilenet_supernet.py:148-163 (keep mask written for backward; step_ptr decorrelates iterations) */
+int atomnas_bn_act_pool(const void* x, int ldx, const float* scale, const float* shift, int relu, void* pooled, int ldp,
+                        unsigned char* keep, float drop_p, unsigned long long seed, const long long* step_ptr, int N, int HW, int C,
+                        int dtype, void* stream);
+int atomnas_pool_act_bwd(const void* dpooled, int ldp, const unsigned char* keep, float drop_p, const void* x, int ldx,
+                         const float* scale, const float* shift, int relu, void* g, int ldg, float* stats2, int N, int HW, int C,
+                         int dtype, void* stream);
+/* g = dy * [z*scale+shift > 0] (scale == NULL: no mask);  stats2 += [sum g, sum g*z];  g may be NULL (statistics only) */
+int atomnas_act_bwd_stats(const void* dy, int lddy, const void* z, int ldz, const float* scale, const float* shift, int relu, void* g,
+                          int ldg, float* stats2, long M, int C, int dtype, void* stream);
+
+/* ---- stem and loss
+ * im2col of the 3x3 stride-2 stem conv (models/mobilenet_supernet.py:126-132): img NCHW fp32 -> col [N*Ho*Wo][ld>=32] */
+int atomnas_im2col_stem(const float* img, void* col, int ld, int N, int H, int W, int dtype, void* stream);
+/* CrossEntropyLabelSmooth (utils/optim.py:180-207) + top-1/top-5 hit counters (common.py:73-79), no host sync.
+ * dlogits = d(mean loss)/dlogits * gscale, storage dtype, columns K..ldd-1 zeroed. */
+int atomnas_ce_smooth(const float* logits, int ldl, const long long* target, float eps, int B, int K, float* loss_per_sample,
+                      float* loss_sum, void* dlogits, int ldd, float gscale, int* topk_correct, int dtype, void* stream);
+int atomnas_colsum(const void* x, int ld, float* out, long M, int C, int dtype, void* stream);
+
+/* ---- optimizer tail on flat fp32 arenas (one launch for all parameters)
+ * L2 'mnas' (utils/optim.py:226-243) + RMSprop.step (utils/rmsprop.py:70-132) + EMA (utils/optim.py:54-65):
+ *   g' = g*hyper[GRAD_SCALE] + wd_chunk[i/256]*p;  sq = alpha*sq + (1-alpha)*g'^2;  avg = sqrt(sq+eps) | sqrt(sq)+eps;
+ *   buf = momentum*buf + g'/avg;  p -= hyper[LR]*buf;  ema = d*ema + (1-d)*p with d = hyper[EMA_DECAY] (d < 0: skip). */
+int atomnas_fused_rmsprop_ema(float* p, const float* g, float* sq, float* buf, float* ema, const float* wd_chunk, long n,
+                              const float* hyper, double alpha, double eps, int eps_inside_sqrt, double momentum, void* stream);
+int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper, void* stream);
+/* out += sum_i coef[i/256] * (p_i^2 | |p_i|): values of the L2 / L1 regularisers for logging (train.py:206-208) */
+int atomnas_weighted_norm(const float* p, const float* coef_chunk, long n, int use_abs, float* out, void* stream);
+/* re-pack fp32 master weights into kernel layouts; jobs_dev: device array of
+ *   struct { long src_off, dst_off; int rows, cols, src_ld, dst_ld, c_off, mode; }  (mode 0 [N][K], 1 transposed, 2 depthwise taps) */
+int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream);
+
+/* ---- dynamic shrink
+ * alive masks |gamma| > thr (train.py:46-63, utils/prune.py:190-195): mode 0 current, 1 current|EMA, 2 EMA only.
+ *   jobs_dev: struct { long off; int count; int out_off; };  outputs: mask bytes, ascending kept-channel indices, kept counts */
+int atomnas_gamma_mask(const float* params, const float* ema, const void* jobs_dev, int njobs, float threshold, int mode,
+                       unsigned char* mask, int* index, int* kept, void* stream);
+/* gather kept channels (models/compress_utils.py:31-37) for a list of tensors, applied to `narenas` arenas at once
+ *   (parameters, RMSprop square_avg / momentum_buffer -- utils/rmsprop.py:134-165, EMA shadow -- utils/optim.py:134-153):
+ *   jobs_dev: struct { long src_off, dst_off, src_os, src_ds, dst_os, dst_ds; int outer, n_kept, inner, idx_off; } */
+int atomnas_channel_repack(const void* src_ptrs_dev, const void* dst_ptrs_dev, int narenas, const void* jobs_dev, int njobs,
+                           const int* index, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATOMNAS_HIP_H */

@@ -1,0 +1,209 @@
+"""Kernel-level parity (GPU): every C-ABI entry point against a float64 torch restatement of the same op.
+
+Inputs are first rounded to the storage dtype, the reference computes in float64, and the kernel result must agree to the
+tolerance of one output rounding (bf16) or accumulation order (fp32).  Integer results (masks, indices, counts) are exact.
+"""
+import itertools
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from kutil import assert_close, cvec, from_act, pad8, rounded, to_act, tol
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from atomnas_amd import ops
+    return ops
+
+
+def fresh(M, C, dtype):
+    """output buffer as the allocator hands it out: padding channels zero (kernels never write non-zero there); the valid
+    region is poisoned so that unwritten elements are caught"""
+    b = torch.zeros(M, pad8(C), dtype=dtype, device="cuda")
+    b[:, :C] = 7.0
+    return b
+
+
+def taps(w):  # [C,1,k,k] -> [k*k][pad8(C)] fp32 on GPU
+    C, _, k, _ = w.shape
+    t = torch.zeros(k * k, pad8(C), dtype=torch.float32, device="cuda")
+    t[:, :C] = w.reshape(C, k * k).t().float().cuda()
+    return t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,stride", list(itertools.product([3, 5, 7], [1, 2])))
+@pytest.mark.parametrize("N,C,H,W", [(2, 1, 7, 7), (3, 13, 15, 15), (2, 32, 8, 14), (1, 70, 28, 28)])
+def test_dwconv_fwd(gpu_lib, dtype, k, stride, N, C, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1000 * k + 10 * stride + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.3
+    for fuse in (False, True):
+        xb = to_act(x, dtype)
+        xr = rounded(x, dtype)
+        xa = torch.relu(xr * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)) if fuse else xr
+        yref = F.conv2d(xa, w.double(), None, stride, (k - 1) // 2, 1, C)
+        Ho, Wo = yref.shape[2:]
+        yb = fresh(N * Ho * Wo, C, dtype)
+        stats = torch.zeros(2, C, dtype=torch.float32, device="cuda")
+        ops.dwconv_fwd(xb, cvec(sc) if fuse else None, cvec(sh) if fuse else None, fuse, taps(w), yb, stats, N, H, W, C, k, stride)
+        torch.cuda.synchronize()
+        y = from_act(yb, N, Ho, Wo, C)
+        assert_close("y", y, yref, **tol(dtype))
+        assert float(yb[:, C:].abs().max() if pad8(C) > C else 0) == 0.0
+        assert_close("sum", stats[0], y.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+        assert_close("sumsq", stats[1], (y * y).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,stride", list(itertools.product([3, 5, 7], [1, 2])))
+@pytest.mark.parametrize("N,C,H,W", [(2, 1, 7, 7), (3, 13, 15, 15), (2, 32, 8, 14), (1, 70, 28, 28)])
+def test_dwconv_bwd(gpu_lib, dtype, k, stride, N, C, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2000 * k + 10 * stride + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.3
+    P = (k - 1) // 2
+    Ho, Wo = (H + 2 * P - k) // stride + 1, (W + 2 * P - k) // stride + 1
+    gup = torch.randn(N, C, Ho, Wo, generator=g)
+    yraw = torch.randn(N, C, Ho, Wo, generator=g)
+    c1 = torch.rand(C, generator=g) + 0.5
+    c2 = torch.randn(C, generator=g) * 0.1
+    c3 = torch.randn(C, generator=g) * 0.1
+    for fuse in (False, True):
+        v = lambda t: t.double().view(1, -1, 1, 1)
+        xr = rounded(x, dtype).requires_grad_(True)
+        pre = xr * v(sc) + v(sh) if fuse else xr
+        xa = torch.relu(pre) if fuse else pre
+        wd = w.double().requires_grad_(True)
+        y = F.conv2d(xa, wd, None, stride, P, 1, C)
+        dy = v(c1) * rounded(gup, dtype) + v(c2) * rounded(yraw, dtype) + v(c3) if fuse else rounded(gup, dtype)
+        xa.retain_grad()
+        (y * dy).sum().backward()
+        href = xa.grad * (pre > 0).double() if fuse else xa.grad
+        hb = fresh(N * H * W, C, dtype)
+        dw = torch.zeros(C, k * k, dtype=torch.float32, device="cuda")
+        stats = torch.zeros(2, C, dtype=torch.float32, device="cuda")
+        ops.dwconv_bwd(to_act(gup, dtype), to_act(yraw, dtype) if fuse else None, cvec(c1) if fuse else None,
+                       cvec(c2) if fuse else None, cvec(c3) if fuse else None, to_act(x, dtype), cvec(sc) if fuse else None,
+                       cvec(sh) if fuse else None, fuse, taps(w), hb, dw, stats, N, H, W, C, k, stride)
+        torch.cuda.synchronize()
+        h = from_act(hb, N, H, W, C)
+        t = tol(dtype)
+        assert_close("h", h, href, t["rtol"], t["atol"] * 4)
+        assert_close("dw", dw.reshape(C, 1, k, k), wd.grad, rtol=2e-3, atol=2e-3 * float(wd.grad.abs().max()))
+        assert_close("sum_h", stats[0], h.sum((0, 2, 3)), rtol=1e-4, atol=2e-3)
+        assert_close("sum_hx", stats[1], (h * rounded(x, dtype)).sum((0, 2, 3)), rtol=1e-4, atol=2e-3)
+
+
+def pack_w(w, dtype, transposed=False):
+    """[N,K] fp32 -> packed [pad64(N)][pad32(K)] storage dtype (or the transpose)"""
+    if transposed:
+        w = w.t()
+    n, k = w.shape
+    buf = torch.zeros((n + 63) // 64 * 64, (k + 31) // 32 * 32, dtype=dtype, device="cuda")
+    buf[:n, :k] = w.to(dtype).cuda()
+    return buf
+
+
+GEMM_SHAPES = [(100, 24, 16), (1000, 432, 24), (333, 40, 139), (64, 16, 432), (257, 100, 40), (50, 7, 3), (4096, 320, 1152)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("variant", ["plain_stats", "bnrelu_stats", "bnbwd_mask_statz", "bnbwd_add_statz", "bias_f32"])
+def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 7 * N + 13 * K)
+    r = lambda *s: torch.randn(*s, generator=g)
+    A, A2, W = r(M, K), r(M, K), r(N, K) / K ** 0.5
+    c1, c2, c3 = torch.rand(K, generator=g) + 0.5, r(K) * 0.2, r(K) * 0.2
+    Z, ADD = r(M, N), r(M, N)
+    zs, zh = torch.rand(N, generator=g) + 0.5, r(N) * 0.3
+    bias = r(N)
+    rd = lambda t: t.to(dtype).double()
+    act2d = lambda t, c: torch.cat([t.to(dtype), torch.zeros(t.shape[0], pad8(c) - c, dtype=dtype)], 1).cuda()
+    Wd = rd(W)
+    kw = {}
+    out_dtype = dtype
+    if variant == "plain_stats":
+        Aeff = rd(A)
+        kw = dict(stat_mode=ops.STAT_SQ)
+    elif variant == "bnrelu_stats":
+        Aeff = torch.relu(rd(A) * c1.double() + c2.double())
+        kw = dict(a_mode=ops.PRO_BNRELU, ac1=cvec(c1), ac2=cvec(c2), a_relu=True, stat_mode=ops.STAT_SQ)
+    else:
+        Aeff = rd(A) if variant == "bias_f32" else c1.double() * rd(A) + c2.double() * rd(A2) + c3.double()
+        if variant != "bias_f32":
+            kw = dict(a_mode=ops.PRO_BNBWD, a2=act2d(A2, K), ac1=cvec(c1), ac2=cvec(c2), ac3=cvec(c3), stat_mode=ops.STAT_Z)
+    if dtype == torch.bfloat16:
+        Aeff = Aeff.to(torch.bfloat16).double()  # the prologue result is rounded to bf16 before the MFMA
+    Cref = Aeff @ Wd.t()
+    if variant == "bnbwd_mask_statz":
+        Cref = Cref * ((rd(Z) * zs.double() + zh.double()) > 0)
+        kw.update(z=act2d(Z, N), zscale=cvec(zs), zshift=cvec(zh), mask=True)
+    elif variant == "bnbwd_add_statz":
+        Cref = Cref + rd(ADD)
+        kw.update(z=act2d(Z, N), add=act2d(ADD, N))
+    elif variant == "bias_f32":
+        Cref = Cref + bias.double()
+        kw.update(bias=cvec(bias))
+        out_dtype = torch.float32
+    Cb = fresh(M, N, out_dtype)
+    stats = torch.zeros(2, N, dtype=torch.float32, device="cuda") if "stat_mode" in kw else None
+    ops.gemm_nt(act2d(A, K), pack_w(W, dtype), Cb, M, N, K, stats=stats, **kw)
+    torch.cuda.synchronize()
+    Cg = Cb[:, :N].double().cpu()
+    scale = float(Cref.abs().max())
+    t = tol(out_dtype if variant == "bias_f32" and dtype == torch.float32 else dtype)
+    assert_close("C", Cg, Cref, t["rtol"], t["atol"] * max(1.0, scale))
+    if pad8(N) > N:
+        assert float(Cb[:, N:].abs().max()) == 0.0
+    if stats is not None:
+        s1 = Cg.sum(0)
+        s2 = (Cg * Cg).sum(0) if kw["stat_mode"] == ops.STAT_SQ else (Cg * rd(Z)).sum(0)
+        assert_close("s1", stats[0], s1, rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale))
+        assert_close("s2", stats[1], s2, rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale) ** 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,NU,NV", [(100, 24, 16), (1000, 24, 432), (3000, 40, 139), (700, 320, 1152), (257, 700, 40), (50, 3, 7)])
+@pytest.mark.parametrize("variant", ["none_none", "none_bnbwd", "bnbwd_bnrelu"])
+def test_gemm_tn(gpu_lib, dtype, M, NU, NV, variant):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 7 * NU + 13 * NV)
+    r = lambda *s: torch.randn(*s, generator=g)
+    U, U2, V, V2 = r(M, NU), r(M, NU), r(M, NV), r(M, NV)
+    uc = [torch.rand(NU, generator=g) + 0.5, r(NU) * 0.2, r(NU) * 0.2]
+    vc = [torch.rand(NV, generator=g) + 0.5, r(NV) * 0.2, r(NV) * 0.2]
+    rd = lambda t: t.to(dtype).double()
+    act2d = lambda t, c: torch.cat([t.to(dtype), torch.zeros(t.shape[0], pad8(c) - c, dtype=dtype)], 1).cuda()
+    kw = {}
+    Ue, Ve = rd(U), rd(V)
+    if variant == "none_bnbwd":
+        Ve = vc[0].double() * rd(V) + vc[1].double() * rd(V2) + vc[2].double()
+        kw = dict(v_mode=ops.PRO_BNBWD, v2=act2d(V2, NV), vc1=cvec(vc[0]), vc2=cvec(vc[1]), vc3=cvec(vc[2]))
+    elif variant == "bnbwd_bnrelu":
+        Ue = uc[0].double() * rd(U) + uc[1].double() * rd(U2) + uc[2].double()
+        Ve = torch.relu(rd(V) * vc[0].double() + vc[1].double())
+        kw = dict(u_mode=ops.PRO_BNBWD, u2=act2d(U2, NU), uc1=cvec(uc[0]), uc2=cvec(uc[1]), uc3=cvec(uc[2]),
+                  v_mode=ops.PRO_BNRELU, vc1=cvec(vc[0]), vc2=cvec(vc[1]), v_relu=True)
+    if dtype == torch.bfloat16:
+        Ue, Ve = Ue.to(torch.bfloat16).double(), Ve.to(torch.bfloat16).double()
+    ref = Ue.t() @ Ve  # [NU, NV]
+    # write the transposed layout out[j][i] (si = 1, sj = NU) as well as the natural one
+    for si, sj, view in ((NV, 1, lambda o: o), (1, NU, lambda o: o.t())):
+        out = torch.zeros(NU, NV, dtype=torch.float32, device="cuda") if si == NV else torch.zeros(NV, NU, dtype=torch.float32, device="cuda")
+        ops.gemm_tn(act2d(U, NU), NU, act2d(V, NV), NV, out, si, sj, M, **kw)
+        torch.cuda.synchronize()
+        assert_close("out", view(out), ref, rtol=2e-3 if dtype == torch.bfloat16 else 2e-4, atol=2e-3 * float(ref.abs().max()))
