@@ -13,9 +13,9 @@ vp, i32, i64, f32, f64, u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, cty
 
 # name -> argument ctypes (all return int status)
 SIGNATURES = {
-    "atomnas_dwconv_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "atomnas_dwconv_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "atomnas_dwconv_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
-                           i32, i32, i32, vp],
+                           i32, i32, i32, i32, vp],
     "atomnas_pw_gemm_nt": [i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp,
                            vp, i32, i64, i32, i32, i32, vp],
     "atomnas_pw_gemm_tn": [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i64,
@@ -33,6 +33,8 @@ SIGNATURES = {
     "atomnas_fused_rmsprop_ema": [vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, i32, f64, vp],
     "atomnas_ema_update": [vp, vp, i64, vp, vp],
     "atomnas_weighted_norm": [vp, vp, i64, i32, vp, vp],
+    "atomnas_reg_grad": [vp, vp, vp, i32, i32, vp, vp, vp],
+    "atomnas_reg_value": [vp, vp, i32, i32, vp, f32, vp, vp],
     "atomnas_pack_weights": [vp, vp, vp, i32, i32, vp],
     "atomnas_gamma_mask": [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp],
     "atomnas_channel_repack": [vp, vp, i32, vp, i32, vp, vp],
@@ -72,8 +74,26 @@ def load():
     return lib
 
 
+# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every call is bracketed by events on the
+# launch stream and (name, tag, start_event, end_event) is appended.  `tag` is set by the caller through profile_tag().
+PROFILE = None
+_TAG = [None]
+
+
+def profile_tag(tag):
+    _TAG[0] = tag
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if PROFILE is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        PROFILE.append((name, _TAG[0], e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise AtomnasHipError("%s failed (rc=%d): %s" % (name, rc, lib.atomnas_last_error().decode()))

@@ -33,13 +33,11 @@ __global__ void k_bn_finalize_fwd(const float* __restrict__ stats, float inv_cou
   if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
   if (running_mean) {
     float m = momentum;
-    if (m < 0.f) m = 1.0f / (float)(nbt[0] + 1);  // cumulative moving average; nbt is bumped by thread 0 below
+    if (m < 0.f) m = 1.0f / (float)(nbt[0] + 1);  // cumulative moving average; the caller bumps the counter afterwards
     running_mean[c] = (1.f - m) * running_mean[c] + m * mean;
     running_var[c] = (1.f - m) * running_var[c] + m * var * unbias;
   }
 }
-
-__global__ void k_bump(long long* nbt) { nbt[0] += 1; }
 
 __global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                  const float* __restrict__ rv, float eps, float* __restrict__ scale, float* __restrict__ shift, int C,
@@ -77,9 +75,9 @@ __global__ void k_bn_finalize_bwd(const float* __restrict__ stats2, float inv_co
       const float s = (g > 0.f) ? 1.f : ((g < 0.f) ? -1.f : 0.f);
       l1 = rho_ptr[0] * penalty[c] * s;
     }
-    dgamma[c] = dg + l1;
+    dgamma[c] += dg + l1;  // gradients accumulate into the (zeroed) arena, like autograd's AccumulateGrad
   }
-  if (dbeta) dbeta[c] = db;
+  if (dbeta) dbeta[c] += db;
 }
 
 // y = act(x*scale + shift) (+ res), 8 channels per thread
@@ -295,7 +293,6 @@ extern "C" int atomnas_bn_finalize_fwd(const float* stats, double count, const f
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 255) / 256), dim3(256), 0, st, stats, (float)(1.0 / count), unbias, gamma, beta,
                      eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C, Cpad);
-  if (num_batches_tracked && running_mean) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, st, num_batches_tracked);
   return check_launch("bn_finalize_fwd");
 }
 

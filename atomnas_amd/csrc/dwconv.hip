@@ -34,7 +34,7 @@ template <typename T, int K, int S, int CV, int TW>
 __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int ldx, const float* __restrict__ in_scale,
                                                     const float* __restrict__ in_shift, int in_relu,
                                                     const float* __restrict__ w, int ldw, T* __restrict__ y, int ldy,
-                                                    float* __restrict__ stats, DwGeom g) {
+                                                    float* __restrict__ stats, int stat_ld, DwGeom g) {
   constexpr int P = (K - 1) / 2;
   constexpr int IW = (TW - 1) * S + K;
   __shared__ float s_red[256 * 2];  // [cvb*CV][2] block partials of sum / sumsq (cvb*CV <= 256)
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
       const int c = blockIdx.y * g.cvb * CV + i;
       if (c < g.C) {
         atomicAdd(&stats[c], s_red[i * 2 + 0]);
-        atomicAdd(&stats[g.C + c], s_red[i * 2 + 1]);
+        atomicAdd(&stats[stat_ld + c], s_red[i * 2 + 1]);
       }
     }
   }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const T* __restrict__ gup, i
                                                     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                     int in_relu, const float* __restrict__ w, int ldw,
                                                     T* __restrict__ h, int ldh, float* __restrict__ dw /*[C][K*K]*/,
-                                                    float* __restrict__ stats /*[2][C]: sum h, sum h*x*/, DwGeom g) {
+                                                    float* __restrict__ stats /*[2][stat_ld]: sum h, sum h*x*/, int stat_ld, DwGeom g) {
   constexpr int P = (K - 1) / 2;
   constexpr int KK = K * K;
   constexpr int RELMIN = fdiv(-P, S);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const T* __restrict__ gup, i
     if (t < KK) {
       if (dw) atomicAdd(&dw[(long)c * KK + t], v);
     } else if (stats) {
-      atomicAdd(&stats[(t - KK) * g.C + c], v);
+      atomicAdd(&stats[(long)(t - KK) * stat_ld + c], v);
     }
   }
 }
@@ -364,7 +364,7 @@ static DwGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int CV, int 
 
 template <typename T, int K, int S>
 static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y,
-                      int ldy, float* stats, int N, int H, int W, int C, hipStream_t st) {
+                      int ldy, float* stats, int stat_ld, int N, int H, int W, int C, hipStream_t st) {
   constexpr int CV = 2, TW = 4;
   const int P = (K - 1) / 2;
   const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
@@ -372,14 +372,14 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
   const int cvecs = (C + CV - 1) / CV;
   dim3 grid((unsigned)(((long)N * g.nchunks * g.spr + g.pb - 1) / g.pb), (cvecs + g.cvb - 1) / g.cvb);
   hipLaunchKernelGGL((k_dwconv_fwd<T, K, S, CV, TW>), grid, dim3(256), 0, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy,
-                     stats, g);
+                     stats, stat_ld, g);
   return check_launch("dwconv_fwd");
 }
 
 template <typename T, int K, int S>
 static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
                       const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h,
-                      int ldh, float* dw, float* stats, int N, int H, int W, int C, hipStream_t st) {
+                      int ldh, float* dw, float* stats, int stat_ld, int N, int H, int W, int C, hipStream_t st) {
   constexpr int CV = 2, TW = 4;
   const int P = (K - 1) / 2;
   const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
@@ -387,7 +387,7 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   const int cvecs = (C + CV - 1) / CV;
   dim3 grid((unsigned)(((long)N * g.nchunks * g.spr + g.pb - 1) / g.pb), (cvecs + g.cvb - 1) / g.cvb);
   hipLaunchKernelGGL((k_dwconv_bwd<T, K, S, CV, TW>), grid, dim3(256), 0, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2,
-                     c3, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)h, ldh, dw, stats, g);
+                     c3, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)h, ldh, dw, stats, stat_ld, g);
   return check_launch("dwconv_bwd");
 }
 
@@ -415,8 +415,8 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
 using namespace atomnas;
 
 extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu,
-                                  const float* w, int ldw, void* y, int ldy, float* stats, int N, int H, int W, int C, int k,
-                                  int stride, int dtype, void* stream) {
+                                  const float* w, int ldw, void* y, int ldy, float* stats, int stat_ld, int N, int H, int W, int C,
+                                  int k, int stride, int dtype, void* stream) {
   ATOMNAS_REQUIRE(x && w && y, "dwconv_fwd: null pointer");
   ATOMNAS_REQUIRE((k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2), "dwconv_fwd: unsupported k=%d stride=%d", k, stride);
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_fwd: bad dtype %d", dtype);
@@ -424,14 +424,15 @@ extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale,
   ATOMNAS_REQUIRE(ldx >= C && ldy >= C && ldw >= C && ldx % 2 == 0 && ldy % 2 == 0 && ldw % 2 == 0, "dwconv_fwd: bad pitch");
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_fwd: scale/shift must come together");
   hipStream_t st = (hipStream_t)stream;
-  DW_DISPATCH(launch_fwd, x, ldx, in_scale, in_shift, in_relu, w, ldw, y, ldy, stats, N, H, W, C, st);
+  ATOMNAS_REQUIRE(!stats || stat_ld >= C, "dwconv_fwd: statistics pitch %d < C=%d", stat_ld, C);
+  DW_DISPATCH(launch_fwd, x, ldx, in_scale, in_shift, in_relu, w, ldw, y, ldy, stats, stat_ld, N, H, W, C, st);
   return 1;
 }
 
 extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2,
                                   const float* c3, const void* x, int ldx, const float* in_scale, const float* in_shift,
-                                  int in_relu, const float* w, int ldw, void* h, int ldh, float* dw, float* stats, int N, int H,
-                                  int W, int C, int k, int stride, int dtype, void* stream) {
+                                  int in_relu, const float* w, int ldw, void* h, int ldh, float* dw, float* stats, int stat_ld, int N,
+                                  int H, int W, int C, int k, int stride, int dtype, void* stream) {
   ATOMNAS_REQUIRE(g && x && w && h, "dwconv_bwd: null pointer");
   ATOMNAS_REQUIRE((k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2), "dwconv_bwd: unsupported k=%d stride=%d", k, stride);
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_bwd: bad dtype %d", dtype);
@@ -441,7 +442,8 @@ extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int 
   ATOMNAS_REQUIRE(!yraw || (c1 && c2 && c3 && ldyr >= C && ldyr % 2 == 0), "dwconv_bwd: yraw needs c1,c2,c3 and a valid pitch");
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_bwd: scale/shift must come together");
   hipStream_t st = (hipStream_t)stream;
-  DW_DISPATCH(launch_bwd, g, ldg, yraw, ldyr, c1, c2, c3, x, ldx, in_scale, in_shift, in_relu, w, ldw, h, ldh, dw, stats, N, H, W,
-              C, st);
+  ATOMNAS_REQUIRE(!stats || stat_ld >= C, "dwconv_bwd: statistics pitch %d < C=%d", stat_ld, C);
+  DW_DISPATCH(launch_bwd, g, ldg, yraw, ldyr, c1, c2, c3, x, ldx, in_scale, in_shift, in_relu, w, ldw, h, ldh, dw, stats, stat_ld,
+              N, H, W, C, st);
   return 1;
 }

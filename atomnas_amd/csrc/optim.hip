@@ -136,3 +136,64 @@ extern "C" int atomnas_pack_weights(const float* arena, void* packbuf, const voi
   else hipLaunchKernelGGL(k_pack<bf16_t>, grid, dim3(256), 0, st, arena, packbuf, (const PackJob*)jobs_dev);
   return check_launch("pack_weights");
 }
+
+// ---- regularisers as gradient contributions (so that p.grad after backward() is what the reference's autograd leaves
+// there): cal_l2_loss (utils/optim.py:210-249) contributes wd*p, cal_bn_l1_loss (utils/prune.py:161-167) contributes
+// rho*penalty*sign(gamma).  One launch over a job table instead of ~2.2k ATen dispatches forward and ~3.3k backward.
+namespace atomnas {
+struct RegJob {
+  long off;
+  int count;
+  float coef;
+};
+
+__global__ __launch_bounds__(256) void k_reg_grad(const float* __restrict__ p, float* __restrict__ g, const RegJob* __restrict__ jobs,
+                                                  int use_sign, const float* __restrict__ mult_ptr, const float* __restrict__ go_ptr) {
+  const RegJob jb = jobs[blockIdx.y];
+  float m = jb.coef;
+  if (mult_ptr) m *= mult_ptr[0];
+  if (go_ptr) m *= go_ptr[0];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.count; i += gridDim.x * 256) {
+    const float v = p[jb.off + i];
+    const float d = use_sign ? ((v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f)) : v;
+    g[jb.off + i] += m * d;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reg_value(const float* __restrict__ p, const RegJob* __restrict__ jobs, int use_abs,
+                                                   const float* __restrict__ mult_ptr, float post_scale, float* __restrict__ out) {
+  __shared__ float s_part[4];
+  const RegJob jb = jobs[blockIdx.y];
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.count; i += gridDim.x * 256) {
+    const float v = p[jb.off + i];
+    acc += use_abs ? fabsf(v) : v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = jb.coef * post_scale;
+    if (mult_ptr) m *= mult_ptr[0];
+    atomicAdd(out, m * (s_part[0] + s_part[1] + s_part[2] + s_part[3]));
+  }
+}
+}  // namespace atomnas
+
+// g[off+i] += coef * mult * go * (use_sign ? sign(p) : p) for every job {long off; int count; float coef;}
+extern "C" int atomnas_reg_grad(const float* p, float* g, const void* jobs_dev, int njobs, int use_sign, const float* mult_ptr,
+                                const float* grad_out_ptr, void* stream) {
+  ATOMNAS_REQUIRE(p && g && jobs_dev && njobs > 0, "reg_grad: bad arguments");
+  hipLaunchKernelGGL(atomnas::k_reg_grad, dim3(8, njobs), dim3(256), 0, (hipStream_t)stream, p, g, (const atomnas::RegJob*)jobs_dev,
+                     use_sign, mult_ptr, grad_out_ptr);
+  return atomnas::check_launch("reg_grad");
+}
+
+// out += post_scale * mult * sum_jobs coef * sum_i (use_abs ? |p_i| : p_i^2)
+extern "C" int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_abs, const float* mult_ptr,
+                                 float post_scale, float* out, void* stream) {
+  ATOMNAS_REQUIRE(p && out && jobs_dev && njobs > 0, "reg_value: bad arguments");
+  hipLaunchKernelGGL(atomnas::k_reg_value, dim3(8, njobs), dim3(256), 0, (hipStream_t)stream, p, (const atomnas::RegJob*)jobs_dev,
+                     use_abs, mult_ptr, post_scale, out);
+  return atomnas::check_launch("reg_value");
+}

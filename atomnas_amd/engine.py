@@ -1,0 +1,126 @@
+"""The training iteration of the hot path as one replayable hipGraph (train.py:165-236 of the reference, per process).
+
+    zero_grad -> forward -> CE-smooth mean (+ L2 + L1) -> backward -> [gradient all-reduce] -> RMSprop -> EMA
+
+Everything between the barriers is device work issued from Python once, captured with torch.cuda.graph (the HIP kernels
+are launched on the capturing stream through the C ABI, so they become graph nodes) and replayed every iteration.  Values
+that change per iteration (lr, rho, EMA decay) are staged through a 4-float device vector, inputs through static buffers.
+With a process group, the gradient arena is all-reduced by RCCL between two graphs (backward | optimizer).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops, runtime
+from .utils import optim as aopt
+from .utils import prune as aprune
+
+
+class TrainStep:
+
+    def __init__(self, model, optimizer, ema=None, prune_info=None, weight_decay=1e-5, wd_method='mnas', label_smoothing=0.1,
+                 batch_size=256, image_size=224, use_graph=True, process_group=None, world_size=1):
+        self.model, self.optimizer, self.ema, self.prune_info = model, optimizer, ema, prune_info
+        self.weight_decay, self.wd_method = weight_decay, wd_method
+        self.use_graph = use_graph
+        self.world_size = world_size
+        self.pg = process_group
+        dev = next(model.parameters()).device
+        self.mgr = runtime.manager_of(model)
+        self.mgr.attach_optimizer(optimizer)
+        optimizer._mgr = self.mgr
+        if ema is not None:
+            ema.attach(self.mgr)
+        self.mgr.ensure()
+        self.criterion = aopt.CrossEntropyLabelSmooth(model.num_classes, label_smoothing, reduction='none')
+        self.x = torch.zeros(batch_size, 3, image_size, image_size, dtype=torch.float32, device=dev)
+        self.y = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=dev)   # CE, L2, L1 of the last step
+        self.g_fwd_bwd = self.g_opt = None
+        self._version = -1
+        self.global_step = 0
+
+    # ---- pieces
+    def _prune_weights(self):
+        if self.prune_info is None or len(self.prune_info.weight) == 0:
+            return [], []
+        table = dict(self.model.named_parameters())
+        return [table[n] for n in self.prune_info.weight], self.prune_info.penalty
+
+    def _fwd_bwd(self):
+        mgr = self.mgr
+        mgr.zero_grad()
+        self.criterion.topk_correct = None if self.criterion.topk_correct is None else self.criterion.topk_correct.zero_()
+        logits = self.model(self.x)
+        loss = self.criterion(logits, self.y).mean()
+        l2 = aopt.cal_l2_loss(self.model, self.weight_decay, self.wd_method)
+        w, pen = self._prune_weights()
+        if w:
+            rho = float(mgr.hyper_host[ops.HYP_RHO])
+            l1 = aprune.cal_bn_l1_loss(w, pen, rho)
+            total = loss + l2 + l1
+            self.loss[2] = l1.detach()
+        else:
+            total = loss + l2
+        total.backward()
+        self.loss[0] = loss.detach()
+        self.loss[1] = l2.detach()
+
+    def _opt(self):
+        mgr = self.mgr
+        if self.world_size > 1:
+            mgr.G.mul_(1.0 / self.world_size)
+        self.optimizer.launch(mgr)
+        if self.ema is not None:
+            self.ema.launch(mgr)
+        mgr.step_counter.add_(1)
+
+    def _capture(self):
+        mgr = self.mgr
+        mgr.ensure()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):   # warm-up outside capture (allocator pools, lazy initialisation)
+            for _ in range(2):
+                self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_fwd_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd_bwd):
+            self._fwd_bwd()
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            self._opt()
+        self._version = mgr.version
+
+    # ---- public
+    def set_batch(self, x, y):
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+
+    def step(self, lr=None, rho=0.0, ema_decay=None):
+        """One iteration on the current static batch.  lr defaults to the optimizer's group lr."""
+        mgr = self.mgr
+        if mgr.dirty or self._version != mgr.version:
+            mgr.ensure()
+            self.g_fwd_bwd = self.g_opt = None
+        h = mgr.hyper_host
+        h[ops.HYP_LR] = float(self.optimizer.param_groups[0]['lr'] if lr is None else lr)
+        h[ops.HYP_RHO] = float(rho)
+        if self.ema is not None:
+            h[ops.HYP_EMA_DECAY] = float(self.ema.momentum_at(self.global_step + 1) if ema_decay is None else ema_decay)
+        else:
+            h[ops.HYP_EMA_DECAY] = -1.0
+        mgr.push_hyper()
+        if self.use_graph:
+            if self.g_fwd_bwd is None:
+                self._capture()
+            self.g_fwd_bwd.replay()
+            if self.world_size > 1:
+                dist.all_reduce(mgr.G, group=self.pg)
+            self.g_opt.replay()
+        else:
+            self._fwd_bwd()
+            if self.world_size > 1:
+                dist.all_reduce(mgr.G, group=self.pg)
+            self._opt()
+        self.global_step += 1

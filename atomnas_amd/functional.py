@@ -1,0 +1,425 @@
+"""Forward / backward executors of the hot path: sequences of C-ABI kernel launches over arena views, wrapped in
+torch.autograd.Function so that the reference's `loss.backward()` drives them.
+
+Activations cross module boundaries as ordinary torch tensors of logical shape [N, C, H, W] in channels_last memory
+format (i.e. NHWC in HBM) and the model's compute dtype; inside a block the 6x-expanded tensors are [M, HT] buffers.
+Parameter gradients are written straight into the gradient arena (p.grad views) instead of being returned to autograd.
+
+Reference call sites: InvertedResidualChannels.forward (models/mobilenet_base.py:371-382), ConvBNReLU (:120-142),
+MobileNetV2.forward (models/mobilenet_supernet.py:169-173), CrossEntropyLabelSmooth.forward (utils/optim.py:199-207).
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .ops import PRO_BNBWD, PRO_BNRELU, PRO_NONE, STAT_SQ, STAT_Z
+from .runtime import pad8
+
+ACT_NONE, ACT_RELU = 0, 1
+
+
+def act_code(module):
+    """Maps the activation module a ConvBNReLU holds to the kernels' activation flag."""
+    if module is None:
+        return ACT_NONE
+    if isinstance(module, nn.ReLU):
+        return ACT_RELU
+    raise NotImplementedError("activation %s is not supported by the HIP path yet (ReLU only)" % type(module).__name__)
+
+
+# ---------------------------------------------------------------------------------------------- layout plumbing
+def to_2d(x, dtype):
+    """[N,C,H,W] tensor -> ([M, C] NHWC view/copy in `dtype`, (N, H, W, C))."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D activation, got shape %s" % (tuple(x.shape),))
+    if not x.is_cuda:
+        raise ops._lib.AtomnasHipError("atomnas_amd runs on the GPU only: input tensor is on %s" % x.device)
+    N, C, H, W = x.shape
+    if C % 8 != 0:
+        raise ValueError("block input channels must be a multiple of 8, got %d" % C)
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    x = x.contiguous(memory_format=torch.channels_last)
+    return x.permute(0, 2, 3, 1).reshape(N * H * W, C), (N, H, W, C)
+
+
+def to_4d(y2d, N, H, W, C):
+    return y2d.view(N, H, W, C).permute(0, 3, 1, 2)
+
+
+def _f32(n, dev, zero=False):
+    return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
+
+
+# ---------------------------------------------------------------------------------------------- batch norm helpers
+class BNState:
+    """Per-call coefficients of one (possibly branch-fused) BatchNorm: scale/shift for the apply, mean/invstd for backward."""
+    __slots__ = ("scale", "shift", "mean", "invstd")
+
+
+def bn_forward_coeffs(bn, stats, count, dev):
+    """bn: dict of arena views (gamma, beta, rm, rv, C, mods).  Uses batch statistics when the BN modules are in training
+    mode (updating running statistics with their momentum; momentum None = cumulative average), running statistics otherwise."""
+    C = bn["C"]
+    Cp = pad8(C)
+    st = BNState()
+    st.scale, st.shift = _f32(Cp, dev), _f32(Cp, dev)
+    mod = bn["mods"][0]
+    eps = mod.eps
+    if mod.training or not mod.track_running_stats:
+        st.mean, st.invstd = _f32(Cp, dev), _f32(Cp, dev)
+        track = mod.track_running_stats
+        ops.bn_finalize_fwd(stats, count, bn["gamma"], bn["beta"], eps, mod.momentum, bn["rm"] if track else None,
+                            bn["rv"] if track else None, mod.num_batches_tracked if track else None, st.scale, st.shift, st.mean,
+                            st.invstd, C)
+        if track:
+            bn["mgr"].bn_trained = True
+    else:
+        st.mean = st.invstd = None
+        ops.bn_eval_coeffs(bn["gamma"], bn["beta"], bn["rm"], bn["rv"], eps, st.scale, st.shift, C)
+    return st
+
+
+def bn_uses_batch_stats(bn):
+    mod = bn["mods"][0]
+    return mod.training or not mod.track_running_stats
+
+
+def bn_backward_coeffs(bn, st, stats2, count, dev):
+    """-> (c1, c2, c3) with dx = c1*g + c2*x + c3; writes dgamma / dbeta into the gradient arena."""
+    C = bn["C"]
+    Cp = pad8(C)
+    c1, c2, c3 = _f32(Cp, dev), _f32(Cp, dev), _f32(Cp, dev)
+    if st.mean is None:
+        raise RuntimeError("backward through a BatchNorm in eval mode is not supported")
+    ops.bn_finalize_bwd(stats2, count, bn["gamma"], st.mean, st.invstd, None, None, bn["dgamma"], bn["dbeta"], c1, c2, c3, C)
+    return c1, c2, c3
+
+
+# ---------------------------------------------------------------------------------------------- atomic block
+def block_forward(pl, x2d, N, H, W, need_grad):
+    """InvertedResidualChannels.forward on arena views.  Returns (out2d, saved) -- saved is None when need_grad is False."""
+    dev, T = x2d.device, x2d.dtype
+    M = N * H * W
+    s = pl.stride
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    M2 = N * Ho * Wo
+    HT = pl.HT
+    act = pl.act
+    sv = {}
+    if pl.expand:
+        bs = bn_uses_batch_stats(pl.bne)
+        E = torch.empty(M, HT, dtype=T, device=dev)
+        stE = _f32(2 * HT, dev, zero=True) if bs else None
+        ops.gemm_nt(x2d, pl.We_pack, E, M, HT, pl.inp, stats=stE, stat_mode=STAT_SQ if bs else 0)
+        bE = bn_forward_coeffs(pl.bne, stE, M, dev)
+    else:
+        E, bE = x2d, None
+    bsd = bn_uses_batch_stats(pl.bnd)
+    D = torch.empty(M2, HT, dtype=T, device=dev)
+    stD = _f32(2 * HT, dev, zero=True) if bsd else None
+    for i in range(pl.nb):
+        o, c = pl.seg[i], pad8(pl.hid[i])
+        xin = E[:, o:] if pl.expand else E
+        ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], D[:, o:],
+                       stD[o:] if bsd else None, HT, N, H, W, c, pl.ks[i], s)
+    bD = bn_forward_coeffs(pl.bnd, stD, M2, dev)
+    bsp = bn_uses_batch_stats(pl.bnp)
+    Pr = torch.empty(M2, pl.oup, dtype=T, device=dev)
+    stP = _f32(2 * pl.oup, dev, zero=True) if bsp else None
+    ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=bool(act), stats=stP,
+                stat_mode=STAT_SQ if bsp else 0)
+    bP = bn_forward_coeffs(pl.bnp, stP, M2, dev)
+    out = torch.empty(M2, pl.oup, dtype=T, device=dev)
+    ops.bn_apply(Pr, bP.scale, bP.shift, False, x2d if pl.res else None, out, M2, pl.oup)
+    if need_grad:
+        sv = dict(x=x2d, E=E, D=D, P=Pr, bE=bE, bD=bD, bP=bP, dims=(N, H, W, Ho, Wo))
+        return out, sv
+    return out, None
+
+
+def block_backward(pl, sv, G):
+    """G = dL/d(out) [M2, oup] -> dL/dx [M, inp]; parameter gradients go to the gradient arena."""
+    dev, T = G.device, G.dtype
+    N, H, W, Ho, Wo = sv["dims"]
+    M, M2 = N * H * W, N * Ho * Wo
+    HT, s, act = pl.HT, pl.stride, pl.act
+    x2d, E, D, Pr, bE, bD, bP = sv["x"], sv["E"], sv["D"], sv["P"], sv["bE"], sv["bD"], sv["bP"]
+    # shared pw_bn backward: statistics pass over (G, P), then coefficients
+    st2P = _f32(2 * pl.oup, dev, zero=True)
+    ops.act_bwd_stats(G, Pr, None, None, False, None, st2P, M2, pl.oup)
+    p1, p2, p3 = bn_backward_coeffs(pl.bnp, bP, st2P, M2, dev)
+    # projection weight gradient: dWp[n][k] = sum_m dP[m][n] * act(bn(D))[m][k]
+    ops.gemm_tn(G, pl.oup, D, HT, pl.Wp_grad, HT, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
+                vc1=bD.scale, vc2=bD.shift, v_relu=bool(act))
+    # projection input gradient, masked by the depthwise ReLU, with the depthwise-BN backward statistics
+    g = torch.empty(M2, HT, dtype=T, device=dev)
+    st2D = _f32(2 * HT, dev, zero=True)
+    ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
+                zshift=bD.shift, mask=bool(act), stats=st2D, stat_mode=STAT_Z)
+    d1, d2, d3 = bn_backward_coeffs(pl.bnd, bD, st2D, M2, dev)
+    # depthwise backward per branch
+    if pl.expand:
+        h = torch.empty(M, HT, dtype=T, device=dev)
+        st2E = _f32(2 * HT, dev, zero=True)
+    else:
+        h = torch.zeros(M, pl.inp, dtype=T, device=dev) if pl.nb > 1 else torch.empty(M, pl.inp, dtype=T, device=dev)
+        st2E = None
+    for i in range(pl.nb):
+        o, c = pl.seg[i], pad8(pl.hid[i])
+        if pl.expand:
+            ops.dwconv_bwd(g[:, o:], D[:, o:], d1[o:], d2[o:], d3[o:], E[:, o:], bE.scale[o:], bE.shift[o:], act, pl.taps[i],
+                           h[:, o:], pl.Wd_grad[i], st2E[o:], HT, N, H, W, c, pl.ks[i], s)
+        else:
+            if pl.nb > 1:
+                raise NotImplementedError("non-expanding block with more than one branch")
+            ops.dwconv_bwd(g[:, o:], D[:, o:], d1[o:], d2[o:], d3[o:], E, None, None, 0, pl.taps[i], h, pl.Wd_grad[i], None, 0, N, H,
+                           W, c, pl.ks[i], s)
+    if not pl.expand:
+        if pl.res:
+            h = h + G
+        return h
+    e1, e2, e3 = bn_backward_coeffs(pl.bne, bE, st2E, M, dev)
+    # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k])
+    ops.gemm_tn(x2d, pl.inp, h, HT, pl.We_grad, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=E, vc1=e1, vc2=e2, vc3=e3)
+    # expand input gradient (+ residual branch)
+    Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
+    ops.gemm_nt(h, pl.WeT_pack, Gx, M, pl.inp, HT, a_mode=PRO_BNBWD, a2=E, ac1=e1, ac2=e2, ac3=e3, add=G if pl.res else None)
+    return Gx
+
+
+class BlockFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, pl):
+        T = pl.mgr.compute_dtype
+        x2d, (N, H, W, C) = to_2d(x, T)
+        if C != pl.inp:
+            raise ValueError("block %s expects %d input channels, got %d" % (pl.name, pl.inp, C))
+        need = torch.is_grad_enabled() or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        out, sv = block_forward(pl, x2d, N, H, W, True)
+        ctx.pl, ctx.sv = pl, sv
+        Ho, Wo = sv["dims"][3], sv["dims"][4]
+        return to_4d(out, N, Ho, Wo, pl.oup)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pl, sv = ctx.pl, ctx.sv
+        G, _ = to_2d(gout, pl.mgr.compute_dtype)
+        N, H, W, _, _ = sv["dims"]
+        gx = block_backward(pl, sv, G)
+        ctx.sv = None
+        return to_4d(gx, N, H, W, pl.inp), None, None
+
+
+def run_block(pl, x, anchor):
+    if pl.nb == 0:
+        return x
+    if torch.is_grad_enabled() and (x.requires_grad or anchor.requires_grad):
+        return BlockFunction.apply(x, anchor, pl)
+    T = pl.mgr.compute_dtype
+    x2d, (N, H, W, C) = to_2d(x, T)
+    out, _ = block_forward(pl, x2d, N, H, W, False)
+    s = pl.stride
+    return to_4d(out, N, (H - 1) // s + 1, (W - 1) // s + 1, pl.oup)
+
+
+# ---------------------------------------------------------------------------------------------- ConvBNReLU (stem / 1x1 / depthwise)
+def convbn_forward(pl, x, need_grad):
+    """Stand-alone ConvBNReLU: stem 3x3/s2 on an NCHW fp32 image (im2col + GEMM), 1x1 conv, or depthwise conv."""
+    mgr = pl.mgr
+    T = mgr.compute_dtype
+    dev = x.device
+    act = pl.act
+    sv = {}
+    if pl.groups == 1 and pl.k == 3:
+        if pl.cin != 3 or pl.stride != 2:
+            raise NotImplementedError("dense 3x3 convolution other than the 3-channel stride-2 stem")
+        N, _, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        M = N * Ho * Wo
+        col = torch.empty(M, 32, dtype=T, device=dev)
+        ops.im2col_stem(x.float().contiguous(), col, N, H, W)
+        a2d, K = col, 27
+        sv["kind"] = "stem"
+    elif pl.groups == 1 and pl.k == 1:
+        a2d, (N, H, W, C) = to_2d(x, T)
+        Ho, Wo, M, K = H, W, N * H * W, pl.cin
+        sv["kind"] = "pw"
+    else:
+        a2d, (N, H, W, C) = to_2d(x, T)
+        s = pl.stride
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        M = N * Ho * Wo
+        sv["kind"] = "dw"
+    bs = bn_uses_batch_stats(pl.bn)
+    Cp = pad8(pl.cout)
+    Y = torch.empty(M, Cp, dtype=T, device=dev) if sv["kind"] != "dw" else torch.zeros(M, Cp, dtype=T, device=dev)
+    st = _f32(2 * pl.cout, dev, zero=True) if bs else None
+    if sv["kind"] == "dw":
+        ops.dwconv_fwd(a2d, None, None, 0, pl.taps, Y, st, pl.cout, N, H, W, pl.cout, pl.k, pl.stride)
+    else:
+        ops.gemm_nt(a2d, pl.W_pack, Y, M, pl.cout, K, stats=st, stat_mode=STAT_SQ if bs else 0)
+    b = bn_forward_coeffs(pl.bn, st, M, dev)
+    out = torch.empty(M, Cp, dtype=T, device=dev)
+    ops.bn_apply(Y, b.scale, b.shift, bool(act), None, out, M, pl.cout)
+    if need_grad:
+        sv.update(a=a2d, Y=Y, b=b, dims=(N, H, W, Ho, Wo), K=K if sv["kind"] != "dw" else 0)
+    return out, (N, Ho, Wo), sv
+
+
+def convbn_backward(pl, sv, G, need_input_grad):
+    dev, T = G.device, G.dtype
+    N, H, W, Ho, Wo = sv["dims"]
+    M = N * Ho * Wo
+    act = pl.act
+    Y, b, a2d = sv["Y"], sv["b"], sv["a"]
+    g = torch.empty_like(Y)
+    st2 = _f32(2 * pl.cout, dev, zero=True)
+    ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, bool(act), g, st2, M, pl.cout)
+    c1, c2, c3 = bn_backward_coeffs(pl.bn, b, st2, M, dev)
+    if sv["kind"] == "dw":
+        h = torch.zeros(N * H * W, pad8(pl.cout), dtype=T, device=dev)
+        ops.dwconv_bwd(g, Y, c1, c2, c3, a2d, None, None, 0, pl.taps, h, pl.W_grad, None, 0, N, H, W, pl.cout, pl.k, pl.stride)
+        return h
+    K = sv["K"]
+    # dW[n][k] = sum_m dY[m][n] * a[m][k]
+    ops.gemm_tn(a2d, K, g, pl.cout, pl.W_grad, 1, K, M, v_mode=PRO_BNBWD, v2=Y, vc1=c1, vc2=c2, vc3=c3)
+    if not need_input_grad or sv["kind"] == "stem":
+        return None
+    Gx = torch.empty(M, pad8(K), dtype=T, device=dev)
+    ops.gemm_nt(g, pl.WT_pack, Gx, M, K, pl.cout, a_mode=PRO_BNBWD, a2=Y, ac1=c1, ac2=c2, ac3=c3)
+    return Gx
+
+
+class ConvBNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, pl):
+        out, (N, Ho, Wo), sv = convbn_forward(pl, x, True)
+        ctx.pl, ctx.sv = pl, sv
+        ctx.x_needs = x.requires_grad
+        return to_4d(out[:, :pl.cout] if out.shape[1] != pl.cout else out, N, Ho, Wo, pl.cout)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pl, sv = ctx.pl, ctx.sv
+        G, _ = to_2d(gout, pl.mgr.compute_dtype)
+        gx = convbn_backward(pl, sv, G, ctx.x_needs)
+        ctx.sv = None
+        N, H, W, _, _ = sv["dims"]
+        if gx is None:
+            return None, None, None
+        cin = pl.cin
+        return to_4d(gx[:, :cin] if gx.shape[1] != cin else gx, N, H, W, cin), None, None
+
+
+def run_convbn(pl, x, anchor):
+    if pl.cout % 8 != 0:
+        raise ValueError("ConvBNReLU output channels must be a multiple of 8 on the HIP path, got %d" % pl.cout)
+    if torch.is_grad_enabled() and (x.requires_grad or anchor.requires_grad):
+        return ConvBNFunction.apply(x, anchor, pl)
+    out, (N, Ho, Wo), _ = convbn_forward(pl, x, False)
+    return to_4d(out, N, Ho, Wo, pl.cout)
+
+
+# ---------------------------------------------------------------------------------------------- fused tail: last conv + pool + dropout + fc
+def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
+    """features[-2] (1x1 ConvBNReLU) -> AvgPool2d(H) -> squeeze -> Dropout -> Linear, without materialising the activated map."""
+    mgr = lp.mgr
+    T = mgr.compute_dtype
+    dev = x.device
+    a2d, (N, H, W, C) = to_2d(x, T)
+    M = N * H * W
+    act = lp.act
+    bs = bn_uses_batch_stats(lp.bn)
+    L = torch.empty(M, lp.cout, dtype=T, device=dev)
+    st = _f32(2 * lp.cout, dev, zero=True) if bs else None
+    ops.gemm_nt(a2d, lp.W_pack, L, M, lp.cout, lp.cin, stats=st, stat_mode=STAT_SQ if bs else 0)
+    b = bn_forward_coeffs(lp.bn, st, M, dev)
+    pooled = torch.empty(N, lp.cout, dtype=T, device=dev)
+    p = float(drop_p) if training else 0.0
+    keep = torch.empty(N, lp.cout, dtype=torch.uint8, device=dev) if p > 0 else None
+    ops.bn_act_pool(L, b.scale, b.shift, bool(act), pooled, keep, p, seed, step_ptr, N, H * W, lp.cout)
+    Kc = fp.cout
+    logits = torch.empty(N, pad8(Kc), dtype=torch.float32, device=dev)
+    ops.gemm_nt(pooled, fp.W_pack, logits, N, Kc, fp.cin, bias=fp.bias)
+    sv = None
+    if need_grad:
+        sv = dict(a=a2d, L=L, b=b, pooled=pooled, keep=keep, p=p, dims=(N, H, W))
+    return logits[:, :Kc], sv
+
+
+def tail_backward(lp, fp, sv, dlogits):
+    """dlogits [N, K] (any float dtype) -> gradient wrt the tail input [M, cin]."""
+    mgr = lp.mgr
+    T = mgr.compute_dtype
+    dev = dlogits.device
+    N, H, W = sv["dims"]
+    M, HW = N * H * W, H * W
+    Kc = fp.cout
+    act = lp.act
+    dl = torch.zeros(N, pad8(Kc), dtype=T, device=dev)
+    dl[:, :Kc] = dlogits
+    # classifier
+    ops.gemm_tn(dl, Kc, sv["pooled"], fp.cin, fp.W_grad, fp.cin, 1, N)
+    if fp.bias_grad is not None:
+        ops.colsum(dl, fp.bias_grad, N, Kc)
+    dpooled = torch.empty(N, fp.cin, dtype=T, device=dev)
+    ops.gemm_nt(dl, fp.WT_pack, dpooled, N, fp.cin, Kc)
+    # dropout + average pool + ReLU backward, with the last BN's backward statistics
+    L, b = sv["L"], sv["b"]
+    gL = torch.empty(M, lp.cout, dtype=T, device=dev)
+    st2 = _f32(2 * lp.cout, dev, zero=True)
+    ops.pool_act_bwd(dpooled, sv["keep"], sv["p"], L, b.scale, b.shift, bool(act), gL, st2, N, HW, lp.cout)
+    c1, c2, c3 = bn_backward_coeffs(lp.bn, b, st2, M, dev)
+    ops.gemm_tn(sv["a"], lp.cin, gL, lp.cout, lp.W_grad, 1, lp.cin, M, v_mode=PRO_BNBWD, v2=L, vc1=c1, vc2=c2, vc3=c3)
+    Gx = torch.empty(M, lp.cin, dtype=T, device=dev)
+    ops.gemm_nt(gL, lp.WT_pack, Gx, M, lp.cin, lp.cout, a_mode=PRO_BNBWD, a2=L, ac1=c1, ac2=c2, ac3=c3)
+    return Gx
+
+
+class TailFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, lp, fp, drop_p, training, seed, step_ptr):
+        logits, sv = tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, True)
+        ctx.lp, ctx.fp, ctx.sv = lp, fp, sv
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lp, fp, sv = ctx.lp, ctx.fp, ctx.sv
+        gx = tail_backward(lp, fp, sv, dlogits)
+        ctx.sv = None
+        N, H, W = sv["dims"]
+        return to_4d(gx, N, H, W, lp.cin), None, None, None, None, None, None, None
+
+
+def run_tail(lp, fp, x, anchor, drop_p, training, seed, step_ptr):
+    if torch.is_grad_enabled() and (x.requires_grad or anchor.requires_grad):
+        return TailFunction.apply(x, anchor, lp, fp, drop_p, training, seed, step_ptr)
+    logits, _ = tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, False)
+    return logits
+
+
+# ---------------------------------------------------------------------------------------------- loss
+class CESmoothFunction(torch.autograd.Function):
+    """Per-sample label-smoothed cross entropy; also leaves top-1 / top-5 hit counts in `topk` (int32[2], accumulated)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, eps, topk):
+        if not logits.is_cuda:
+            raise ops._lib.AtomnasHipError("CrossEntropyLabelSmooth runs on the GPU only")
+        B, K = logits.shape
+        lg = logits.float()
+        if lg.stride(1) != 1:
+            lg = lg.contiguous()
+        loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+        dl = torch.empty(B, K, dtype=torch.float32, device=logits.device)
+        # gscale = B: dl holds d(loss_i)/d(logits_i) (the 1/B of a mean reduction comes in through grad_output)
+        ops.ce_smooth(lg, target, eps, B, K, loss, None, dl, float(B), topk)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dl,) = ctx.saved_tensors
+        return dl * gout.unsqueeze(1), None, None, None

@@ -48,17 +48,17 @@ def _chk_cuda(*ts):
             raise _lib.AtomnasHipError("atomnas_amd kernels run on the GPU only (got a %s tensor)" % t.device)
 
 
-def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, N, H, W, C, k, stride):
+def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, stat_ld, N, H, W, C, k, stride):
     _chk_cuda(x, y, w_taps)
     call("atomnas_dwconv_fwd", _p(x), _ld(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(y), _ld(y),
-         _p(stats), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
+         _p(stats), stat_ld, N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
 
-def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, dw, stats, N, H, W, C, k, stride):
+def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, dw, stats, stat_ld, N, H, W, C, k, stride):
     _chk_cuda(g, x, h, w_taps)
     call("atomnas_dwconv_bwd", _p(g), _ld(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _p(c1), _p(c2), _p(c3), _p(x), _ld(x),
-         _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _p(dw), _p(stats), N, H, W, C, k,
-         stride, dt_code(x.dtype), _stream())
+         _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _p(dw), _p(stats), stat_ld, N, H, W, C,
+         k, stride, dt_code(x.dtype), _stream())
 
 
 def gemm_nt(a, wp, c, M, N, K, a_mode=PRO_NONE, a2=None, ac1=None, ac2=None, ac3=None, a_relu=False, add=None, z=None,
@@ -154,3 +154,11 @@ def gamma_mask(params, ema, jobs_dev, njobs, threshold, mode, mask, index, kept)
 
 def channel_repack(src_ptrs_dev, dst_ptrs_dev, narenas, jobs_dev, njobs, index):
     call("atomnas_channel_repack", _p(src_ptrs_dev), _p(dst_ptrs_dev), narenas, _p(jobs_dev), njobs, _p(index), _stream())
+
+
+def reg_grad(p, g, jobs_dev, njobs, use_sign, mult_ptr=None, grad_out=None):
+    call("atomnas_reg_grad", _p(p), _p(g), _p(jobs_dev), njobs, int(use_sign), _p(mult_ptr), _p(grad_out), _stream())
+
+
+def reg_value(p, jobs_dev, njobs, use_abs, mult_ptr, post_scale, out):
+    call("atomnas_reg_value", _p(p), _p(jobs_dev), njobs, int(use_abs), _p(mult_ptr), float(post_scale), _p(out), _stream())

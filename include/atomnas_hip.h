@@ -47,10 +47,11 @@ int atomnas_runtime_version(void);
 
 /* ---- depthwise k x k convolution: nn.Conv2d(C, C, k, stride, (k-1)/2, groups=C, bias=False)
  *      models/mobilenet_base.py:330-336 (built through ConvBNReLU :120-142); k in {3,5,7}, stride in {1,2}.
- * forward: y = dwconv(act(x*in_scale+in_shift));  stats += [sum y, sum y^2]   (in_scale == NULL: x used as is)
+ * forward: y = dwconv(act(x*in_scale+in_shift));  stats[c], stats[stat_ld+c] += sum y, sum y^2   (in_scale == NULL: x as is)
  *   w: fp32 taps [k*k][ldw] (tap-major, see atomnas_pack_weights mode 2). */
 int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
-                       void* y, int ldy, float* stats, int N, int H, int W, int C, int k, int stride, int dtype, void* stream);
+                       void* y, int ldy, float* stats, int stat_ld, int N, int H, int W, int C, int k, int stride, int dtype,
+                       void* stream);
 
 /* backward (input gradient and weight gradient in one pass over the data):
  *   dYraw = c1*g + c2*yraw + c3  (yraw == NULL: dYraw = g)      -- BatchNorm backward of the BN after the conv
@@ -59,8 +60,8 @@ int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const floa
  *   stats += [sum h, sum h*x]                                   -- for the producer's BatchNorm backward */
 int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
                        const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
-                       void* h, int ldh, float* dw, float* stats, int N, int H, int W, int C, int k, int stride, int dtype,
-                       void* stream);
+                       void* h, int ldh, float* dw, float* stats, int stat_ld, int N, int H, int W, int C, int k, int stride,
+                       int dtype, void* stream);
 
 /* ---- pointwise (1x1) convolutions as MFMA GEMMs: models/mobilenet_base.py:316-320 (expand), :338 (project),
  *      models/mobilenet_supernet.py:148-153 (last conv), :160-163 (classifier); branches concatenated (:378).
@@ -83,7 +84,7 @@ int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void* u2, int l
 /* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;
  *      kwargs from models/mobilenet_supernet.py:95-98; calibration mode utils/common.py:214-226.
  * finalize forward: stats=[sum x, sum x^2] over `count` elements -> scale = gamma*invstd, shift = beta - mean*scale,
- *   save_mean / save_invstd for backward, running statistics update (momentum < 0: cumulative average, counter bumped). */
+ *   save_mean / save_invstd for backward, running statistics update (momentum < 0: cumulative average 1/(counter+1); the caller bumps the counter). */
 int atomnas_bn_finalize_fwd(const float* stats, double count, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
                             float* save_mean, float* save_invstd, int C, void* stream);
@@ -128,6 +129,13 @@ int atomnas_fused_rmsprop_ema(float* p, const float* g, float* sq, float* buf, f
 int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper, void* stream);
 /* out += sum_i coef[i/256] * (p_i^2 | |p_i|): values of the L2 / L1 regularisers for logging (train.py:206-208) */
 int atomnas_weighted_norm(const float* p, const float* coef_chunk, long n, int use_abs, float* out, void* stream);
+/* regularisers as gradient contributions / values over a job table {long off; int count; float coef;}:
+ *   cal_l2_loss (utils/optim.py:210-249): g += wd*p, value 0.5*wd*sum p^2;  cal_bn_l1_loss (utils/prune.py:161-167):
+ *   g += rho*penalty*sign(gamma), value rho*penalty*sum|gamma|.  mult_ptr / grad_out_ptr: optional device scalars. */
+int atomnas_reg_grad(const float* p, float* g, const void* jobs_dev, int njobs, int use_sign, const float* mult_ptr,
+                     const float* grad_out_ptr, void* stream);
+int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_abs, const float* mult_ptr, float post_scale,
+                      float* out, void* stream);
 /* re-pack fp32 master weights into kernel layouts; jobs_dev: device array of
  *   struct { long src_off, dst_off; int rows, cols, src_ld, dst_ld, c_off, mode; }  (mode 0 [N][K], 1 transposed, 2 depthwise taps) */
 int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream);

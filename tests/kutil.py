@@ -38,13 +38,20 @@ def tol(dtype):
     return dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=1.2e-2, atol=1e-2)
 
 
-def assert_close(name, got, ref, rtol, atol):
+def assert_close(name, got, ref, rtol, atol, outlier_frac=0.0, rel_l2=None):
+    """Element-wise |got-ref| <= atol + rtol*|ref|, except for at most `outlier_frac` of the elements (bf16 activations
+    flip a ReLU mask for pre-activations within rounding distance of zero; such elements are individually wrong by a full
+    gradient contribution but rare).  rel_l2 additionally bounds ||got-ref|| / ||ref||."""
     got = got.double().cpu()
     ref = ref.double().cpu()
     err = (got - ref).abs()
+    if rel_l2 is not None:
+        rl = float(err.norm() / max(float(ref.norm()), 1e-30))
+        if rl > rel_l2:
+            raise AssertionError("%s: relative L2 error %.4g > %.4g" % (name, rl, rel_l2))
     bound = atol + rtol * ref.abs()
     bad = err > bound
-    if bad.any():
+    if float(bad.sum()) > outlier_frac * bad.numel():
         idx = torch.nonzero(bad)[0].tolist()
         raise AssertionError("%s: %d/%d mismatches, max err %.4g (ref max %.4g), first at %s got %.6g ref %.6g" %
                              (name, int(bad.sum()), bad.numel(), float(err.max()), float(ref.abs().max()), idx,

@@ -1,0 +1,184 @@
+"""Module-level parity (GPU): InvertedResidualChannels / ConvBNReLU / whole model on the HIP path vs the CPU oracle.
+
+fp32 storage must match the oracle (float64 evaluation of the same state_dict) to accumulation-order tolerance; bf16
+storage to the tolerance of bf16 activations (stated per test).  Parameter gradients are read from p.grad (gradient arena).
+"""
+import collections
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import atomnas_oracle as orc  # noqa: E402
+
+from kutil import assert_close  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomize(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() == 1 and "bias" not in n:      # BN gamma
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            elif p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            else:
+                fan = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) / fan ** 0.5)
+        for n, b in module.named_buffers():
+            if "running_mean" in n:
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif "running_var" in n:
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+
+
+def _sd64(module, prefix=""):
+    return collections.OrderedDict((prefix + k, (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu().clone()))
+                                   for k, v in module.state_dict().items())
+
+
+BLOCKS = [
+    dict(inp=8, oup=8, stride=1, channels=[16, 16, 16], ks=[3, 5, 7], expand=True),      # residual, aligned
+    dict(inp=8, oup=16, stride=2, channels=[12, 20, 7], ks=[3, 5, 7], expand=True),      # ragged (post-shrink) widths
+    dict(inp=16, oup=24, stride=2, channels=[96], ks=[5], expand=True),                  # single branch
+    dict(inp=16, oup=8, stride=1, channels=[16], ks=[3], expand=False),                  # first block of the supernet
+    dict(inp=24, oup=24, stride=1, channels=[1, 3], ks=[3, 7], expand=True),             # nearly pruned
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", BLOCKS)
+def test_block_forward_backward(gpu_lib, cfg, dtype):
+    from atomnas_amd.models import mobilenet_base as mb
+    act = mb.get_active_fn("nn.ReLU")
+    bn_kw = {"momentum": 0.01, "eps": 1e-3}
+    blk = mb.InvertedResidualChannels(cfg["inp"], cfg["oup"], cfg["stride"], cfg["channels"], cfg["ks"], cfg["expand"],
+                                      active_fn=act, batch_norm_kwargs=bn_kw)
+    blk.compute_dtype = dtype
+    _randomize(blk, 7)
+    N, H = 3, 14
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, cfg["inp"], H, H, generator=g)
+    Ho = (H - 1) // cfg["stride"] + 1
+    gout = torch.randn(N, cfg["oup"], Ho, Ho, generator=g)
+    if dtype == torch.bfloat16:
+        x, gout = x.bfloat16().float(), gout.bfloat16().float()
+    sd0 = _sd64(blk, "blk.")
+
+    blk.cuda().train()
+    xg = x.cuda().requires_grad_(True)
+    out = blk(xg)
+    assert out.dtype == dtype and out.shape == (N, cfg["oup"], Ho, Ho)
+    out.backward(gout.cuda().to(dtype))
+    torch.cuda.synchronize()
+
+    # oracle in float64 on the same state_dict
+    spec = dict(eps=1e-3, momentum=0.01, act="nn.ReLU")
+    ob = dict(name="blk", inp=cfg["inp"], oup=cfg["oup"], stride=cfg["stride"], expand=cfg["expand"], channels=cfg["channels"],
+              ks=cfg["ks"], res=cfg["stride"] == 1 and cfg["inp"] == cfg["oup"])
+    work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
+    xo = x.double().requires_grad_(True)
+    stats = {}
+    q = orc.NoQuant if dtype == torch.float32 else orc.Bf16Storage
+    ref = orc.block_forward(xo, work, ob, True, spec, stats, q)
+    ref.backward(gout.double())
+
+    if dtype == torch.float32:
+        t_act, t_grad = dict(rtol=1e-3, atol=1e-4), dict(rtol=2e-3, atol=2e-4)
+    else:  # oracle emulates bf16 storage: what is left is fp32 accumulation order and rare double roundings / mask flips
+        t_act = dict(rtol=1.6e-2, atol=1.6e-2, outlier_frac=0.002)
+        t_grad = dict(rtol=2e-2, atol=2e-2, outlier_frac=0.01, rel_l2=0.02)
+    assert_close("out", out, ref, **t_act)
+    gscale = float(xo.grad.abs().max())
+    extra = {k: v for k, v in t_grad.items() if k in ("outlier_frac", "rel_l2")}
+    assert_close("dx", xg.grad, xo.grad, t_grad["rtol"], t_grad["atol"] * max(1.0, gscale), **extra)
+    for name, p in blk.named_parameters():
+        r = work["blk." + name].grad
+        s = max(1e-2, float(r.abs().max()))
+        assert_close("grad " + name, p.grad, r, t_grad["rtol"], t_grad["atol"] * s, **extra)
+    for name, b in blk.named_buffers():
+        if "running" in name:
+            prefix = "blk." + name.rsplit(".", 1)[0]
+            rm, rv = stats[prefix]
+            assert_close(name, b, rm if name.endswith("mean") else rv, rtol=2e-3 if dtype == torch.float32 else 2e-2, atol=1e-4 if dtype == torch.float32 else 2e-3)
+        elif "num_batches_tracked" in name:
+            assert int(b) == 1
+
+
+def test_block_eval_mode(gpu_lib):
+    from atomnas_amd.models import mobilenet_base as mb
+    cfg = BLOCKS[1]
+    blk = mb.InvertedResidualChannels(cfg["inp"], cfg["oup"], cfg["stride"], cfg["channels"], cfg["ks"], cfg["expand"],
+                                      active_fn=mb.get_active_fn("nn.ReLU"), batch_norm_kwargs={"momentum": 0.01, "eps": 1e-3})
+    blk.compute_dtype = torch.float32
+    _randomize(blk, 3)
+    sd0 = _sd64(blk, "blk.")
+    x = torch.randn(2, cfg["inp"], 10, 10)
+    blk.cuda().eval()
+    with torch.no_grad():
+        out = blk(x.cuda())
+    ob = dict(name="blk", inp=cfg["inp"], oup=cfg["oup"], stride=cfg["stride"], expand=True, channels=cfg["channels"], ks=cfg["ks"], res=False)
+    ref = orc.block_forward(x.double(), sd0, ob, False, dict(eps=1e-3, momentum=0.01, act="nn.ReLU"))
+    assert_close("eval out", out, ref, rtol=1e-3, atol=1e-4)
+    assert all(int(b) == 0 for n, b in blk.named_buffers() if "num_batches" in n)
+
+
+TINY = dict(num_classes=10, input_size=64, input_channel=16, last_channel=64, width_mult=1.0, dropout_ratio=0.0,
+            batch_norm_momentum=0.01, batch_norm_epsilon=1e-3, active_fn="nn.ReLU",
+            inverted_residual_setting=[[1, 8, 1, 1, [3]], [6, 16, 2, 2, [3, 5, 7]], [6, 24, 2, 2, [3, 5, 7]], [6, 32, 1, 2, [3, 5, 7]],
+                                       [6, 40, 1, 2, [3, 5, 7]]])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_forward_backward(gpu_lib, dtype):
+    from atomnas_amd.models import mobilenet_supernet as ms
+    from atomnas_amd.utils import optim as aopt
+    model = ms.Model(**TINY)
+    model.set_compute_dtype(dtype)
+    _randomize(model, 5)
+    sd0 = _sd64(model)
+    spec = orc.spec_from_model(model)
+    g = torch.Generator().manual_seed(3)
+    N = 6
+    x = torch.randn(N, 3, 64, 64, generator=g)
+    y = torch.randint(0, 10, (N,), generator=g)
+    model.cuda().train()
+    crit = aopt.CrossEntropyLabelSmooth(10, 0.1, reduction="none")
+    logits = model(x.cuda())
+    loss = crit(logits, y.cuda()).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
+    xin = x.bfloat16().double() if dtype == torch.bfloat16 else x.double()
+    ref_logits = orc.model_forward(xin, work, spec, True, {}, q=orc.NoQuant if dtype == torch.float32 else orc.Bf16Storage)
+    ref_loss = orc.ce_label_smooth(ref_logits, y, 0.1).mean()
+    ref_loss.backward()
+    if dtype == torch.float32:
+        ta, tg = dict(rtol=2e-3, atol=2e-4), dict(rtol=1e-2, atol=1e-3)
+    else:
+        ta, tg = dict(rtol=3e-2, atol=3e-2), None
+    assert_close("logits", logits, ref_logits, **ta)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < (1e-4 if dtype == torch.float32 else 1e-2)
+    gnorm = max(float(work[n].grad.norm()) for n, _ in model.named_parameters())
+    for name, p in model.named_parameters():
+        r = work[name].grad
+        if dtype == torch.float32:
+            s = max(1e-2, float(r.abs().max()))
+            assert_close("grad " + name, p.grad, r, tg["rtol"], tg["atol"] * s)
+        elif float(r.norm()) > 1e-2 * gnorm:
+            # Whole-network bf16 gradients cannot be compared element-wise with ANY other implementation: 1-ulp forward
+            # differences (fp32 accumulation order) grow ~2x per block through the batch statistics, flip a percent of the
+            # ReLU masks in late layers, and each flip changes a gradient contribution completely (measured here: forward
+            # relative L2 error 1.8e-2 at the last block -> ~0.2 in the gradients, identical for every layer).  Component
+            # level bf16 parity is exact-to-rounding (test_block_forward_backward, tools/dbg_tail.py); here we pin the
+            # direction and scale of every significant gradient tensor.
+            gg = p.grad.double().cpu().flatten()
+            cos = float(torch.dot(gg, r.flatten()) / (gg.norm() * r.norm()))
+            ratio = float(gg.norm() / r.norm())
+            assert cos > 0.9 and 0.8 < ratio < 1.25, "grad %s: cosine %.3f norm ratio %.3f" % (name, cos, ratio)

@@ -54,7 +54,7 @@ def test_dwconv_fwd(gpu_lib, dtype, k, stride, N, C, H, W):
         Ho, Wo = yref.shape[2:]
         yb = fresh(N * Ho * Wo, C, dtype)
         stats = torch.zeros(2, C, dtype=torch.float32, device="cuda")
-        ops.dwconv_fwd(xb, cvec(sc) if fuse else None, cvec(sh) if fuse else None, fuse, taps(w), yb, stats, N, H, W, C, k, stride)
+        ops.dwconv_fwd(xb, cvec(sc) if fuse else None, cvec(sh) if fuse else None, fuse, taps(w), yb, stats, C, N, H, W, C, k, stride)
         torch.cuda.synchronize()
         y = from_act(yb, N, Ho, Wo, C)
         assert_close("y", y, yref, **tol(dtype))
@@ -96,7 +96,7 @@ def test_dwconv_bwd(gpu_lib, dtype, k, stride, N, C, H, W):
         stats = torch.zeros(2, C, dtype=torch.float32, device="cuda")
         ops.dwconv_bwd(to_act(gup, dtype), to_act(yraw, dtype) if fuse else None, cvec(c1) if fuse else None,
                        cvec(c2) if fuse else None, cvec(c3) if fuse else None, to_act(x, dtype), cvec(sc) if fuse else None,
-                       cvec(sh) if fuse else None, fuse, taps(w), hb, dw, stats, N, H, W, C, k, stride)
+                       cvec(sh) if fuse else None, fuse, taps(w), hb, dw, stats, C, N, H, W, C, k, stride)
         torch.cuda.synchronize()
         h = from_act(hb, N, H, W, C)
         t = tol(dtype)

@@ -1,0 +1,20 @@
+import sys, os, collections, torch
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle"); sys.path.insert(0, "/root/repo/tests")
+import atomnas_oracle as orc
+from test_block_gpu import TINY, _randomize, _sd64
+from atomnas_amd.models import mobilenet_supernet as ms
+from atomnas_amd.utils import optim as aopt
+dtype = torch.bfloat16
+model = ms.Model(**TINY); model.set_compute_dtype(dtype); _randomize(model, 5)
+sd0 = _sd64(model); spec = orc.spec_from_model(model)
+g = torch.Generator().manual_seed(3); N = 6
+x = torch.randn(N, 3, 64, 64, generator=g); y = torch.randint(0, 10, (N,), generator=g)
+model.cuda().train()
+crit = aopt.CrossEntropyLabelSmooth(10, 0.1, reduction="none")
+logits = model(x.cuda()); loss = crit(logits, y.cuda()).mean(); loss.backward(); torch.cuda.synchronize()
+work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
+ref_logits = orc.model_forward(x.bfloat16().double(), work, spec, True, {}, q=orc.Bf16Storage)
+orc.ce_label_smooth(ref_logits, y, 0.1).mean().backward()
+for name, p in model.named_parameters():
+    r = work[name].grad; gg = p.grad.double().cpu()
+    print("%-40s relL2 %.4f  |ref| %.3e" % (name, float((gg - r).norm() / r.norm().clamp_min(1e-30)), float(r.norm())))
