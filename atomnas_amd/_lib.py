@@ -58,6 +58,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  -- must come first: the library then binds to the HIP runtime torch ships (same SONAME)
     if not os.path.exists(LIB_PATH):
         raise AtomnasHipError(
             "libatomnas_hip.so is missing (%s). Build it with `python -m atomnas_amd.build`; there is no CPU fallback." % LIB_PATH)

@@ -50,12 +50,16 @@ def _chk_cuda(*ts):
 
 def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, stat_ld, N, H, W, C, k, stride):
     _chk_cuda(x, y, w_taps)
+    if _lib.PROFILE is not None:
+        _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
     call("atomnas_dwconv_fwd", _p(x), _ld(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(y), _ld(y),
          _p(stats), stat_ld, N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
 
 def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, dw, stats, stat_ld, N, H, W, C, k, stride):
     _chk_cuda(g, x, h, w_taps)
+    if _lib.PROFILE is not None:
+        _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
     call("atomnas_dwconv_bwd", _p(g), _ld(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _p(c1), _p(c2), _p(c3), _p(x), _ld(x),
          _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _p(dw), _p(stats), stat_ld, N, H, W, C,
          k, stride, dt_code(x.dtype), _stream())
@@ -64,6 +68,8 @@ def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, d
 def gemm_nt(a, wp, c, M, N, K, a_mode=PRO_NONE, a2=None, ac1=None, ac2=None, ac3=None, a_relu=False, add=None, z=None,
             zscale=None, zshift=None, mask=False, bias=None, stats=None, stat_mode=STAT_NONE):
     _chk_cuda(a, wp, c)
+    if _lib.PROFILE is not None:
+        _lib.profile_tag("M%d N%d K%d pro%d st%d%s%s" % (M, N, K, a_mode, stat_mode, "+add" if add is not None else "", "+mask" if mask else ""))
     out_f32 = 1 if (c.dtype == torch.float32 and a.dtype != torch.float32) else 0
     call("atomnas_pw_gemm_nt", a_mode, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, _p(ac1), _p(ac2), _p(ac3),
          int(a_relu), _p(wp), wp.stride(0), _p(c), _ld(c), out_f32, _p(add), _ld(add) if add is not None else 0, _p(z),
@@ -74,6 +80,8 @@ def gemm_nt(a, wp, c, M, N, K, a_mode=PRO_NONE, a2=None, ac1=None, ac2=None, ac3
 def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc2=None, uc3=None, u_relu=False, v_mode=PRO_NONE,
             v2=None, vc1=None, vc2=None, vc3=None, v_relu=False):
     _chk_cuda(u, v, out)
+    if _lib.PROFILE is not None:
+        _lib.profile_tag("M%d NU%d NV%d pro%d,%d" % (M, NU, NV, u_mode, v_mode))
     call("atomnas_pw_gemm_tn", u_mode, _p(u), _ld(u), _p(u2), _ld(u2) if u2 is not None else 0, _p(uc1), _p(uc2), _p(uc3),
          int(u_relu), NU, v_mode, _p(v), _ld(v), _p(v2), _ld(v2) if v2 is not None else 0, _p(vc1), _p(vc2), _p(vc3), int(v_relu),
          NV, _p(out), si, sj, M, dt_code(u.dtype), _stream())

@@ -442,5 +442,5 @@ def train_step(sd, spec, opt_state, ema_shadow, x, target, hp, prune_names=None,
             d = hp['ema_decay']
             for k in ema_shadow:
                 ema_update(ema_shadow[k], sd[k], d)
-    return dict(loss=float(loss), loss_l2=float(loss_l2), loss_l1=float(loss_l1), logits=logits.detach(), grads=grads,
+    return dict(loss=float(loss.detach()), loss_l2=float(torch.as_tensor(loss_l2).detach()), loss_l1=float(torch.as_tensor(loss_l1).detach()), logits=logits.detach(), grads=grads,
                 loss_vec=loss_vec.detach())

@@ -37,10 +37,17 @@ ts.step(rho=1e-5); torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for name, tag, e0, e1 in _lib.PROFILE:
     a = agg.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
+prof = _lib.PROFILE
 _lib.PROFILE = None
 tot = sum(v[1] for v in agg.values())
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]): print("  %-28s n=%4d  %8.3f ms  %5.1f%%" % (k, v[0], v[1], 100 * v[1] / tot))
 print("  sum of kernel times %.2f ms" % tot)
+if os.environ.get("DETAIL"):
+    det = collections.OrderedDict()
+    for name, tag, e0, e1 in prof:
+        if name in ("atomnas_dwconv_bwd", "atomnas_dwconv_fwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn"):
+            a = det.setdefault((name, tag), [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
+    for (name, tag), v in det.items(): print("    %-22s %-40s n=%2d %8.3f ms" % (name[8:], tag, v[0], v[1]))
 ts.use_graph = True
 t0 = time.time(); ts.step(rho=1e-5); torch.cuda.synchronize(); print("capture %.2fs" % (time.time() - t0))
 for _ in range(3): ts.step(rho=1e-5)
