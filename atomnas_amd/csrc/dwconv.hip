@@ -10,332 +10,490 @@
 //             h     = dXa * [x*in_scale+in_shift > 0]           (ReLU-backward of the producer's activation)
 //             + per-channel sum(h), sum(h*x) for the BN-backward of the producer's BN
 //
-// Work decomposition (HBM-bound, VALU-heavy): a thread owns CV consecutive channels and a column strip of TW
-// pixels, and walks down the rows of one image chunk; re-reads of the (k-1) halo rows come from the same CU's
-// L1 / the XCD's L2.  Lanes of a wave run along channels first, so a wave reads contiguous NHWC bytes.
+// Structure (both directions): a 256-thread workgroup owns a slab of CB channels and walks over spatial tiles
+// (persistent loop, so the per-channel reductions are flushed once per workgroup).  Per tile the haloed operand tile is
+// staged ONCE through LDS as fp32 *after* its prologue (BN apply + ReLU, or the BN-backward affine of two streams), with
+// 16-byte global loads; the k*k taps then slide over LDS rows held in registers (ds_read_b64 of a channel pair, packed
+// fp32 FMAs), so each element costs one HBM read, one transform and k*k FMAs instead of k reloads and k transforms.
+// LDS rows are padded so that the two tile rows a 32-lane LDS group touches fall into different bank halves.
 #include "common.h"
+#include <unordered_map>
+#ifndef DW_EXP
+#define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute
+#endif
 
 namespace atomnas {
 
 constexpr __host__ __device__ int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+constexpr __host__ __device__ int cdiv(int a, int b) { return -fdiv(-a, b); }
 constexpr __host__ __device__ int pmod(int a, int b) { return ((a % b) + b) % b; }
+
+// 8 consecutive channels as loaded from HBM, kept raw in registers while a tile is in flight (software prefetch)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ float get(int e) const { return (float)v[e]; }
+};
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+  __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e] : b[e - 4]; }
+};
 
 struct DwGeom {
   int N, H, W, C, Ho, Wo;
-  int cvb;      // channel-vectors per block (lanes along channels)
-  int pb;       // pixel lanes per block
-  int spr;      // column strips per row
-  int rh;       // rows per chunk
-  int nchunks;  // row chunks per image
+  int CB;                 // channels per slab (8, 16, 32 or 64)
+  int TH, TW;             // tile: output pixels (forward) / input pixels (backward)
+  int tiles_y, tiles_x;   // tiles per image
+  int LH, LW, RP;         // LDS operand tile: rows, cols, row pitch (floats)
+  int nworkers;           // workgroups per slab (persistent loop over tiles), multiple of 8
+  int nslabs;             // channel slabs
 };
 
+static inline int lds_pitch(int lw, int cb) {
+  int rp = lw * cb;
+  // rows r and r+1 are read by the two halves of a 32-lane LDS group: keep them 32 banks (dwords) apart (mod 64)
+  int pad = (32 - rp % 64 + 64) % 64;
+  return rp + pad;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int K, int S, int CV, int TW>
+template <typename T, int K, int S, int SW, int CB, int TM>
 __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int ldx, const float* __restrict__ in_scale,
                                                     const float* __restrict__ in_shift, int in_relu,
                                                     const float* __restrict__ w, int ldw, T* __restrict__ y, int ldy,
                                                     float* __restrict__ stats, int stat_ld, DwGeom g) {
   constexpr int P = (K - 1) / 2;
-  constexpr int IW = (TW - 1) * S + K;
-  __shared__ float s_red[256 * 2];  // [cvb*CV][2] block partials of sum / sumsq (cvb*CV <= 256)
+  constexpr int IWS = (SW - 1) * S + K;  // input columns one strip needs
+  constexpr int LMAX = (TM - 1) * S + K;                           // largest LDS tile extent for this instantiation
+  constexpr int PF = (LMAX * LMAX * (CB / 8) + 255) / 256;         // 16-byte loads per thread per tile
+  static_assert(PF <= 32, "prefetch mask is 32 bits");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;                         // [LH][RP]
+  float* s_w = s_in + g.LH * g.RP;            // [K*K][CB]
+  float* s_st = s_w + K * K * CB;             // [2][CB]
 
   const int tid = threadIdx.x;
-  const int cvl = tid % g.cvb;
-  const int pl = tid / g.cvb;
-  const int c0 = (blockIdx.y * g.cvb + cvl) * CV;
-  const long gp = (long)blockIdx.x * g.pb + pl;
-  const long nstrips = (long)g.N * g.nchunks * g.spr;
-  const bool active = (pl < g.pb) && (c0 < g.C) && (gp < nstrips);
+  constexpr int C2 = CB / 2, CG = CB / 8;
+  // Workgroup b runs on XCD b % 8 (private L2 each).  The slabs that share 128-byte lines of a pixel (64 channels) must
+  // hit the same L2 at about the same time, or every line is fetched from HBM once per slab: consecutive workgroups of
+  // one XCD take the slabs of one worker (= one tile sequence).
+  const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;
+  const int slab = b_local % g.nslabs, worker = (b_local / g.nslabs) * 8 + b_xcd;
+  const int c_base = slab * CB;
+  const int cpad = (g.C + 7) & ~7;
 
-  if (stats) {
-    for (int i = tid; i < g.cvb * CV * 2; i += 256) s_red[i] = 0.f;
-    __syncthreads();
+  for (int i = tid; i < K * K * CB; i += 256) {
+    const int t = i / CB, c = i % CB;
+    s_w[i] = (c_base + c < g.C) ? w[(long)t * ldw + c_base + c] : 0.f;
+  }
+  for (int i = tid; i < 2 * CB; i += 256) s_st[i] = 0.f;
+
+  // staging role: fixed channel group per thread (256 % CG == 0)
+  const int cg = tid % CG;
+  const bool cg_ok = c_base + cg * 8 < cpad;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+  if (in_scale && cg_ok) { VecIO<float, 8>::load(in_scale + c_base + cg * 8, sc); VecIO<float, 8>::load(in_shift + c_base + cg * 8, sh); }
+
+  // compute role: fixed channel pair per thread (256 % C2 == 0)
+  const int c2 = tid % C2;
+  const int ch = c_base + 2 * c2;
+  const int nstrips = g.TW / SW;
+  const int nitems = C2 * g.TH * nstrips;
+  float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+
+  const int ntiles = g.N * g.tiles_y * g.tiles_x;
+  const int npix = g.LH * g.LW;
+  // tile-independent index math, done once (integer division is a ~30-instruction sequence on CDNA)
+  int p_iy[PF], p_ix[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int pidx = tid / CG + i * (256 / CG);
+    p_iy[i] = pidx < npix ? pidx / g.LW : -100000;   // out-of-tile slots fail every bounds test
+    p_ix[i] = pidx % g.LW;
+  }
+  // software pipeline: the next tile's HBM loads are issued before the current tile is computed and land in registers
+  Raw8<T> pf[PF];
+  unsigned pfmask = 0;
+  auto issue = [&](int n, int ty, int tx) {
+    const int hi0 = ty * g.TH * S - P, wi0 = tx * g.TW * S - P;
+    const T* xn = x + (long)n * g.H * g.W * ldx + c_base + cg * 8;
+    pfmask = 0;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int hi = hi0 + p_iy[i], wi = wi0 + p_ix[i];
+      if (cg_ok && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
+        pf[i].load(xn + ((long)hi * g.W + wi) * ldx);
+        pfmask |= 1u << i;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      if (p_iy[i] >= 0) {
+        float v[8];
+        const bool ok = (pfmask >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = pf[i].get(e) * sc[e] + sh[e];
+          a = in_relu ? fmaxf(a, 0.f) : a;
+          v[e] = ok ? a : 0.f;
+        }
+        float* d = s_in + p_iy[i] * g.RP + p_ix[i] * CB + cg * 8;
+        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+    }
+  };
+  // work items of this thread (at most NIT): output row r, strip j
+  constexpr int NIT = (C2 * TM * (TM / SW) + 255) / 256;
+  int it_r[NIT], it_j[NIT];
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int it = tid + q * 256;
+    const int rs = it / C2;
+    it_r[q] = it < nitems ? rs / nstrips : -1;
+    it_j[q] = rs % nstrips;
   }
 
-  float ssum[CV], ssq[CV];
-#pragma unroll
-  for (int c = 0; c < CV; ++c) ssum[c] = ssq[c] = 0.f;
-
-  if (active) {
-    const int ws = (int)(gp % g.spr);
-    const int chunk = (int)((gp / g.spr) % g.nchunks);
-    const int n = (int)(gp / ((long)g.spr * g.nchunks));
-    const int wo0 = ws * TW;
-    const int wi0 = wo0 * S - P;
-
-    float wr[K * K][CV];
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) VecIO<float, CV>::load(w + (long)t * ldw + c0, wr[t]);
-    float sc[CV], sh[CV];
-#pragma unroll
-    for (int c = 0; c < CV; ++c) { sc[c] = 1.f; sh[c] = 0.f; }
-    if (in_scale) { VecIO<float, CV>::load(in_scale + c0, sc); VecIO<float, CV>::load(in_shift + c0, sh); }
-    bool cvalid[CV];
-#pragma unroll
-    for (int c = 0; c < CV; ++c) cvalid[c] = (c0 + c) < g.C;
-
-    const int ho_beg = chunk * g.rh;
-    const int ho_end = min(g.Ho, ho_beg + g.rh);
-    const T* xn = x + (long)n * g.H * g.W * ldx + c0;
-    T* yn = y + (long)n * g.Ho * g.Wo * ldy + c0;
-
-    for (int ho = ho_beg; ho < ho_end; ++ho) {
-      float acc[TW][CV];
-#pragma unroll
-      for (int t = 0; t < TW; ++t)
-#pragma unroll
-        for (int c = 0; c < CV; ++c) acc[t][c] = 0.f;
+  // tile walk with carried (n, ty, tx) for the current and the prefetched tile
+  int tile = worker;
+  int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
+  const int dtx = g.nworkers % g.tiles_x, dty = (g.nworkers / g.tiles_x) % g.tiles_y, dn = g.nworkers / (g.tiles_x * g.tiles_y);
+  auto advance = [&](int& an, int& aty, int& atx) {
+    atx += dtx;
+    if (atx >= g.tiles_x) { atx -= g.tiles_x; aty += 1; }
+    aty += dty;
+    if (aty >= g.tiles_y) { aty -= g.tiles_y; an += 1; }
+    an += dn;
+  };
+  int ntx = tx, nty = ty, nn = n;
+  if (tile < ntiles) issue(n, ty, tx);
+  for (; tile < ntiles; tile += g.nworkers) {
+    const int ho0 = ty * g.TH, wo0 = tx * g.TW;
+    __syncthreads();  // previous tile fully consumed (also orders the s_w / s_st initialisation)
+    if (DW_EXP != 3) commit();
+    __syncthreads();
+    ntx = tx; nty = ty; nn = n;
+    advance(nn, nty, ntx);
+    if (tile + g.nworkers < ntiles) issue(nn, nty, ntx);
 
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const int hi = ho * S + ky - P;
-        if (hi < 0 || hi >= g.H) continue;
-        const T* xr = xn + (long)hi * g.W * ldx;
-        float in[IW][CV];
+    for (int q = 0; q < (DW_EXP == 2 ? 0 : NIT); ++q) {
+      const int r = it_r[q], j = it_j[q];
+      const int ho = ho0 + r;
+      if (r < 0 || ho >= g.Ho) continue;
+      f32x2 acc[SW];
 #pragma unroll
-        for (int j = 0; j < IW; ++j) {
-          const int wi = wi0 + j;
-          if (wi >= 0 && wi < g.W) {
-            float v[CV];
-            VecIO<T, CV>::load(xr + (long)wi * ldx, v);
+      for (int t = 0; t < SW; ++t) acc[t] = f32x2{0.f, 0.f};
+#pragma unroll 1
+      for (int ky = 0; ky < K; ++ky) {  // not unrolled: keeps one LDS row (IWS pairs) live instead of K of them
+        const float* row = s_in + (r * S + ky) * g.RP + (j * SW * S) * CB + 2 * c2;
+        f32x2 in[IWS];
 #pragma unroll
-            for (int c = 0; c < CV; ++c) {
-              float a = v[c] * sc[c] + sh[c];
-              in[j][c] = in_relu ? fmaxf(a, 0.f) : a;
-            }
-          } else {
+        for (int i = 0; i < IWS; ++i) in[i] = *reinterpret_cast<const f32x2*>(row + i * CB);
 #pragma unroll
-            for (int c = 0; c < CV; ++c) in[j][c] = 0.f;
-          }
+        for (int kx = 0; kx < K; ++kx) {
+          const f32x2 wv = *reinterpret_cast<const f32x2*>(s_w + (ky * K + kx) * CB + 2 * c2);
+#pragma unroll
+          for (int t = 0; t < SW; ++t) acc[t] += in[t * S + kx] * wv;
         }
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-          for (int t = 0; t < TW; ++t)
-#pragma unroll
-            for (int c = 0; c < CV; ++c) acc[t][c] += in[t * S + kx][c] * wr[ky * K + kx][c];
       }
-
-      T* yr = yn + (long)ho * g.Wo * ldy;
+      if (ch < cpad) {
+        T* yr = y + (((long)n * g.Ho + ho) * g.Wo) * ldy + ch;
 #pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        const int wo = wo0 + t;
-        if (wo < g.Wo) {
-          float o[CV];
-#pragma unroll
-          for (int c = 0; c < CV; ++c) {
-            // statistics are taken on the stored (rounded) value so that normalisation is self-consistent
-            float r = cvalid[c] ? to_f32(from_f32<T>(acc[t][c])) : 0.f;
-            o[c] = r;
-            ssum[c] += r;
-            ssq[c] += r * r;
+        for (int t = 0; t < SW; ++t) {
+          const int wo = wo0 + j * SW + t;
+          if (wo < g.Wo) {
+            float o[2];
+            o[0] = (ch < g.C) ? to_f32(from_f32<T>(acc[t][0])) : 0.f;
+            o[1] = (ch + 1 < g.C) ? to_f32(from_f32<T>(acc[t][1])) : 0.f;
+            if (DW_EXP != 1) VecIO<T, 2>::store(yr + (long)wo * ldy, o);
+            ssum[0] += o[0]; ssq[0] += o[0] * o[0];
+            ssum[1] += o[1]; ssq[1] += o[1] * o[1];
           }
-          VecIO<T, CV>::store(yr + (long)wo * ldy, o);
         }
       }
     }
+    tx = ntx; ty = nty; n = nn;
   }
 
   if (stats) {
-    if (active) {
 #pragma unroll
-      for (int c = 0; c < CV; ++c) {
-        atomicAdd(&s_red[(cvl * CV + c) * 2 + 0], ssum[c]);
-        atomicAdd(&s_red[(cvl * CV + c) * 2 + 1], ssq[c]);
-      }
+    for (int o = 32; o >= C2; o >>= 1) {
+      ssum[0] += __shfl_xor(ssum[0], o, 64); ssum[1] += __shfl_xor(ssum[1], o, 64);
+      ssq[0] += __shfl_xor(ssq[0], o, 64); ssq[1] += __shfl_xor(ssq[1], o, 64);
+    }
+    if ((tid & 63) < C2) {
+      atomicAdd(&s_st[2 * c2], ssum[0]);
+      atomicAdd(&s_st[2 * c2 + 1], ssum[1]);
+      atomicAdd(&s_st[CB + 2 * c2], ssq[0]);
+      atomicAdd(&s_st[CB + 2 * c2 + 1], ssq[1]);
     }
     __syncthreads();
-    for (int i = tid; i < g.cvb * CV; i += 256) {
-      const int c = blockIdx.y * g.cvb * CV + i;
+    for (int i = tid; i < CB; i += 256) {
+      const int c = c_base + i;
       if (c < g.C) {
-        atomicAdd(&stats[c], s_red[i * 2 + 0]);
-        atomicAdd(&stats[stat_ld + c], s_red[i * 2 + 1]);
+        atomicAdd(&stats[c], s_st[i]);
+        atomicAdd(&stats[stat_ld + c], s_st[CB + i]);
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// One thread owns CV channels and a column strip of TW *input* pixels; for every input row it gathers the
-// contributing output rows.  For stride 2 only taps with matching parity contribute (static per (t,kx), uniform
-// per row for ky).
-template <typename T, int K, int S, int CV, int TW>
-__global__ __launch_bounds__(256) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, const T* __restrict__ yraw, int ldyr,
-                                                    const float* __restrict__ c1, const float* __restrict__ c2,
+// Tiles are in INPUT space (TH x TW input pixels); the LDS tile holds dYraw over the output window those pixels touch.
+// Work item = (channel pair, input row, strip of SW input pixels).  For stride 2 only taps of matching parity contribute:
+// per (t, kx) that is a compile-time fact (tile and strip origins are even), per ky it is uniform for a row.
+template <typename T, int K, int S, int SW, int CB>
+__global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, const T* __restrict__ yraw, int ldyr,
+                                                    const float* __restrict__ c1, const float* __restrict__ c2p,
                                                     const float* __restrict__ c3, const T* __restrict__ x, int ldx,
                                                     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                    int in_relu, const float* __restrict__ w, int ldw,
-                                                    T* __restrict__ h, int ldh, float* __restrict__ dw /*[C][K*K]*/,
-                                                    float* __restrict__ stats /*[2][stat_ld]: sum h, sum h*x*/, int stat_ld, DwGeom g) {
+                                                    int in_relu, const float* __restrict__ w, int ldw, T* __restrict__ h, int ldh,
+                                                    float* __restrict__ dw /*[C][K*K]*/, float* __restrict__ stats, int stat_ld,
+                                                    DwGeom g) {
   constexpr int P = (K - 1) / 2;
   constexpr int KK = K * K;
-  constexpr int RELMIN = fdiv(-P, S);
-  constexpr int RELMAX = fdiv(TW - 1 + P, S);
-  constexpr int DW = RELMAX - RELMIN + 1;
-  constexpr int MAXCH = 128;  // cvb*CV <= MAXCH (host guarantees)
-  __shared__ float s_w[KK * MAXCH];
-  __shared__ float s_red[MAXCH * (KK + 2)];
+  constexpr int RELMIN = fdiv(-P, S);            // first output column (relative to strip origin / S) a strip touches
+  constexpr int RELMAX = fdiv(SW - 1 + P, S);
+  constexpr int DWN = RELMAX - RELMIN + 1;       // dY columns per strip
+  static_assert(SW % S == 0, "strip origins must stay multiples of the stride");
+  constexpr int LMAXB = fdiv(14 - 1 + P, S) - cdiv(P - (K - 1), S) + 1;  // dY window of a 14-pixel input tile
+  constexpr int PF = (LMAXB * (fdiv(14 - 1 + P, S) - fdiv(-P, S) + 1) * (CB / 8) + 255) / 256;
+  static_assert(PF <= 32, "prefetch mask is 32 bits");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_dy = smem;                        // [LH][RP]
+  float* s_w = s_dy + g.LH * g.RP;           // [KK][CB]
+  float* s_red = s_w + KK * CB;              // [CB][KK + 2]
 
   const int tid = threadIdx.x;
-  const int cvl = tid % g.cvb;
-  const int pl = tid / g.cvb;
-  const int cb0 = blockIdx.y * g.cvb * CV;  // first channel of this block
-  const int c0 = cb0 + cvl * CV;
-  const int nch = g.cvb * CV;
-  const long gp = (long)blockIdx.x * g.pb + pl;
-  const long nstrips = (long)g.N * g.nchunks * g.spr;
-  const bool active = (pl < g.pb) && (c0 < g.C) && (gp < nstrips);
+  constexpr int C2 = CB / 2, CG = CB / 8;
+  const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;   // XCD-aware decode, see k_dwconv_fwd
+  const int slab = b_local % g.nslabs, worker = (b_local / g.nslabs) * 8 + b_xcd;
+  const int c_base = slab * CB;
+  const int cpad = (g.C + 7) & ~7;
 
-  for (int i = tid; i < KK * nch; i += 256) {
-    const int t = i / nch, c = i % nch;
-    s_w[t * nch + c] = (cb0 + c < g.C) ? w[(long)t * ldw + cb0 + c] : 0.f;
+  for (int i = tid; i < KK * CB; i += 256) {
+    const int t = i / CB, c = i % CB;
+    s_w[i] = (c_base + c < g.C) ? w[(long)t * ldw + c_base + c] : 0.f;
   }
-  for (int i = tid; i < nch * (KK + 2); i += 256) s_red[i] = 0.f;
-  __syncthreads();
+  for (int i = tid; i < CB * (KK + 2); i += 256) s_red[i] = 0.f;
 
-  float dwa[KK][CV];
-  float s0[CV], s1[CV];
-#pragma unroll
-  for (int t = 0; t < KK; ++t)
-#pragma unroll
-    for (int c = 0; c < CV; ++c) dwa[t][c] = 0.f;
-#pragma unroll
-  for (int c = 0; c < CV; ++c) s0[c] = s1[c] = 0.f;
+  const int cg = tid % CG;
+  const bool cg_ok = c_base + cg * 8 < cpad;
 
-  if (active) {
-    const int ws = (int)(gp % g.spr);
-    const int chunk = (int)((gp / g.spr) % g.nchunks);
-    const int n = (int)(gp / ((long)g.spr * g.nchunks));
-    const int wi0 = ws * TW;            // multiple of TW (TW % S == 0)
-    const int wob = wi0 / S + RELMIN;   // first output column of the dY window
+  const int cc2 = tid % C2;
+  const int ch = c_base + 2 * cc2;
+  const bool ch_ok = ch < cpad;
+  float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
+  if (in_scale && ch_ok) { VecIO<float, 2>::load(in_scale + ch, sc); VecIO<float, 2>::load(in_shift + ch, sh); }
+  const int nstrips = g.TW / SW;
+  const int nitems = C2 * g.TH * nstrips;
 
-    float sc[CV], sh[CV], k1[CV], k2[CV], k3[CV];
-    bool cvalid[CV];
+  f32x2 dwa[KK];
 #pragma unroll
-    for (int c = 0; c < CV; ++c) { sc[c] = 1.f; sh[c] = 0.f; k1[c] = 1.f; k2[c] = 0.f; k3[c] = 0.f; cvalid[c] = (c0 + c) < g.C; }
-    if (in_scale) { VecIO<float, CV>::load(in_scale + c0, sc); VecIO<float, CV>::load(in_shift + c0, sh); }
-    if (c1) { VecIO<float, CV>::load(c1 + c0, k1); VecIO<float, CV>::load(c2 + c0, k2); VecIO<float, CV>::load(c3 + c0, k3); }
+  for (int t = 0; t < KK; ++t) dwa[t] = f32x2{0.f, 0.f};
+  float s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f};
 
-    const int hi_beg = chunk * g.rh;
-    const int hi_end = min(g.H, hi_beg + g.rh);
-    const T* xn = x + (long)n * g.H * g.W * ldx + c0;
-    T* hn = h + (long)n * g.H * g.W * ldh + c0;
-    const T* gn = gup + (long)n * g.Ho * g.Wo * ldg + c0;
-    const T* yn = yraw ? yraw + (long)n * g.Ho * g.Wo * ldyr + c0 : nullptr;
+  const int ntiles = g.N * g.tiles_y * g.tiles_x;
+  const int npix = g.LH * g.LW;
+  int p_iy[PF], p_ix[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int pidx = tid / CG + i * (256 / CG);
+    p_iy[i] = pidx < npix ? pidx / g.LW : -100000;
+    p_ix[i] = pidx % g.LW;
+  }
+  Raw8<T> pfg[PF], pfy[PF];
+  unsigned pfmask = 0;
+  auto issue = [&](int n, int ty, int tx) {
+    const int hob = cdiv(ty * g.TH + P - (K - 1), S), wob = (tx * g.TW) / S + RELMIN;
+    const T* gn = gup + (long)n * g.Ho * g.Wo * ldg + c_base + cg * 8;
+    const T* yn = yraw ? yraw + (long)n * g.Ho * g.Wo * ldyr + c_base + cg * 8 : nullptr;
+    pfmask = 0;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int ho = hob + p_iy[i], wo = wob + p_ix[i];
+      if (cg_ok && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
+        const long off = (long)ho * g.Wo + wo;
+        pfg[i].load(gn + off * ldg);
+        if (yn) pfy[i].load(yn + off * ldyr);
+        pfmask |= 1u << i;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      if (p_iy[i] >= 0) {
+        float v[8];
+        const bool ok = (pfmask >> i) & 1u;
+        float q1[8], q2[8], q3[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { q1[e] = 1.f; q2[e] = 0.f; q3[e] = 0.f; }
+        if (c1 && cg_ok) {  // reloaded per tile (L1-resident): keeps 24 registers free during the FMA phase
+          VecIO<float, 8>::load(c1 + c_base + cg * 8, q1);
+          VecIO<float, 8>::load(c2p + c_base + cg * 8, q2);
+          VecIO<float, 8>::load(c3 + c_base + cg * 8, q3);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = q1[e] * pfg[i].get(e);
+          if (yraw) a += q2[e] * pfy[i].get(e) + q3[e];
+          v[e] = ok ? a : 0.f;
+        }
+        float* d = s_dy + p_iy[i] * g.RP + p_ix[i] * CB + cg * 8;
+        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+    }
+  };
+  constexpr int NIT = (C2 * 14 * (14 / SW) + 255) / 256;
+  int it_r[NIT], it_j[NIT];
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int it = tid + q * 256;
+    const int rs = it / C2;
+    it_r[q] = it < nitems ? rs / nstrips : -1;
+    it_j[q] = rs % nstrips;
+  }
 
-    for (int hi = hi_beg; hi < hi_end; ++hi) {
-      // this row's input pixels: raw value, activated value (for dW), relu mask
-      float xraw[TW][CV], xa[TW][CV];
-      bool pvalid[TW];
-      const T* xr = xn + (long)hi * g.W * ldx;
+  int tile = worker;
+  int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
+  const int dtx = g.nworkers % g.tiles_x, dty = (g.nworkers / g.tiles_x) % g.tiles_y, dn = g.nworkers / (g.tiles_x * g.tiles_y);
+  auto advance = [&](int& an, int& aty, int& atx) {
+    atx += dtx;
+    if (atx >= g.tiles_x) { atx -= g.tiles_x; aty += 1; }
+    aty += dty;
+    if (aty >= g.tiles_y) { aty -= g.tiles_y; an += 1; }
+    an += dn;
+  };
+  int ntx = tx, nty = ty, nn = n;
+  if (tile < ntiles) issue(n, ty, tx);
+  for (; tile < ntiles; tile += g.nworkers) {
+    const int hi0 = ty * g.TH, wi0 = tx * g.TW;                 // multiples of S (TH, TW even when S == 2)
+    const int hob = cdiv(hi0 + P - (K - 1), S);                 // first output row held in LDS
+    __syncthreads();
+    commit();
+    __syncthreads();
+    ntx = tx; nty = ty; nn = n;
+    advance(nn, nty, ntx);
+    if (tile + g.nworkers < ntiles) issue(nn, nty, ntx);
+
 #pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        const int wi = wi0 + t;
-        pvalid[t] = wi < g.W;
-        if (pvalid[t]) {
-          VecIO<T, CV>::load(xr + (long)wi * ldx, xraw[t]);
+    for (int q = 0; q < (DW_EXP == 5 ? 0 : NIT); ++q) {
+      const int r = it_r[q], j = it_j[q];
+      const int hi = hi0 + r;
+      if (r < 0 || hi >= g.H || !ch_ok) continue;
+      const int wis = wi0 + j * SW;  // first input column of this strip (multiple of S)
+      // this strip's activated input pixels (for the weight gradient)
+      f32x2 xa[SW];
+      const T* xr = x + (((long)n * g.H + hi) * g.W) * ldx + ch;
 #pragma unroll
-          for (int c = 0; c < CV; ++c) {
-            float a = xraw[t][c] * sc[c] + sh[c];
-            xa[t][c] = in_relu ? fmaxf(a, 0.f) : a;
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < CV; ++c) { xraw[t][c] = 0.f; xa[t][c] = 0.f; }
+      for (int t = 0; t < SW; ++t) {
+        const int wi = wis + t;
+        xa[t] = f32x2{0.f, 0.f};
+        if (wi < g.W) {
+          float v[2];
+          VecIO<T, 2>::load(xr + (long)wi * ldx, v);
+          const float a0 = v[0] * sc[0] + sh[0], a1 = v[1] * sc[1] + sh[1];
+          xa[t] = in_relu ? f32x2{fmaxf(a0, 0.f), fmaxf(a1, 0.f)} : f32x2{a0, a1};
         }
       }
-      float dx[TW][CV];
+      f32x2 dx[SW];
 #pragma unroll
-      for (int t = 0; t < TW; ++t)
-#pragma unroll
-        for (int c = 0; c < CV; ++c) dx[t][c] = 0.f;
+      for (int t = 0; t < SW; ++t) dx[t] = f32x2{0.f, 0.f};
 
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         const int numr = hi + P - ky;
-        if (numr < 0) continue;
-        if (S > 1 && (numr % S) != 0) continue;
-        const int ho = numr / S;
-        if (ho >= g.Ho) continue;
-        // dY window for this output row
-        float dy[DW][CV];
-        const T* gr = gn + (long)ho * g.Wo * ldg;
-        const T* yr = yn ? yn + (long)ho * g.Wo * ldyr : nullptr;
+        if (S > 1 && pmod(numr, S) != 0) continue;
+        const int ho = fdiv(numr, S);
+        if (ho < 0 || ho >= g.Ho) continue;   // rows outside the image hold zeros anyway; skip the work
+        const float* row = s_dy + (ho - hob) * g.RP + ((wis - wi0) / S) * CB + 2 * cc2;
+        f32x2 dy[DWN];
 #pragma unroll
-        for (int j = 0; j < DW; ++j) {
-          const int wo = wob + j;
-          if (wo >= 0 && wo < g.Wo) {
-            float gv[CV];
-            VecIO<T, CV>::load(gr + (long)wo * ldg, gv);
-            if (yr) {
-              float yv[CV];
-              VecIO<T, CV>::load(yr + (long)wo * ldyr, yv);
-#pragma unroll
-              for (int c = 0; c < CV; ++c) dy[j][c] = k1[c] * gv[c] + k2[c] * yv[c] + k3[c];
-            } else {
-#pragma unroll
-              for (int c = 0; c < CV; ++c) dy[j][c] = k1[c] * gv[c];
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < CV; ++c) dy[j][c] = 0.f;
-          }
-        }
+        for (int i = 0; i < DWN; ++i) dy[i] = *reinterpret_cast<const f32x2*>(row + i * CB);
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-          float wv[CV];
+          const f32x2 wv = *reinterpret_cast<const f32x2*>(s_w + (ky * K + kx) * CB + 2 * cc2);
 #pragma unroll
-          for (int c = 0; c < CV; ++c) wv[c] = s_w[(ky * K + kx) * nch + cvl * CV + c];
-#pragma unroll
-          for (int t = 0; t < TW; ++t) {
-            const int num = t + P - kx;                 // compile-time after unrolling
+          for (int t = 0; t < SW; ++t) {
+            const int num = t + P - kx;  // compile-time after unrolling
             if (pmod(num, S) != 0) continue;
-            const int j = fdiv(num, S) - RELMIN;
-#pragma unroll
-            for (int c = 0; c < CV; ++c) {
-              dx[t][c] += dy[j][c] * wv[c];
-              dwa[ky * K + kx][c] += xa[t][c] * dy[j][c];
-            }
+            const int jj = fdiv(num, S) - RELMIN;
+            dx[t] += dy[jj] * wv;
+            dwa[ky * K + kx] += xa[t] * dy[jj];
           }
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep one dY row live at a time (the loop is unrolled for static dwa indices)
       }
 
-      T* hr = hn + (long)hi * g.W * ldh;
+      // epilogue: ReLU mask of the producer (x is re-read; it is hot in L1/L2), rounding, statistics
+      T* hr = h + (((long)n * g.H + hi) * g.W) * ldh + ch;
 #pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        if (pvalid[t]) {
-          float o[CV];
+      for (int t = 0; t < SW; ++t) {
+        const int wi = wis + t;
+        if (wi < g.W) {
+          float xv[2], o[2];
+          VecIO<T, 2>::load(xr + (long)wi * ldx, xv);
 #pragma unroll
-          for (int c = 0; c < CV; ++c) {
-            float a = xraw[t][c] * sc[c] + sh[c];
+          for (int c = 0; c < 2; ++c) {
+            const float a = xv[c] * sc[c] + sh[c];
             float v = (in_relu && !(a > 0.f)) ? 0.f : dx[t][c];
-            v = cvalid[c] ? to_f32(from_f32<T>(v)) : 0.f;
+            v = (ch + c < g.C) ? to_f32(from_f32<T>(v)) : 0.f;
             o[c] = v;
             s0[c] += v;
-            s1[c] += v * xraw[t][c];
+            s1[c] += v * xv[c];
           }
-          VecIO<T, CV>::store(hr + (long)(wi0 + t) * ldh, o);
+          VecIO<T, 2>::store(hr + (long)wi * ldh, o);
         }
       }
     }
+    tx = ntx; ty = nty; n = nn;
   }
 
-  if (active) {
+  // block reduction of the weight gradient and the statistics, one flush per workgroup: lanes l, l+C2, l+2*C2, ... of a
+  // wave hold the same channel pair -> butterfly over those first, then one LDS atomic per value from the first C2 lanes
+  {
+    const int lane = tid & 63;
 #pragma unroll
-    for (int c = 0; c < CV; ++c) {
-      float* r = &s_red[(cvl * CV + c) * (KK + 2)];
+    for (int t = 0; t < KK; ++t) {
 #pragma unroll
-      for (int t = 0; t < KK; ++t) atomicAdd(&r[t], dwa[t][c]);
-      atomicAdd(&r[KK], s0[c]);
-      atomicAdd(&r[KK + 1], s1[c]);
+      for (int o = 32; o >= C2; o >>= 1) {
+        dwa[t][0] += __shfl_xor(dwa[t][0], o, 64);
+        dwa[t][1] += __shfl_xor(dwa[t][1], o, 64);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= C2; o >>= 1) {
+      s0[0] += __shfl_xor(s0[0], o, 64); s0[1] += __shfl_xor(s0[1], o, 64);
+      s1[0] += __shfl_xor(s1[0], o, 64); s1[1] += __shfl_xor(s1[1], o, 64);
+    }
+    if (lane < C2) {
+      float* r0 = &s_red[(2 * cc2) * (KK + 2)];
+      float* r1 = &s_red[(2 * cc2 + 1) * (KK + 2)];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        atomicAdd(&r0[t], dwa[t][0]);
+        atomicAdd(&r1[t], dwa[t][1]);
+      }
+      atomicAdd(&r0[KK], s0[0]); atomicAdd(&r0[KK + 1], s1[0]);
+      atomicAdd(&r1[KK], s0[1]); atomicAdd(&r1[KK + 1], s1[1]);
     }
   }
   __syncthreads();
-  for (int i = tid; i < nch * (KK + 2); i += 256) {
+  for (int i = tid; i < CB * (KK + 2); i += 256) {
     const int cl = i / (KK + 2), t = i % (KK + 2);
-    const int c = cb0 + cl;
+    const int c = c_base + cl;
     if (c >= g.C) continue;
     const float v = s_red[i];
+    if (DW_EXP == 4) continue;
     if (t < KK) {
       if (dw) atomicAdd(&dw[(long)c * KK + t], v);
     } else if (stats) {
@@ -345,34 +503,90 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const T* __restrict__ gup, i
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static DwGeom make_geom(int N, int H, int W, int C, int Ho, int Wo, int CV, int TW, int rows, int cols, int max_cvb) {
-  DwGeom g;
-  g.N = N; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo;
-  const int cvecs = (C + CV - 1) / CV;
-  g.cvb = cvecs < max_cvb ? cvecs : max_cvb;
-  g.pb = 256 / g.cvb;
-  g.spr = (cols + TW - 1) / TW;
-  // aim for >= ~4096 thread strips per channel group so that the chip is filled; otherwise split rows
-  long strips = (long)N * g.spr;
-  int nch = 1;
-  while (strips * nch * ((cvecs + g.cvb - 1) / g.cvb) * g.cvb < 256L * 2048 && nch * 8 <= rows) nch *= 2;
-  g.rh = (rows + nch - 1) / nch;
-  if (g.rh % 2) g.rh += 1;  // keep chunk starts even (stride-2 row parity is then uniform across a wave)
-  g.nchunks = (rows + g.rh - 1) / g.rh;
-  return g;
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+static int slab_width(int preferred, int cpad) {
+  int need = cpad <= 8 ? 8 : (cpad <= 16 ? 16 : (cpad <= 32 ? 32 : 64));
+  return preferred < need ? preferred : need;
+}
+
+// Tile configuration.  rows/cols: extent of the tiled space (output pixels forward, input pixels backward).
+static void pick_tiles(DwGeom& g, int rows, int cols, int sw, int cb, int even) {
+  g.CB = cb;
+  g.TH = rows < 14 ? rows : 14;
+  g.TW = cols < 14 ? cols : 14;
+  g.TW = (g.TW + sw - 1) / sw * sw;  // whole strips
+  if (even && (g.TH % 2)) g.TH += 1;
+  g.tiles_y = (rows + g.TH - 1) / g.TH;
+  g.tiles_x = (cols + g.TW - 1) / g.TW;
+}
+
+static void set_workers(DwGeom& g, int nslabs, size_t lds_bytes) {
+  const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
+  int per_cu = (int)(160 * 1024 / (lds_bytes + 1024));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  long want = ((long)num_cus() * per_cu + nslabs - 1) / nslabs;
+  if (want > ntiles) want = ntiles;
+  want = (want + 7) / 8 * 8;   // one worker group per XCD
+  g.nworkers = (int)want;
+  g.nslabs = nslabs;
+}
+
+template <typename KernelT>
+static void allow_big_lds(KernelT kern, size_t lds) {
+  // dynamic LDS above 64 KiB must be opted into once per kernel (not a stream operation; done at first use)
+  static std::unordered_map<const void*, size_t> granted;
+  if (lds <= 64 * 1024) return;
+  size_t& have = granted[(const void*)kern];
+  if (lds > have) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    have = lds;
+  }
 }
 
 template <typename T, int K, int S>
 static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y,
                       int ldy, float* stats, int stat_ld, int N, int H, int W, int C, hipStream_t st) {
-  constexpr int CV = 2, TW = 4;
-  const int P = (K - 1) / 2;
-  const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
-  DwGeom g = make_geom(N, H, W, C, Ho, Wo, CV, TW, Ho, Wo, 64);
-  const int cvecs = (C + CV - 1) / CV;
-  dim3 grid((unsigned)(((long)N * g.nchunks * g.spr + g.pb - 1) / g.pb), (cvecs + g.cvb - 1) / g.cvb);
-  hipLaunchKernelGGL((k_dwconv_fwd<T, K, S, CV, TW>), grid, dim3(256), 0, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy,
-                     stats, stat_ld, g);
+  constexpr int P = (K - 1) / 2;
+  DwGeom g;
+  g.N = N; g.H = H; g.W = W; g.C = C;
+  g.Ho = (H + 2 * P - K) / S + 1; g.Wo = (W + 2 * P - K) / S + 1;
+  const int cpad = (C + 7) / 8 * 8;
+  // 14x14 output tiles of 16 channels (several workgroups per CU); small maps take the whole image and 64 channels
+  const int sw = 7;
+  const int cb = slab_width((g.Wo <= 7 && g.Ho <= 7) ? 64 : 16, cpad);
+  pick_tiles(g, g.Ho, g.Wo, sw, cb, 0);
+  ATOMNAS_REQUIRE(cb <= 16 || (g.TH <= 7 && g.TW <= 7), "dwconv_fwd: internal tile configuration error");
+  g.LH = (g.TH - 1) * S + K;
+  g.LW = (g.TW - 1) * S + K;
+  g.RP = lds_pitch(g.LW, cb);
+  const int nslabs = (cpad + cb - 1) / cb;
+  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 2 * cb) * sizeof(float);
+  ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
+  set_workers(g, nslabs, lds);
+  dim3 grid(g.nworkers * nslabs);
+#define FWD_CASE(CBV, TMV)                                                                                                   \
+  {                                                                                                                      \
+    auto kern = k_dwconv_fwd<T, K, S, 7, CBV, TMV>;                                                                           \
+    allow_big_lds(kern, lds);                                                                                            \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy, stats, stat_ld, g); \
+  }
+  const bool small = g.TH <= 7 && g.TW <= 7;
+  if (cb == 8) { if (small) FWD_CASE(8, 7) else FWD_CASE(8, 14) }
+  else if (cb == 16) { if (small) FWD_CASE(16, 7) else FWD_CASE(16, 14) }
+  else if (cb == 32) FWD_CASE(32, 7)
+  else FWD_CASE(64, 7)
+#undef FWD_CASE
   return check_launch("dwconv_fwd");
 }
 
@@ -380,14 +594,32 @@ template <typename T, int K, int S>
 static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
                       const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h,
                       int ldh, float* dw, float* stats, int stat_ld, int N, int H, int W, int C, hipStream_t st) {
-  constexpr int CV = 2, TW = 4;
-  const int P = (K - 1) / 2;
-  const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
-  DwGeom g = make_geom(N, H, W, C, Ho, Wo, CV, TW, H, W, 64);
-  const int cvecs = (C + CV - 1) / CV;
-  dim3 grid((unsigned)(((long)N * g.nchunks * g.spr + g.pb - 1) / g.pb), (cvecs + g.cvb - 1) / g.cvb);
-  hipLaunchKernelGGL((k_dwconv_bwd<T, K, S, CV, TW>), grid, dim3(256), 0, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2,
-                     c3, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)h, ldh, dw, stats, stat_ld, g);
+  constexpr int P = (K - 1) / 2;
+  constexpr int SW = (S == 2) ? 14 : 7;
+  DwGeom g;
+  g.N = N; g.H = H; g.W = W; g.C = C;
+  g.Ho = (H + 2 * P - K) / S + 1; g.Wo = (W + 2 * P - K) / S + 1;
+  const int cpad = (C + 7) / 8 * 8;
+  const int cb = slab_width(16, cpad);
+  pick_tiles(g, H, W, SW, cb, S == 2);
+  // output window of an input tile: rows ceil((hi0+P-K+1)/S) .. floor((hi0+TH-1+P)/S)
+  g.LH = fdiv(g.TH - 1 + P, S) - cdiv(P - (K - 1), S) + 1;
+  g.LW = fdiv(g.TW - 1 + P, S) - fdiv(-P, S) + 1;
+  g.RP = lds_pitch(g.LW, cb);
+  const int nslabs = (cpad + cb - 1) / cb;
+  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2)) * sizeof(float);
+  ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
+  set_workers(g, nslabs, lds);
+  dim3 grid(g.nworkers * nslabs);
+#define BWD_CASE(CBV)                                                                                                     \
+  {                                                                                                                       \
+    auto kern = k_dwconv_bwd<T, K, S, SW, CBV>;                                                                           \
+    allow_big_lds(kern, lds);                                                                                             \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2, c3, (const T*)x, ldx, sc, \
+                       sh, relu, w, ldw, (T*)h, ldh, dw, stats, stat_ld, g);                                              \
+  }
+  if (cb == 8) BWD_CASE(8) else BWD_CASE(16)
+#undef BWD_CASE
   return check_launch("dwconv_bwd");
 }
 
@@ -421,10 +653,12 @@ extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale,
   ATOMNAS_REQUIRE((k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2), "dwconv_fwd: unsupported k=%d stride=%d", k, stride);
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_fwd: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "dwconv_fwd: empty shape");
-  ATOMNAS_REQUIRE(ldx >= C && ldy >= C && ldw >= C && ldx % 2 == 0 && ldy % 2 == 0 && ldw % 2 == 0, "dwconv_fwd: bad pitch");
+  const int cpad = (C + 7) / 8 * 8;
+  ATOMNAS_REQUIRE(ldx >= cpad && ldy >= cpad && ldw >= C && ldx % 8 == 0 && ldy % 8 == 0,
+                  "dwconv_fwd: bad pitch (C=%d ldx=%d ldy=%d ldw=%d)", C, ldx, ldy, ldw);
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_fwd: scale/shift must come together");
-  hipStream_t st = (hipStream_t)stream;
   ATOMNAS_REQUIRE(!stats || stat_ld >= C, "dwconv_fwd: statistics pitch %d < C=%d", stat_ld, C);
+  hipStream_t st = (hipStream_t)stream;
   DW_DISPATCH(launch_fwd, x, ldx, in_scale, in_shift, in_relu, w, ldw, y, ldy, stats, stat_ld, N, H, W, C, st);
   return 1;
 }
@@ -437,12 +671,13 @@ extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int 
   ATOMNAS_REQUIRE((k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2), "dwconv_bwd: unsupported k=%d stride=%d", k, stride);
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_bwd: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd: empty shape");
-  ATOMNAS_REQUIRE(ldx >= C && ldg >= C && ldh >= C && ldw >= C && ldx % 2 == 0 && ldg % 2 == 0 && ldh % 2 == 0 && ldw % 2 == 0,
+  const int cpad = (C + 7) / 8 * 8;
+  ATOMNAS_REQUIRE(ldx >= cpad && ldg >= cpad && ldh >= cpad && ldw >= C && ldx % 8 == 0 && ldg % 8 == 0 && ldh % 8 == 0,
                   "dwconv_bwd: bad pitch");
-  ATOMNAS_REQUIRE(!yraw || (c1 && c2 && c3 && ldyr >= C && ldyr % 2 == 0), "dwconv_bwd: yraw needs c1,c2,c3 and a valid pitch");
+  ATOMNAS_REQUIRE(!yraw || (c1 && c2 && c3 && ldyr >= cpad && ldyr % 8 == 0), "dwconv_bwd: yraw needs c1,c2,c3 and a valid pitch");
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_bwd: scale/shift must come together");
-  hipStream_t st = (hipStream_t)stream;
   ATOMNAS_REQUIRE(!stats || stat_ld >= C, "dwconv_bwd: statistics pitch %d < C=%d", stat_ld, C);
+  hipStream_t st = (hipStream_t)stream;
   DW_DISPATCH(launch_bwd, g, ldg, yraw, ldyr, c1, c2, c3, x, ldx, in_scale, in_shift, in_relu, w, ldw, h, ldh, dw, stats, stat_ld,
               N, H, W, C, st);
   return 1;

