@@ -22,8 +22,20 @@ __global__ void k_bn_finalize_fwd(const float* __restrict__ stats, float inv_cou
     if (save_mean) { save_mean[c] = 0.f; save_invstd[c] = 0.f; }
     return;
   }
-  const float mean = stats[c] * inv_count;
-  float var = stats[C + c] * inv_count - mean * mean;
+  float p0[8], p1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) p0[u] = p1[u] = 0.f;
+  for (int r = 0; r < STAT_ROWS; r += 8) {  // partial rows, see common.h; 16 independent loads in flight
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      p0[u] += stats[(long)(r + u) * 2 * C + c];
+      p1[u] += stats[(long)(r + u) * 2 * C + C + c];
+    }
+  }
+  const float a0 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]));
+  const float a1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]));
+  const float mean = a0 * inv_count;
+  float var = a1 * inv_count - mean * mean;
   var = fmaxf(var, 0.f);
   const float invstd = 1.0f / sqrtf(var + eps);
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -61,7 +73,18 @@ __global__ void k_bn_finalize_bwd(const float* __restrict__ stats2, float inv_co
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cpad) return;
   if (c >= C) { c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
-  const float sg = stats2[c], sgx = stats2[C + c];
+  float p0[8], p1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) p0[u] = p1[u] = 0.f;
+  for (int r = 0; r < STAT_ROWS; r += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      p0[u] += stats2[(long)(r + u) * 2 * C + c];
+      p1[u] += stats2[(long)(r + u) * 2 * C + C + c];
+    }
+  }
+  const float sg = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]));
+  const float sgx = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]));
   const float mean = save_mean[c], r = save_invstd[c];
   const float g = gamma ? gamma[c] : 1.f;
   const float dg = r * (sgx - mean * sg);
@@ -218,8 +241,9 @@ __global__ __launch_bounds__(256) void k_pool_act_bwd(const T* __restrict__ dpoo
     for (int i = tid; i < 256; i += 256) {
       const int c = blockIdx.y * 256 + i;
       if (c < C) {
-        atomicAdd(&stats2[c], s_red[i * 2]);
-        atomicAdd(&stats2[C + c], s_red[i * 2 + 1]);
+        float* srow = stats2 + (long)(blockIdx.x % STAT_ROWS) * 2 * C;
+        atomicAdd(&srow[c], s_red[i * 2]);
+        atomicAdd(&srow[C + c], s_red[i * 2 + 1]);
       }
     }
   }
@@ -271,8 +295,9 @@ __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy,
     for (int i = tid; i < 256; i += 256) {
       const int c = blockIdx.y * 256 + i;
       if (c < C) {
-        atomicAdd(&stats2[c], s_red[i * 2]);
-        atomicAdd(&stats2[C + c], s_red[i * 2 + 1]);
+        float* srow = stats2 + (long)(blockIdx.x % STAT_ROWS) * 2 * C;
+        atomicAdd(&srow[c], s_red[i * 2]);
+        atomicAdd(&srow[C + c], s_red[i * 2 + 1]);
       }
     }
   }
@@ -291,7 +316,7 @@ extern "C" int atomnas_bn_finalize_fwd(const float* stats, double count, const f
   const int Cpad = (C + 7) / 8 * 8;
   const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 255) / 256), dim3(256), 0, st, stats, (float)(1.0 / count), unbias, gamma, beta,
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 63) / 64), dim3(64), 0, st, stats, (float)(1.0 / count), unbias, gamma, beta,
                      eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C, Cpad);
   return check_launch("bn_finalize_fwd");
 }
@@ -310,7 +335,7 @@ extern "C" int atomnas_bn_finalize_bwd(const float* stats2, double count, const 
                                        float* dbeta, float* c1, float* c2, float* c3, int C, void* stream) {
   ATOMNAS_REQUIRE(stats2 && save_mean && save_invstd && c1 && c2 && c3 && C > 0 && count > 0, "bn_finalize_bwd: bad arguments");
   const int Cpad = (C + 7) / 8 * 8;
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats2, (float)(1.0 / count),
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats2, (float)(1.0 / count),
                      gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, Cpad);
   return check_launch("bn_finalize_bwd");
 }

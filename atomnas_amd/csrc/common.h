@@ -16,6 +16,11 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
 
+// Per-channel statistics are accumulated into STAT_ROWS partial rows ([STAT_ROWS][2][pitch], zero-initialised) that the
+// BatchNorm finalize kernels sum: atomics on ONE address from thousands of workgroups serialise at ~350 ns each on
+// MI355X (device-scope atomics resolve at the memory side), which cost 10x the kernel itself before the rows were split.
+constexpr int STAT_ROWS = 64;
+
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);

@@ -238,8 +238,9 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
     for (int i = tid; i < CB; i += 256) {
       const int c = c_base + i;
       if (c < g.C) {
-        atomicAdd(&stats[c], s_st[i]);
-        atomicAdd(&stats[stat_ld + c], s_st[CB + i]);
+        float* srow = stats + (long)(worker % STAT_ROWS) * 2 * stat_ld;
+        atomicAdd(&srow[c], s_st[i]);
+        atomicAdd(&srow[stat_ld + c], s_st[CB + i]);
       }
     }
   }
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     if (t < KK) {
       if (dw) atomicAdd(&dw[(long)c * KK + t], v);
     } else if (stats) {
-      atomicAdd(&stats[(long)(t - KK) * stat_ld + c], v);
+      atomicAdd(&stats[(long)(worker % STAT_ROWS) * 2 * stat_ld + (long)(t - KK) * stat_ld + c], v);
     }
   }
 }

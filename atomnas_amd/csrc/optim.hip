@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_reg_value(const float* __restrict__ p, 
 extern "C" int atomnas_reg_grad(const float* p, float* g, const void* jobs_dev, int njobs, int use_sign, const float* mult_ptr,
                                 const float* grad_out_ptr, void* stream) {
   ATOMNAS_REQUIRE(p && g && jobs_dev && njobs > 0, "reg_grad: bad arguments");
-  hipLaunchKernelGGL(atomnas::k_reg_grad, dim3(8, njobs), dim3(256), 0, (hipStream_t)stream, p, g, (const atomnas::RegJob*)jobs_dev,
+  hipLaunchKernelGGL(atomnas::k_reg_grad, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, p, g, (const atomnas::RegJob*)jobs_dev,
                      use_sign, mult_ptr, grad_out_ptr);
   return atomnas::check_launch("reg_grad");
 }
@@ -193,7 +193,7 @@ extern "C" int atomnas_reg_grad(const float* p, float* g, const void* jobs_dev, 
 extern "C" int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_abs, const float* mult_ptr,
                                  float post_scale, float* out, void* stream) {
   ATOMNAS_REQUIRE(p && out && jobs_dev && njobs > 0, "reg_value: bad arguments");
-  hipLaunchKernelGGL(atomnas::k_reg_value, dim3(8, njobs), dim3(256), 0, (hipStream_t)stream, p, (const atomnas::RegJob*)jobs_dev,
+  hipLaunchKernelGGL(atomnas::k_reg_value, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, p, (const atomnas::RegJob*)jobs_dev,
                      use_abs, mult_ptr, post_scale, out);
   return atomnas::check_launch("reg_value");
 }

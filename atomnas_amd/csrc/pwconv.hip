@@ -100,7 +100,7 @@ struct Epilogue {
   const void* z; int ldz;              // optional raw activation stream (storage T) for mask / STAT_Z
   const float* zscale; const float* zshift; int mask;  // mask: c *= [z*zscale+zshift > 0]
   const float* bias;                   // optional per-output-channel bias
-  float* stats; int stat_mode;         // [2][N] fp32, accumulated atomically
+  float* stats; int stat_mode;         // [STAT_ROWS][2][N] fp32 partial rows, accumulated atomically
 };
 
 constexpr int NT_MAX_STAT = 3520;  // largest hidden width of the supernet (3*1152) rounded up to 64
@@ -251,9 +251,142 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
 
   if (do_stats) {
     __syncthreads();
+    float* srow = ep.stats + (long)(blockIdx.x % STAT_ROWS) * 2 * N;
     for (int i = tid; i < 2 * N; i += 256) {
       const float v = s_stat[i];
-      if (v != 0.f) atomicAdd(&ep.stats[i], v);
+      if (v != 0.f) atomicAdd(&srow[i], v);
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ gemm_nt, column-stationary
+// For the expand-like shapes (K <= 192, N large: the 6x-wide hidden tensor is the OUTPUT).  A wave owns one 64-channel
+// chunk of the output and a range of 16-row tiles: the weight fragments of the chunk stay in registers for the whole range
+// (no weight traffic in the row loop), and the per-channel statistics are accumulated per lane across the rows and reduced
+// once at the end (the row-stationary kernel pays 128 cross-lane operations per tile for them).  A is re-read once per
+// chunk, from L2: it is the narrow operand (K/N of the output bytes).
+template <int MODE, int KSTEPS>
+__global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K,
+                                                    int nchunks, int tiles_per_item) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, j = lane & 15;
+  const int wrow = 16 * (j >> 2) + (j & 3);
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long mtiles = (M + 15) / 16;
+  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
+  if (item >= nranges * nchunks) return;
+  // consecutive items share the row range and differ in the chunk: the waves of a workgroup (and its XCD neighbours) then
+  // re-read the same rows of A from L2 while they are hot
+  const int chunk = (int)(item % nchunks);
+  const long range = item / nchunks;
+  const int nc = chunk * 64;
+  const int nb = nc + 16 * q;
+  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+
+  typename MM::frag wf[KSTEPS][4];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[ks][t] = MM::raw(Wp + (long)(nc + wrow + 4 * t) * ldw + ks * 32 + 8 * q);
+
+  float s1[16], s2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+
+  const long mt_beg = range * tiles_per_item;
+  const long mt_end = mt_beg + tiles_per_item < mtiles ? mt_beg + tiles_per_item : mtiles;
+  for (long mt = mt_beg; mt < mt_end; ++mt) {
+    const long row = mt * 16 + j;
+    const bool rowvalid = row < M;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      float av[8];
+      load_pro<T, MODE>(A, row, rowvalid, ks * 32 + 8 * q, K, av);
+      const typename MM::frag af = MM::pack(av);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
+    }
+    if (!rowvalid) continue;
+    float c[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[4 * t + r] = acc[t][r];
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+      const int n8 = nb + 8 * h8;
+      if (n8 >= N) continue;
+      float zv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) zv[i] = 0.f;
+      if (ep.bias) {
+        float bs[8];
+        VecIO<float, 8>::load(ep.bias + n8, bs);  // per-channel vectors are readable up to N rounded up to 8
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[8 * h8 + i] += bs[i];
+      }
+      if (ep.add) {
+        float tmp[8];
+        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.add) + row * ep.ldadd + n8, tmp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
+      }
+      if (ep.z) {
+        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + row * ep.ldz + n8, zv);
+        if (ep.mask) {
+          float zs[8], zh[8];
+          VecIO<float, 8>::load(ep.zscale + n8, zs);
+          VecIO<float, 8>::load(ep.zshift + n8, zh);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float a = zv[i] * zs[i] + zh[i];
+            if (!(a > 0.f)) c[8 * h8 + i] = 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n8 + i >= N) c[8 * h8 + i] = 0.f;
+      float o8[8];
+      if (ep.out_f32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
+        VecIO<float, 8>::store(reinterpret_cast<float*>(ep.c) + row * ep.ldc + n8, o8);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
+        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + row * ep.ldc + n8, o8);
+      }
+      if (do_stats) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          s1[8 * h8 + i] += o8[i];
+          s2[8 * h8 + i] += (ep.stat_mode == STAT_SQ) ? o8[i] * o8[i] : o8[i] * zv[i];
+        }
+      }
+    }
+  }
+
+  if (do_stats) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float a = s1[i], b = s2[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (j == 0 && nb + i < N) {
+        float* srow = ep.stats + (long)(range % STAT_ROWS) * 2 * N;
+        atomicAdd(&srow[nb + i], a);
+        atomicAdd(&srow[N + nb + i], b);
+      }
     }
   }
 }
@@ -350,8 +483,34 @@ __global__ __launch_bounds__(256) void k_gemm_tn(Operand U, int NU, Operand V, i
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+template <int KSTEPS>
+static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
+  const int nchunks = (N + 63) / 64;
+  const long mtiles = (M + 15) / 16;
+  // about 16 waves per CU in flight, but at least 8 row tiles per item so that the register-resident weights pay off
+  long tiles_per_item = (mtiles * nchunks + 4095) / 4096;
+  if (tiles_per_item < 8) tiles_per_item = 8;
+  const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;
+  dim3 grid((unsigned)((items + 3) / 4)), block(256);
+  const bf16_t* W = (const bf16_t*)Wp;
+  if (mode == PRO_NONE) hipLaunchKernelGGL((k_gemm_nt_cs<PRO_NONE, KSTEPS>), grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);
+  else if (mode == PRO_BNRELU) hipLaunchKernelGGL((k_gemm_nt_cs<PRO_BNRELU, KSTEPS>), grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);
+  else hipLaunchKernelGGL((k_gemm_nt_cs<PRO_BNBWD, KSTEPS>), grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);
+}
+
 template <typename T>
 static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    // column-stationary form when the output is the wide operand
+    if (K <= 192 && N >= 2 * K && N >= 96 && M >= 1024) {
+      const int ksteps = (K + 31) / 32;
+      if (ksteps == 1) launch_nt_cs<1>(mode, A, Wp, ldw, ep, M, N, K, st);
+      else if (ksteps == 2) launch_nt_cs<2>(mode, A, Wp, ldw, ep, M, N, K, st);
+      else if (ksteps == 3) launch_nt_cs<3>(mode, A, Wp, ldw, ep, M, N, K, st);
+      else launch_nt_cs<6>(mode, A, Wp, ldw, ep, M, N, K, st);
+      return check_launch("gemm_nt_cs");
+    }
+  }
   constexpr int KS = 4 * Mma<T>::EPL;
   const int Kpad = (K + KS - 1) / KS * KS;
   const long mtiles = (M + 15) / 16;

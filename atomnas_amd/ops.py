@@ -13,6 +13,7 @@ from ._lib import call
 PRO_NONE, PRO_BNRELU, PRO_BNBWD = 0, 1, 2
 STAT_NONE, STAT_SQ, STAT_Z = 0, 1, 2
 HYP_LR, HYP_RHO, HYP_EMA_DECAY, HYP_GRAD_SCALE = 0, 1, 2, 3
+STAT_ROWS = 64  # partial rows of every statistics buffer ([STAT_ROWS][2][C], see include/atomnas_hip.h)
 
 
 def _p(t):

@@ -13,7 +13,8 @@
  *   - activations are NHWC viewed as [M = N*H*W rows][C channels] with an explicit channel pitch ld (elements);
  *     ld is a multiple of 8 and channels C..ld-1 hold zeros.  dtype: 0 = fp32, 1 = bf16 storage (fp32 accumulation).
  *   - per-channel fp32 vectors (scale, shift, c1..c3, gamma, ...) are readable up to C rounded up to 8.
- *   - "stats" outputs are accumulated atomically into zero-initialised fp32 buffers of shape [2][C].
+ *   - "stats" outputs are accumulated atomically into zero-initialised fp32 buffers of shape [ATOMNAS_STAT_ROWS][2][C]
+ *     (partial rows; the BatchNorm finalize functions sum them -- same-address atomics serialise on MI355X).
  */
 #ifndef ATOMNAS_HIP_H
 #define ATOMNAS_HIP_H
@@ -21,6 +22,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define ATOMNAS_STAT_ROWS 64
 
 #define ATOMNAS_DT_F32 0
 #define ATOMNAS_DT_BF16 1

@@ -160,7 +160,7 @@ def test_model_forward_backward(gpu_lib, dtype):
     ref_loss = orc.ce_label_smooth(ref_logits, y, 0.1).mean()
     ref_loss.backward()
     if dtype == torch.float32:
-        ta, tg = dict(rtol=2e-3, atol=2e-4), dict(rtol=1e-2, atol=1e-3)
+        ta, tg = dict(rtol=2e-3, atol=2e-4), dict(rtol=1e-2, atol=3e-3)  # fp32: atomics / accumulation order only
     else:
         ta, tg = dict(rtol=3e-2, atol=3e-2), None
     assert_close("logits", logits, ref_logits, **ta)

@@ -53,12 +53,13 @@ def test_dwconv_fwd(gpu_lib, dtype, k, stride, N, C, H, W):
         yref = F.conv2d(xa, w.double(), None, stride, (k - 1) // 2, 1, C)
         Ho, Wo = yref.shape[2:]
         yb = fresh(N * Ho * Wo, C, dtype)
-        stats = torch.zeros(2, C, dtype=torch.float32, device="cuda")
+        stats = torch.zeros(64, 2, C, dtype=torch.float32, device="cuda")
         ops.dwconv_fwd(xb, cvec(sc) if fuse else None, cvec(sh) if fuse else None, fuse, taps(w), yb, stats, C, N, H, W, C, k, stride)
         torch.cuda.synchronize()
         y = from_act(yb, N, Ho, Wo, C)
         assert_close("y", y, yref, **tol(dtype))
         assert float(yb[:, C:].abs().max() if pad8(C) > C else 0) == 0.0
+        stats = stats.sum(0)  # partial rows
         assert_close("sum", stats[0], y.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
         assert_close("sumsq", stats[1], (y * y).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
 
@@ -93,7 +94,7 @@ def test_dwconv_bwd(gpu_lib, dtype, k, stride, N, C, H, W):
         href = xa.grad * (pre > 0).double() if fuse else xa.grad
         hb = fresh(N * H * W, C, dtype)
         dw = torch.zeros(C, k * k, dtype=torch.float32, device="cuda")
-        stats = torch.zeros(2, C, dtype=torch.float32, device="cuda")
+        stats = torch.zeros(64, 2, C, dtype=torch.float32, device="cuda")
         ops.dwconv_bwd(to_act(gup, dtype), to_act(yraw, dtype) if fuse else None, cvec(c1) if fuse else None,
                        cvec(c2) if fuse else None, cvec(c3) if fuse else None, to_act(x, dtype), cvec(sc) if fuse else None,
                        cvec(sh) if fuse else None, fuse, taps(w), hb, dw, stats, C, N, H, W, C, k, stride)
@@ -102,6 +103,7 @@ def test_dwconv_bwd(gpu_lib, dtype, k, stride, N, C, H, W):
         t = tol(dtype)
         assert_close("h", h, href, t["rtol"], t["atol"] * 4)
         assert_close("dw", dw.reshape(C, 1, k, k), wd.grad, rtol=2e-3, atol=2e-3 * float(wd.grad.abs().max()))
+        stats = stats.sum(0)
         assert_close("sum_h", stats[0], h.sum((0, 2, 3)), rtol=1e-4, atol=2e-3)
         assert_close("sum_hx", stats[1], (h * rounded(x, dtype)).sum((0, 2, 3)), rtol=1e-4, atol=2e-3)
 
@@ -160,7 +162,7 @@ def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
         kw.update(bias=cvec(bias))
         out_dtype = torch.float32
     Cb = fresh(M, N, out_dtype)
-    stats = torch.zeros(2, N, dtype=torch.float32, device="cuda") if "stat_mode" in kw else None
+    stats = torch.zeros(64, 2, N, dtype=torch.float32, device="cuda") if "stat_mode" in kw else None
     ops.gemm_nt(act2d(A, K), pack_w(W, dtype), Cb, M, N, K, stats=stats, **kw)
     torch.cuda.synchronize()
     Cg = Cb[:, :N].double().cpu()
@@ -170,6 +172,7 @@ def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
     if pad8(N) > N:
         assert float(Cb[:, N:].abs().max()) == 0.0
     if stats is not None:
+        stats = stats.sum(0)
         s1 = Cg.sum(0)
         s2 = (Cg * Cg).sum(0) if kw["stat_mode"] == ops.STAT_SQ else (Cg * rd(Z)).sum(0)
         assert_close("s1", stats[0], s1, rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale))
