@@ -77,13 +77,18 @@ class TrainStep:
     def _capture(self):
         mgr = self.mgr
         mgr.ensure()
+        # warm-up outside capture (allocator pools, lazy initialisation); it must not leave a trace in the training state:
+        # BN running statistics / counters are snapshotted and restored, gradients are re-zeroed by the step itself
+        keep_s, keep_c = mgr.S.clone(), mgr.CNT.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):   # warm-up outside capture (allocator pools, lazy initialisation)
+        with torch.cuda.stream(s):
             for _ in range(2):
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        mgr.S.copy_(keep_s)
+        mgr.CNT.copy_(keep_c)
         self.g_fwd_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fwd_bwd):
             self._fwd_bwd()
