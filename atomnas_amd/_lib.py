@@ -38,6 +38,8 @@ SIGNATURES = {
     "atomnas_pack_weights": [vp, vp, vp, i32, i32, vp],
     "atomnas_gamma_mask": [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp],
     "atomnas_channel_repack": [vp, vp, i32, vp, i32, vp, vp],
+    "atomnas_mask_index": [vp, i32, vp, vp, vp],
+    "atomnas_gather_dim": [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp],
 }
 NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version": (i32, []),
              "atomnas_runtime_version": (i32, [])}

@@ -95,3 +95,63 @@ extern "C" int atomnas_channel_repack(const void* src_ptrs_dev, const void* dst_
                      narenas, (const RepackJob*)jobs_dev, index);
   return check_launch("channel_repack");
 }
+
+// ---- single-tensor forms used by the reference-compatible per-tensor protocol (info['mask_hook'](new, old, mask))
+namespace atomnas {
+// index[k] = position of the k-th non-zero byte of mask[0..count); kept[0] = number of non-zero bytes (one workgroup)
+__global__ __launch_bounds__(256) void k_mask_index(const unsigned char* __restrict__ mask, int count, int* __restrict__ index,
+                                                    int* __restrict__ kept) {
+  __shared__ int s_scan[256];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < count; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    const int alive = (c < count && mask[c] != 0) ? 1 : 0;
+    s_scan[threadIdx.x] = alive;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int v = (threadIdx.x >= o) ? s_scan[threadIdx.x - o] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int incl = s_scan[threadIdx.x];
+    const int base = s_base;
+    if (alive) index[base + incl - 1] = c;
+    __syncthreads();
+    if (threadIdx.x == 255) s_base = base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) kept[0] = s_base;
+}
+
+// dst[o*dst_os + j*dst_ds + i] = src[o*src_os + index[j]*src_ds + i]   (fp32 elements)
+__global__ __launch_bounds__(256) void k_gather_dim(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ index,
+                                                    long src_os, long src_ds, long dst_os, long dst_ds, int outer, int n_kept, int inner) {
+  const long total = (long)outer * n_kept * inner;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e % inner);
+    const int j = (int)((e / inner) % n_kept);
+    const int o = (int)(e / ((long)inner * n_kept));
+    dst[o * dst_os + j * dst_ds + i] = src[o * src_os + (long)index[j] * src_ds + i];
+  }
+}
+}  // namespace atomnas
+
+extern "C" int atomnas_mask_index(const unsigned char* mask, int count, int* index, int* kept, void* stream) {
+  ATOMNAS_REQUIRE(mask && index && kept && count > 0, "mask_index: bad arguments");
+  hipLaunchKernelGGL(atomnas::k_mask_index, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, count, index, kept);
+  return atomnas::check_launch("mask_index");
+}
+
+extern "C" int atomnas_gather_dim(const float* src, float* dst, const int* index, long src_os, long src_ds, long dst_os, long dst_ds,
+                                  int outer, int n_kept, int inner, void* stream) {
+  ATOMNAS_REQUIRE(src && dst && index && outer > 0 && n_kept > 0 && inner > 0, "gather_dim: bad arguments");
+  const long total = (long)outer * n_kept * inner;
+  long blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(atomnas::k_gather_dim, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, index, src_os, src_ds,
+                     dst_os, dst_ds, outer, n_kept, inner);
+  return atomnas::check_launch("gather_dim");
+}

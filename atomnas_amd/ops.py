@@ -171,3 +171,41 @@ def reg_grad(p, g, jobs_dev, njobs, use_sign, mult_ptr=None, grad_out=None):
 
 def reg_value(p, jobs_dev, njobs, use_abs, mult_ptr, post_scale, out):
     call("atomnas_reg_value", _p(p), _p(jobs_dev), njobs, int(use_abs), _p(mult_ptr), float(post_scale), _p(out), _stream())
+
+
+def gather_by_mask(dst, src, mask, dim):
+    """dst <- src[mask] (dim 0) or src[:, mask] (dim 1) on device, fp32, arbitrary strides: mask -> ascending kept-channel
+    index (atomnas_mask_index), then an index-packed gather (atomnas_gather_dim).  The integer index is bit-exact with
+    torch.nonzero by construction (stable prefix sum)."""
+    _chk_cuda(dst, src, mask)
+    if src.dtype != torch.float32 or dst.dtype != torch.float32:
+        raise TypeError("gather_by_mask moves fp32 master tensors")
+    n = src.shape[dim]
+    m8 = mask.to(torch.uint8).contiguous()
+    index = torch.empty(n, dtype=torch.int32, device=src.device)
+    kept = torch.zeros(1, dtype=torch.int32, device=src.device)
+    call("atomnas_mask_index", _p(m8), n, _p(index), _p(kept), _stream())
+    n_kept = dst.shape[dim]
+    if n_kept == 0:
+        return index, kept
+    if dim == 0:
+        inner = 1
+        for s_ in src.shape[1:]:
+            inner *= s_
+        sv, dv = src.reshape(n, inner) if src.is_contiguous() else None, dst.reshape(n_kept, inner) if dst.is_contiguous() else None
+        if sv is None or dv is None:
+            raise ValueError("dim-0 gather needs contiguous tensors")
+        call("atomnas_gather_dim", _p(sv), _p(dv), _p(index), 0, inner, 0, inner, 1, n_kept, inner, _stream())
+    elif dim == 1:
+        outer = src.shape[0]
+        inner = 1
+        for s_ in src.shape[2:]:
+            inner *= s_
+        if inner != 1 and not (src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("dim-1 gather of strided tensors supports trailing singleton dimensions only")
+        s_os, s_ds = (src.stride(0), src.stride(1)) if inner == 1 else (src.shape[1] * inner, inner)
+        d_os, d_ds = (dst.stride(0), dst.stride(1)) if inner == 1 else (dst.shape[1] * inner, inner)
+        call("atomnas_gather_dim", _p(src), _p(dst), _p(index), s_os, s_ds, d_os, d_ds, outer, n_kept, inner, _stream())
+    else:
+        raise NotImplementedError()
+    return index, kept

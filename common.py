@@ -1,0 +1,158 @@
+"""Glue between train.py and the hot path, with the reference's function names (common.py): model factory, forward_loss,
+EMA setup / EMA-model extraction, derived batch size / learning rate / steps per epoch, MAC stamping."""
+import copy
+import importlib
+import logging
+import math
+
+import torch
+
+from atomnas_amd.models import mobilenet_base as mb
+from atomnas_amd.utils import distributed as udist
+from atomnas_amd.utils import optim
+from atomnas_amd.utils.common import get_params_by_name
+from atomnas_amd.utils.config import FLAGS
+from atomnas_amd.utils.model_profiling import model_profiling
+
+
+class Meters(object):
+    """Device-side running sums (loss, top-1 / top-5 hits, samples): no per-step host synchronisation; flushed (one small
+    all-reduce when distributed) every log interval -- replaces the list-backed ScalarMeters + all_gather of common.py:83-114."""
+
+    def __init__(self, phase, device):
+        self.phase = phase
+        self.acc = torch.zeros(4, dtype=torch.float64, device=device)   # loss sum, top1 hits, top5 hits, samples
+
+    def add(self, loss_vec, topk_correct):
+        self.acc[0] += loss_vec.detach().double().sum()
+        self.acc[1] += topk_correct[0].double()
+        self.acc[2] += topk_correct[1].double()
+        self.acc[3] += loss_vec.numel()
+
+    def flush(self):
+        acc = self.acc.clone()
+        if FLAGS.use_distributed:
+            torch.distributed.all_reduce(acc)
+        self.acc.zero_()
+        loss, t1, t5, n = acc.tolist()
+        n = max(n, 1.0)
+        return {'loss': loss / n, 'top1_error': 1.0 - t1 / n, 'top5_error': 1.0 - t5 / n}
+
+
+def get_meters(phase, device='cuda'):
+    return Meters(phase, device)
+
+
+def get_model():
+    """Model from FLAGS.model (module path, e.g. models.mobilenet_supernet) and FLAGS.model_kwparams, initialised and wrapped
+    for data parallelism (common.py:127-146)."""
+    model_lib = importlib.import_module(FLAGS.model)
+    model = model_lib.Model(**FLAGS.model_kwparams, input_size=FLAGS.image_size)
+    if FLAGS.reset_parameters:
+        method = FLAGS.get('reset_param_method', None)
+        if method == 'slimmable':
+            model.apply(mb.init_weights_slimmable)
+        elif method == 'mnas':
+            model.apply(mb.init_weights_mnas)
+        elif method is not None:
+            raise ValueError('Unknown init method: {}'.format(method))
+        logging.info('Init model by: {}'.format(method))
+    if FLAGS.get('compute_dtype', 'bf16') == 'f32':
+        model.set_compute_dtype(torch.float32)
+    model.cuda()
+    if FLAGS.use_distributed:
+        wrapper = udist.AllReduceDistributedDataParallel(model)
+    else:
+        wrapper = _SingleProcessWrapper(model)
+    return model, wrapper
+
+
+class _SingleProcessWrapper(torch.nn.Module):
+    """`.module` indirection without torch.nn.DataParallel (one process drives one GPU here)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+
+def unwrap_model(model_wrapper):
+    return model_wrapper.module
+
+
+def setup_ema(model):
+    """EMA over all parameters and BN running statistics; decay adjusted to the global batch size (common.py:42-64)."""
+    if FLAGS.moving_average_decay <= 0.0:
+        return None
+    decay = FLAGS.moving_average_decay
+    if FLAGS.moving_average_decay_adjust:
+        decay = optim.ExponentialMovingAverage.adjust_momentum(decay, FLAGS.moving_average_decay_base_batch / FLAGS.batch_size)
+    logging.info('Moving average for model parameters: {}'.format(decay))
+    ema = optim.ExponentialMovingAverage(decay)
+    for name, p in model.named_parameters():
+        ema.register(name, p)
+    for name, b in model.named_buffers():
+        if 'running_var' in name or 'running_mean' in name:
+            ema.register(name, b)
+    return ema
+
+
+def forward_loss(model, criterion, input, target, meter):
+    """Forward + per-sample loss; top-k hits are counted on device by the criterion (common.py:67-80 does two host syncs)."""
+    output = model(input)
+    loss = criterion(output, target)
+    if meter is not None:
+        topk = getattr(criterion, 'topk_correct', None)
+        if topk is None:   # plain CrossEntropyLoss in validation
+            _, pred = output.topk(5)
+            hit = pred.eq(target.view(-1, 1))
+            topk = torch.stack([hit[:, :1].any(1).sum(), hit.any(1).sum()])
+        meter.add(loss, topk)
+        if getattr(criterion, 'topk_correct', None) is not None:
+            criterion.topk_correct.zero_()
+    return torch.mean(loss)
+
+
+def get_ema_model(ema, model_wrapper):
+    """A copy of the model carrying the EMA weights (common.py:155-172); the copy gets its own arenas."""
+    if ema is None:
+        return model_wrapper
+    src = unwrap_model(model_wrapper)
+    clone = copy.deepcopy(_detached(src))
+    clone.cuda()
+    table = dict(clone.named_parameters())
+    table.update(dict(clone.named_buffers()))
+    with torch.no_grad():
+        for name in ema.average_names():
+            table[name].copy_(ema.average(name))
+    return _SingleProcessWrapper(clone)
+
+
+def _detached(model):
+    """Shallow structural copy source for deepcopy: drops arena bookkeeping so that the clone materialises its own."""
+    shadow = copy.copy(model)
+    shadow.__dict__ = dict(model.__dict__)
+    shadow.__dict__.pop('_arena', None)
+    return shadow
+
+
+def profiling(model, use_cuda=True):
+    logging.info('Start model profiling, use_cuda:{}.'.format(use_cuda))
+    model_profiling(model, FLAGS.image_size, FLAGS.image_size, verbose=False)
+
+
+def setup_distributed(num_images=None):
+    """batch_size = world * per_gpu_batch_size; lr = base_lr * batch / base_total_batch; steps per epoch = ceil(N / batch)
+    (common.py:185-209)."""
+    if FLAGS.use_distributed:
+        udist.init_dist()
+        FLAGS.batch_size = udist.get_world_size() * FLAGS.per_gpu_batch_size
+    else:
+        FLAGS.batch_size = FLAGS.per_gpu_batch_size
+    FLAGS._loader_batch_size = FLAGS.per_gpu_batch_size
+    if 'base_lr' in FLAGS:
+        FLAGS.lr = FLAGS.base_lr * (FLAGS.batch_size / FLAGS.base_total_batch)
+    if num_images:
+        FLAGS._steps_per_epoch = math.ceil(num_images / FLAGS.batch_size)

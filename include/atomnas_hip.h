@@ -154,6 +154,13 @@ int atomnas_gamma_mask(const float* params, const float* ema, const void* jobs_d
 int atomnas_channel_repack(const void* src_ptrs_dev, const void* dst_ptrs_dev, int narenas, const void* jobs_dev, int njobs,
                            const int* index, void* stream);
 
+/* single-tensor forms of the same repack, for the reference's per-tensor protocol info['mask_hook'](new, old, mask)
+ *   (models/compress_utils.py:31-37): kept-channel index of a byte mask, then a gather along one dimension of an fp32 tensor
+ *   viewed as [outer][dim][inner] with explicit element strides. */
+int atomnas_mask_index(const unsigned char* mask, int count, int* index, int* kept, void* stream);
+int atomnas_gather_dim(const float* src, float* dst, const int* index, long src_os, long src_ds, long dst_os, long dst_ds, int outer,
+                       int n_kept, int inner, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,3 +56,41 @@ def assert_close(name, got, ref, rtol, atol, outlier_frac=0.0, rel_l2=None):
         raise AssertionError("%s: %d/%d mismatches, max err %.4g (ref max %.4g), first at %s got %.6g ref %.6g" %
                              (name, int(bad.sum()), bad.numel(), float(err.max()), float(ref.abs().max()), idx,
                               float(got[tuple(idx)]), float(ref[tuple(idx)])))
+
+
+# ---- deterministic, RNG-free fills shared with tools/make_golden.py (inputs of the golden fixtures are regenerated, not stored)
+def counter_fill(t, seed):
+    n = t.numel()
+    idx = torch.arange(n, dtype=torch.float64)
+    v = torch.sin(idx * 12.9898 + seed * 78.233) * 43758.5453
+    v = v - torch.floor(v)   # [0, 1)
+    return (v - 0.5).reshape(t.shape)
+
+
+def randomize_counter(module, seed):
+    with torch.no_grad():
+        for i, (n, p) in enumerate(module.named_parameters()):
+            f = counter_fill(p, seed + i)
+            if p.dim() == 1 and "bias" not in n:
+                p.copy_(f + 1.0)
+            elif p.dim() == 1:
+                p.copy_(f * 0.4)
+            else:
+                p.copy_(f * 2.0 / p[0].numel() ** 0.5)
+        for i, (n, b) in enumerate(module.named_buffers()):
+            if "running_mean" in n:
+                b.copy_(counter_fill(b, seed + 1000 + i) * 0.2)
+            elif "running_var" in n:
+                b.copy_(counter_fill(b, seed + 2000 + i) + 1.0)
+
+
+def check_digest(name, t, d, rtol=1e-6):
+    """Compares a tensor with the fingerprint stored in a golden fixture (shape, sum, sum of squares, head, tail)."""
+    f = t.detach().double().cpu().flatten()
+    assert tuple(t.shape) == tuple(d["shape"]), (name, tuple(t.shape), d["shape"])
+    scale = max(1.0, abs(d["sum"]), d["sumsq"] ** 0.5)
+    assert abs(float(f.sum()) - d["sum"]) <= rtol * scale * max(1.0, f.numel() ** 0.5), (name, float(f.sum()), d["sum"])
+    assert abs(float((f * f).sum()) - d["sumsq"]) <= rtol * max(1.0, d["sumsq"]) * 10, (name, float((f * f).sum()), d["sumsq"])
+    s = max(1e-6, float(d["head"].abs().max()), float(d["tail"].abs().max()))
+    assert float((f[:4] - d["head"]).abs().max()) <= rtol * 100 * s + 1e-12, (name, f[:4], d["head"])
+    assert float((f[-4:] - d["tail"]).abs().max()) <= rtol * 100 * s + 1e-12, (name, f[-4:], d["tail"])

@@ -1,0 +1,170 @@
+"""Pins the CPU oracle (oracle/atomnas_oracle.py) against fixtures produced by running the REFERENCE in this container
+(tools/make_golden.py -> tests/golden/*.pt).  CPU only; the GPU tests then compare the HIP path with the pinned oracle."""
+import collections
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import atomnas_oracle as orc  # noqa: E402
+
+from kutil import assert_close, check_digest, counter_fill, randomize_counter  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=False)
+
+
+def _spec_of(kw):
+    """Structure description from supernet kwargs only (no module needed): mirrors models/mobilenet_supernet.py:124-163."""
+    blocks = []
+    width = kw["input_channel"]
+    idx = 1
+    for t, c, n, s, ks in kw["inverted_residual_setting"]:
+        for rep in range(n):
+            stride = s if rep == 0 else 1
+            blocks.append(dict(name="features.%d" % idx, inp=width, oup=c, stride=stride, expand=t != 1,
+                               channels=[int(round(width * t))] * len(ks), ks=list(ks), res=stride == 1 and width == c))
+            width = c
+            idx += 1
+    return dict(stem="features.0", last="features.%d" % idx, blocks=blocks, eps=kw["batch_norm_epsilon"], momentum=kw["batch_norm_momentum"],
+                dropout=kw.get("dropout_ratio", 0.2), act=kw["active_fn"], pool=kw["input_size"] // 32, num_classes=kw["num_classes"])
+
+
+def test_blocks_forward_backward_eval():
+    g = load("blocks.pt")
+    for name, b in g.items():
+        cfg = b["cfg"]
+        blk = dict(name="blk", inp=cfg["inp"], oup=cfg["oup"], stride=cfg["stride"], expand=cfg["expand"], channels=cfg["channels"],
+                   ks=cfg["ks"], res=cfg["stride"] == 1 and cfg["inp"] == cfg["oup"])
+        spec = dict(eps=1e-3, momentum=0.01, act="nn.ReLU")
+        work = {"blk." + k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.clone()) for k, v in b["sd"].items()}
+        x = b["x"].clone().requires_grad_(True)
+        stats = {}
+        out = orc.block_forward(x, work, blk, True, spec, stats)
+        assert_close(name + " out", out, b["out"], rtol=1e-9, atol=1e-10)
+        out.backward(b["gout"])
+        assert_close(name + " dx", x.grad, b["dx"], rtol=1e-8, atol=1e-10)
+        for k, gref in b["grads"].items():
+            assert_close(name + " grad " + k, work["blk." + k].grad, gref, rtol=1e-8, atol=1e-10)
+        for prefix, (rm, rv) in stats.items():
+            key = prefix[len("blk."):]
+            assert_close(name + " rm " + key, rm, b["sd_after"][key + ".running_mean"], rtol=1e-9, atol=1e-12)
+            assert_close(name + " rv " + key, rv, b["sd_after"][key + ".running_var"], rtol=1e-9, atol=1e-12)
+        # eval mode uses the statistics as updated by the training forward
+        sd_eval = {"blk." + k: v for k, v in b["sd_after"].items()}
+        out_e = orc.block_forward(b["x"], sd_eval, blk, False, spec)
+        assert_close(name + " eval", out_e, b["out_eval"], rtol=1e-9, atol=1e-10)
+
+
+def _tiny_state(kw, seed):
+    """state_dict of the tiny supernet with the generator's counter-based initialisation (structure from atomnas_amd's
+    builder, which test_host_logic pins key-by-key against the reference)."""
+    from atomnas_amd.models import mobilenet_supernet as ms
+    model = ms.Model(**kw)
+    randomize_counter(model, seed)
+    return collections.OrderedDict((k, v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items())
+
+
+def test_two_training_iterations():
+    """oracle.train_step == the reference's loop body (model, CE-smooth, cal_l2_loss, cal_bn_l1_loss, RMSprop, EMA), 2 iterations."""
+    g = load("train_steps.pt")
+    kw = g["kw"]
+    sd = _tiny_state(kw, 5)
+    spec = _spec_of(kw)
+    names, pen, pcf = orc.prune_penalties(spec, kw["input_size"])
+    assert names == g["prune_names"]
+    assert_close("penalties", torch.tensor(pen), torch.tensor(g["penalties"]), rtol=1e-12, atol=0)
+    assert_close("pcf", torch.tensor(pcf), torch.tensor(g["pcf"]), rtol=1e-12, atol=0)
+    opt_state, ema = {}, collections.OrderedDict((k, v.clone()) for k, v in sd.items() if v.is_floating_point())
+    for i, st in enumerate(g["steps"]):
+        x = counter_fill(torch.empty(6, 3, 64, 64), st["x_seed"]) * 4
+        d = orc.ema_decay(0.99, i + 1)
+        r = orc.train_step(sd, spec, opt_state, ema, x, st["y"], dict(lr=st["lr"], rho=st["rho"], weight_decay=1e-3, wd_method="mnas",
+                           label_smoothing=0.1, alpha=0.9, eps=1e-3, momentum=0.9, ema_decay=d), names, pen)
+        assert abs(r["loss"] - st["loss"]) < 1e-9 and abs(r["loss_l2"] - st["l2"]) < 1e-10 and abs(r["loss_l1"] - st["l1"]) < 1e-9, (i, r["loss"], st["loss"])
+        assert_close("logits", r["logits"], st["logits"], rtol=1e-8, atol=1e-9)
+        for k, dg in st["grads"].items():
+            check_digest("grad " + k, r["grads"][k], dg, rtol=1e-7)
+    for k, dg in g["sd_final"].items():
+        check_digest("final " + k, sd[k], dg, rtol=1e-7)
+    for k, dg in g["ema_final"].items():
+        check_digest("ema " + k, ema[k], dg, rtol=1e-7)
+    for k, dg in g["opt_sq"].items():
+        check_digest("sq " + k, opt_state[k]["square_avg"], dg, rtol=1e-7)
+        check_digest("buf " + k, opt_state[k]["momentum_buffer"], g["opt_buf"][k], rtol=1e-7)
+    total, _ = orc.model_macs(spec, 64, kw["input_channel"], 40, kw["last_channel"])
+    assert total == g["n_macs"]
+
+
+def test_shrink_state_dict():
+    """oracle.shrink_state_dict == shrink_model + copmress_inverted_residual_channels of the reference: names, shapes, values
+    (incl. a dropped middle branch, a fully pruned block and a single surviving atom) and the network after the shrink."""
+    g = load("shrink.pt")
+    spec = _spec_of(g["kw"])
+    sd_pre = collections.OrderedDict((k, v.clone()) for k, v in g["sd_pre"].items())
+    new_sd, new_spec = orc.shrink_state_dict(sd_pre, spec, g["masks"])
+    assert set(new_sd.keys()) == set(g["sd_post"].keys())
+    for k, dg in g["sd_post"].items():
+        check_digest("post " + k, new_sd[k], dg, rtol=1e-6)
+    rows = [[b["oup"], 1, b["stride"], b["ks"], b["channels"], b["expand"]] for b in new_spec["blocks"]]
+    assert rows == g["output_network"]["inverted_residual_setting"]
+    total, _ = orc.model_macs(new_spec, 64, g["kw"]["input_channel"], 40, g["kw"]["last_channel"])
+    assert total == g["n_macs_post"]
+    x = (counter_fill(torch.empty(4, 3, 64, 64), 400) * 4).float()
+    logits = orc.model_forward(x, new_sd, new_spec, False)
+    assert_close("logits after shrink", logits, g["logits_post"], rtol=1e-4, atol=1e-5)
+    # the same gather applied to optimizer state and EMA shadows
+    for src, post in ((g["ema_pre"], g["ema_post"]), (g["sq_pre"], g["sq_post"]), (g["buf_pre"], g["buf_post"])):
+        full = collections.OrderedDict(sd_pre)
+        full.update({k: v for k, v in src.items()})
+        moved, _ = orc.shrink_state_dict(full, spec, g["masks"])
+        for k, dg in post.items():
+            check_digest("moved " + k, moved[k], dg, rtol=1e-6)
+
+
+def test_tables_macs_penalties_schedules():
+    g = load("tables.pt")
+    from atomnas_amd import configs
+    for name, key in (("atomnas_c", "atomnas_c_supernet"), ("atomnas_a", "atomnas_a_supernet")):
+        kw = dict(configs.model_kwparams(key), input_size=224)
+        spec = _spec_of(kw)
+        names, pen, pcf = orc.prune_penalties(spec, 224)
+        t = g[name]
+        assert names == t["names"]
+        assert_close("pen", torch.tensor(pen), torch.tensor(t["penalties"]), rtol=1e-12, atol=0)
+        assert_close("pcf", torch.tensor(pcf), torch.tensor(t["pcf"]), rtol=1e-12, atol=0)
+        total, per_block = orc.model_macs(spec, 224, kw["input_channel"], 320, 1280)
+        assert total == t["n_macs"]
+        assert [sum(b) for b in per_block] == t["block_macs"]
+    spe = 626
+    for i, v in zip(g["rho"]["idx"], g["rho"]["val"]):
+        assert orc.rho_schedule(i, 1e-4, 0, 25, spe, True) == v
+    assert [orc.rho_schedule(i, 1.0, 1, 3, 2, False) for i in range(10)] == g["rho_epochwise"]
+    for i, v in zip(g["lr"]["idx"], g["lr"]["val"]):
+        assert abs(0.128 * orc.lr_lambda(i, 0.128, 0.016, spe) - v) < 1e-15
+    assert orc.ema_adjust_momentum(0.9999, 4096 / 2048) == g["ema_decay"]["adjusted"]
+    assert [orc.ema_decay(0.99994999875, n) for n in (1, 10, 100, 100000, 1000000)] == g["ema_decay"]["sched"]
+
+
+def test_full_supernet_eval_logits():
+    """Full-size AtomNAS-C supernet, batch 2, eval mode: catches any wiring error in the oracle's model walk."""
+    g = load("full_supernet_eval.pt")
+    from atomnas_amd import configs
+    from atomnas_amd.models import mobilenet_supernet as ms
+    kw = dict(configs.model_kwparams("atomnas_c_supernet"), input_size=224)
+    model = ms.Model(**kw)
+    randomize_counter(model, 1)
+    sd = collections.OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    spec = orc.spec_from_model(model)
+    x = (counter_fill(torch.empty(2, 3, 224, 224), 1234) * 4).float()
+    with torch.no_grad():
+        logits, feats = orc.model_forward(x, sd, spec, False, return_features=True)
+    assert_close("logits", logits, g["logits"], rtol=1e-3, atol=1e-4)
+    for (m, a), f in zip(g["feats"][:len(feats)], feats):
+        assert abs(float(f.mean()) - m) < 1e-4 * max(1, abs(m)) and abs(float(f.abs().max()) - a) < 1e-3 * max(1, a)

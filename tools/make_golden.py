@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.pt by importing and running the REFERENCE (/root/reference) in this container (CPU, fp32/fp64).
+
+Run once here; the reference never travels (not even as bytecode) -- only the small input/output tensors below do.
+The fixtures pin oracle/atomnas_oracle.py (tests/test_oracle_golden.py) and, through it, the HIP path.
+
+    python tools/make_golden.py
+"""
+import collections
+import copy
+import os
+import sys
+import types
+
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+sys.path.insert(0, REF)
+import models.mobilenet_base as mb            # noqa: E402  (reference)
+import models.mobilenet_supernet as ms        # noqa: E402
+import models.compress_utils as cu            # noqa: E402,F401
+import utils.prune as rprune                  # noqa: E402
+import utils.optim as roptim                  # noqa: E402
+import utils.rmsprop as rrms                  # noqa: E402
+import utils.model_profiling as rprof         # noqa: E402
+
+
+def counter_fill(t, seed):
+    """Deterministic, RNG-free fill in [-0.5, 0.5): value depends only on (flat index, seed)."""
+    n = t.numel()
+    idx = torch.arange(n, dtype=torch.float64)
+    v = torch.sin(idx * 12.9898 + seed * 78.233) * 43758.5453
+    v = v - torch.floor(v)   # [0, 1)
+    return (v - 0.5).reshape(t.shape)
+
+
+def randomize(module, seed):
+    with torch.no_grad():
+        for i, (n, p) in enumerate(module.named_parameters()):
+            f = counter_fill(p, seed + i)
+            if p.dim() == 1 and "bias" not in n:
+                p.copy_(f + 1.0)                      # BN gamma in [0.5, 1.5)
+            elif p.dim() == 1:
+                p.copy_(f * 0.4)
+            else:
+                p.copy_(f * 2.0 / p[0].numel() ** 0.5)
+        for i, (n, b) in enumerate(module.named_buffers()):
+            if "running_mean" in n:
+                b.copy_(counter_fill(b, seed + 1000 + i) * 0.2)
+            elif "running_var" in n:
+                b.copy_(counter_fill(b, seed + 2000 + i) + 1.0)
+
+
+def digest(t):
+    """Compact fingerprint of a tensor: shape, sum, sum of squares, first and last four elements (float64)."""
+    f = t.detach().double().flatten()
+    return dict(shape=tuple(t.shape), sum=float(f.sum()), sumsq=float((f * f).sum()), head=f[:4].clone(), tail=f[-4:].clone())
+
+
+def digests(d):
+    return collections.OrderedDict((k, digest(v)) for k, v in d.items())
+
+
+def sd_of(m):
+    return collections.OrderedDict((k, v.detach().clone()) for k, v in m.state_dict().items())
+
+
+TINY = dict(num_classes=10, input_size=64, input_channel=16, last_channel=64, width_mult=1.0, dropout_ratio=0.0,
+            batch_norm_momentum=0.01, batch_norm_epsilon=1e-3, active_fn="nn.ReLU",
+            inverted_residual_setting=[[1, 8, 1, 1, [3]], [6, 16, 2, 2, [3, 5, 7]], [6, 24, 2, 2, [3, 5, 7]], [6, 32, 1, 2, [3, 5, 7]],
+                                       [6, 40, 1, 2, [3, 5, 7]]])
+SUPERNET_ROWS = [[1, 16, 1, 1, [3]], [6, 24, 4, 2, [3, 5, 7]], [6, 40, 4, 2, [3, 5, 7]], [6, 80, 4, 2, [3, 5, 7]], [6, 96, 4, 1, [3, 5, 7]],
+                 [6, 192, 4, 2, [3, 5, 7]], [6, 320, 1, 1, [3, 5, 7]]]
+
+
+def g_blocks():
+    out = {}
+    cfgs = [dict(inp=8, oup=8, stride=1, channels=[16, 16, 16], ks=[3, 5, 7], expand=True),
+            dict(inp=8, oup=12, stride=2, channels=[12, 20, 7], ks=[3, 5, 7], expand=True),
+            dict(inp=16, oup=8, stride=1, channels=[16], ks=[3], expand=False)]
+    for ci, cfg in enumerate(cfgs):
+        blk = mb.InvertedResidualChannels(cfg["inp"], cfg["oup"], cfg["stride"], cfg["channels"], cfg["ks"], cfg["expand"],
+                                          active_fn=mb.get_active_fn("nn.ReLU"), batch_norm_kwargs={"momentum": 0.01, "eps": 1e-3})
+        randomize(blk, 10 * ci)
+        blk = blk.double().train()
+        sd0 = sd_of(blk)
+        x = (counter_fill(torch.empty(3, cfg["inp"], 14, 14), 77 + ci) * 4).requires_grad_(True)
+        y = blk(x)
+        gout = counter_fill(y.detach(), 99 + ci) * 2
+        y.backward(gout)
+        out["block%d" % ci] = dict(cfg=cfg, sd=sd0, x=x.detach(), out=y.detach(), gout=gout, dx=x.grad.clone(),
+                                   grads={n: p.grad.clone() for n, p in blk.named_parameters()}, sd_after=sd_of(blk))
+        blk.eval()
+        out["block%d" % ci]["out_eval"] = blk(x.detach()).detach()
+    torch.save(out, os.path.join(OUT, "blocks.pt"))
+
+
+def g_train_steps():
+    """Two iterations of the reference's loop body (train.py:165-236) on the tiny supernet, single process."""
+    model = ms.Model(**TINY)
+    randomize(model, 5)
+    rprof.model_profiling(model, 64, 64, use_cuda=False, num_forwards=0, verbose=False)
+    model = model.double().train()
+    flags = {'bn_prune_filter': 'expansion_only_skip_expand1'}
+    pinfo = rprune.get_bn_to_prune(model, flags, verbose=False)
+    sd0 = sd_of(model)
+    crit = roptim.CrossEntropyLabelSmooth(10, 0.1, reduction='none')
+    opt = rrms.RMSprop(model.parameters(), lr=0.002, alpha=0.9, momentum=0.9, eps=1e-3, eps_inside_sqrt=True, weight_decay=0)
+    ema = roptim.ExponentialMovingAverage(0.99)
+    for n, p in model.named_parameters():
+        ema.register(n, p)
+    for n, b in model.named_buffers():
+        if 'running_var' in n or 'running_mean' in n:
+            ema.register(n, b)
+    named = dict(model.named_parameters())
+    steps = []
+    gstep = 0
+    for step in range(2):
+        x = counter_fill(torch.empty(6, 3, 64, 64), 300 + step) * 4
+        y = (torch.arange(6) * 7 + step * 3) % 10
+        lr, rho = 0.002 * (1 + step), 1e-3 * (1 + step)
+        for g in opt.param_groups:
+            g['lr'] = lr
+        opt.zero_grad()
+        logits = model(x)
+        loss = torch.mean(crit(logits, y))
+        l2 = roptim.cal_l2_loss(model, 1e-3, 'mnas')
+        l1 = rprune.cal_bn_l1_loss([named[n] for n in pinfo.weight], pinfo.penalty, rho)
+        (loss + l2 + l1).backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        opt.step()
+        gstep += 1
+        for n in ema.average_names():
+            src = named[n] if n in named else dict(model.named_buffers())[n]
+            ema(n, src, gstep)
+        steps.append(dict(x_seed=300 + step, y=y, lr=lr, rho=rho, logits=logits.detach().clone(), loss=float(loss), l2=float(l2),
+                          l1=float(l1), grads=digests(grads), grads_sample={k: grads[k].float() for k in list(grads)[:3] + list(grads)[-2:]}))
+    keep = [n for n in dict(model.named_parameters()) if n.endswith('1.1.weight') or n.startswith('features.0.') or n.startswith('classifier')]
+    out = dict(kw=TINY, init="randomize(model, 5)", x_fill="counter_fill(empty(6,3,64,64), x_seed) * 4", steps=steps,
+               sd_final=digests(sd_of(model)), sd_final_sample={k: v.float() for k, v in sd_of(model).items() if k in keep},
+               prune_names=pinfo.weight, penalties=pinfo.penalty, pcf=pinfo.get_info_list('per_channel_flops'),
+               ema_final=digests({k: ema.average(k) for k in ema.average_names()}),
+               opt_sq=digests({n: opt.state[p]['square_avg'] for n, p in model.named_parameters()}),
+               opt_buf=digests({n: opt.state[p]['momentum_buffer'] for n, p in model.named_parameters()}), n_macs=model.n_macs)
+    torch.save(out, os.path.join(OUT, "train_steps.pt"))
+
+
+def g_shrink():
+    """shrink_model (train.py:27-81) on the tiny supernet with chosen dead atoms: one ordinary block, one block that loses
+    its middle branch, one block that loses every branch."""
+    model = ms.Model(**TINY)
+    randomize(model, 9)
+    rprof.model_profiling(model, 64, 64, use_cuda=False, num_forwards=0, verbose=False)
+    model.train()   # the profiler leaves the model in eval mode; run_one_epoch switches back (train.py:146-147)
+    pinfo = rprune.get_bn_to_prune(model, {'bn_prune_filter': 'expansion_only_skip_expand1'}, verbose=False)
+    opt = rrms.RMSprop(model.parameters(), lr=0.002, alpha=0.9, momentum=0.9, eps=1e-3, eps_inside_sqrt=True, weight_decay=0)
+    ema = roptim.ExponentialMovingAverage(0.99)
+    for n, p in model.named_parameters():
+        ema.register(n, p)
+    for n, b in model.named_buffers():
+        if 'running_var' in n or 'running_mean' in n:
+            ema.register(n, b)
+    # one optimizer step so that state exists
+    x = (counter_fill(torch.empty(4, 3, 64, 64), 400) * 4).float()
+    y = torch.arange(4) % 10
+    torch.mean(roptim.CrossEntropyLabelSmooth(10, 0.1)(model(x), y)).backward()
+    opt.step()
+    named = dict(model.named_parameters())
+    with torch.no_grad():
+        # dead atoms: gamma (and EMA gamma) set to exactly 0
+        def kill(name, idx):
+            named[name][idx] = 0.0
+            ema.average(name)[idx] = 0.0
+        n_of = lambda name: named[name].numel()
+        kill('features.2.ops.0.1.1.weight', torch.arange(0, n_of('features.2.ops.0.1.1.weight'), 3))   # every third atom
+        kill('features.3.ops.1.1.1.weight', torch.arange(n_of('features.3.ops.1.1.1.weight')))         # whole middle (k=5) branch
+        for i in range(3):   # a whole block (features.5 is 24->24 stride 1: the identity that remains is valid)
+            kill('features.5.ops.%d.1.1.weight' % i, torch.arange(n_of('features.5.ops.%d.1.1.weight' % i)))
+        kill('features.6.ops.2.1.1.weight', torch.arange(1, n_of('features.6.ops.2.1.1.weight')))      # a single survivor
+        named['features.6.ops.0.1.1.weight'][7] = 5e-4                       # below threshold but EMA alive -> kept (OR)
+    sd_pre = sd_of(model)
+    ema_pre = {k: ema.average(k).clone() for k in ema.average_names()}
+    sq_pre = {n: opt.state[p]['square_avg'].clone() for n, p in model.named_parameters()}
+    buf_pre = {n: opt.state[p]['momentum_buffer'].clone() for n, p in model.named_parameters()}
+    thr = 1e-3
+    masks = {}
+    for block_name, block in model.get_named_block_list().items():
+        m = [bn.weight.detach().abs() > thr for bn in block.get_depthwise_bn()]
+        me = [ema.average('{}.{}.weight'.format(block_name, name)).detach().abs() > thr for name in block.get_named_depthwise_bn().keys()]
+        m = [a | b for a, b in zip(m, me)]
+        masks[block_name] = [t.clone() for t in m]
+        block.compress_by_mask(m, ema=ema, optimizer=opt, prune_info=pinfo, prefix=block_name, verbose=False)
+    assert set(id(p) for p in opt.param_groups[0]['params']) == set(id(p) for p in model.parameters())
+    rprof.model_profiling(model, 64, 64, use_cuda=False, num_forwards=0, verbose=False)
+    post_names = [n for n, _ in model.named_parameters()]
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    out = dict(kw=TINY, sd_pre=sd_pre, ema_pre=ema_pre, sq_pre=sq_pre, buf_pre=buf_pre, masks=masks, sd_post=digests(sd_of(model)),
+               ema_post=digests({k: ema.average(k) for k in ema.average_names()}), ema_names_post=ema.average_names(),
+               opt_order_post=[id2name[id(p)] for p in opt.param_groups[0]['params']],
+               sq_post=digests({n: opt.state[p]['square_avg'] for n, p in model.named_parameters()}),
+               buf_post=digests({n: opt.state[p]['momentum_buffer'] for n, p in model.named_parameters()}),
+               prune_weight_post=pinfo.weight, prune_penalty_post=pinfo.penalty, output_network=mb.output_network(model),
+               n_macs_post=model.n_macs, param_names_post=post_names,
+               logits_post=model.eval()(x).detach().clone(), x_fill='counter_fill(empty(4,3,64,64), 400) * 4')
+    torch.save(out, os.path.join(OUT, "shrink.pt"))
+
+
+def g_tables():
+    out = {}
+    for name, inch in (("atomnas_c", 32), ("atomnas_a", 16)):
+        model = ms.Model(num_classes=1000, input_size=224, input_channel=inch, last_channel=1280, active_fn='nn.ReLU',
+                         inverted_residual_setting=SUPERNET_ROWS, batch_norm_momentum=0.01, batch_norm_epsilon=1e-3)
+        rprof.model_profiling(model, 224, 224, use_cuda=False, num_forwards=0, verbose=False)
+        pinfo = rprune.get_bn_to_prune(model, {'bn_prune_filter': 'expansion_only_skip_expand1'}, verbose=False)
+        out[name] = dict(n_macs=model.n_macs, n_params=int(model.n_params), names=pinfo.weight, penalties=pinfo.penalty,
+                         pcf=pinfo.get_info_list('per_channel_flops'),
+                         block_macs=[b.n_macs for b in model.get_named_block_list().values()],
+                         n_tensors=len(list(model.parameters())), keys=list(model.state_dict().keys()),
+                         shapes=[tuple(v.shape) for v in model.state_dict().values()])
+    # schedules at the cfg-4 hyper-parameters (global batch 2048): steps/epoch 626
+    spe = 626
+    rs = rprune.get_rho_scheduler(dict(rho=1e-4, epoch_free=0, epoch_warmup=25, scheduler='linear', stepwise=True), spe)
+    idx = [0, 1, 2, 625, 626, 627, 3129, 3130, 3131, 4507, 4508, 5008, 15649, 15650, 20000]
+    out['rho'] = dict(idx=idx, val=[rs(i) for i in idx])
+    rs2 = rprune.get_rho_scheduler(dict(rho=1.0, epoch_free=1, epoch_warmup=3, scheduler='linear', stepwise=False), 2)
+    out['rho_epochwise'] = [rs2(i) for i in range(10)]
+    flags = types.SimpleNamespace(lr=0.128, base_lr=0.016, _steps_per_epoch=spe, lr_scheduler='exp_decaying', exp_decay_epoch_interval=2.4,
+                                  exp_decaying_lr_gamma=0.97, num_epochs=350)
+    flags.get = lambda k, d=None: {'lr_stepwise': False, 'epoch_warmup': 5}.get(k, d)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.128)
+    sched = roptim.get_lr_scheduler(opt, flags)
+    lam = sched.lr_lambdas[0]
+    out['lr'] = dict(idx=idx, val=[0.128 * lam(i) for i in idx])
+    out['ema_decay'] = dict(adjusted=roptim.ExponentialMovingAverage.adjust_momentum(0.9999, 4096 / 2048),
+                            sched=[min(0.99994999875, (1.0 + n) / (10.0 + n)) for n in (1, 10, 100, 100000, 1000000)])
+    torch.save(out, os.path.join(OUT, "tables.pt"))
+
+
+def g_full_supernet():
+    """Full-size AtomNAS-C supernet, batch 2, counter-filled weights: logits and per-block output statistics."""
+    model = ms.Model(num_classes=1000, input_size=224, input_channel=32, last_channel=1280, active_fn='nn.ReLU', dropout_ratio=0.2,
+                     inverted_residual_setting=SUPERNET_ROWS, batch_norm_momentum=0.01, batch_norm_epsilon=1e-3)
+    randomize(model, 1)
+    model.eval()   # eval mode: deterministic (no dropout), exercises running statistics
+    x = (counter_fill(torch.empty(2, 3, 224, 224), 1234) * 4).float()
+    feats = []
+    y = x
+    with torch.no_grad():
+        for m in model.features:
+            y = m(y)
+            feats.append((float(y.mean()), float(y.abs().max())))
+        logits = model.classifier(y.squeeze(3).squeeze(2))
+    torch.save(dict(logits=logits, feats=feats, fill="tools/make_golden.py:counter_fill/randomize(model, 1); x = counter_fill(.,1234)*4"),
+               os.path.join(OUT, "full_supernet_eval.pt"))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    g_blocks()
+    g_train_steps()
+    g_shrink()
+    g_tables()
+    g_full_supernet()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""AtomNAS supernet training on MI355X:  python train.py app:apps/slimming/shrink/atomnas_c.yml [--dotted.key value ...]
+
+Same entry, yaml semantics and loop order as the reference's train.py (run_one_epoch :130-250, per-epoch validate / mask /
+shrink :364-411, checkpoint :395-411), with the iteration executed by atomnas_amd.engine.TrainStep (one replayed hipGraph
+per iteration, RCCL all-reduce of the gradient arena).  Under a launcher (torch.distributed.run) one process drives one GPU.
+Input pipeline: `dataset: imagenet1k_fake` (synthetic, device resident) -- the JPEG/LMDB pipeline is outside this path.
+"""
+import logging
+import os
+import sys
+import time
+
+import torch
+
+from atomnas_amd import engine
+from atomnas_amd.models import mobilenet_base as mb
+from atomnas_amd.utils import config as cfg
+from atomnas_amd.utils import distributed as udist
+from atomnas_amd.utils import optim, prune
+from atomnas_amd.utils.common import bn_calibration, get_params_by_name, set_random_seed
+
+NUM_IMAGENET_TRAIN = 1281167
+
+
+def fake_batches(batch, image_size, num_classes, steps, seed):
+    """Device-resident synthetic batches (normal images, uniform labels); the reference's FakeData is all zeros."""
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.randn(batch, 3, image_size, image_size, device='cuda', generator=g)
+    y = torch.randint(0, num_classes, (batch,), device='cuda', generator=g)
+    for _ in range(steps):
+        yield x, y
+
+
+def shrink_model(model_wrapper, ema, optimizer, prune_info, threshold=1e-3, ema_only=False):
+    """Discard dead atomic blocks (train.py:27-81): mask = |gamma| > thr OR |gamma_ema| > thr (EMA only at the last epoch)."""
+    import common as mc
+    FLAGS = cfg.FLAGS
+    model = mc.unwrap_model(model_wrapper)
+    for block_name, block in model.get_named_block_list().items():
+        assert isinstance(block, mb.InvertedResidualChannels)
+        masks = [bn.weight.detach().abs() > threshold for bn in block.get_depthwise_bn()]
+        if ema is not None:
+            masks_ema = [ema.average('{}.{}.weight'.format(block_name, name)).detach().abs() > threshold
+                         for name in block.get_named_depthwise_bn().keys()]
+            masks = masks_ema if ema_only else [a | b for a, b in zip(masks, masks_ema)]
+        block.compress_by_mask(masks, ema=ema, optimizer=optimizer, prune_info=prune_info, prefix=block_name, verbose=False)
+    if optimizer is not None:
+        assert set(id(p) for p in optimizer.param_groups[0]['params']) == set(id(p) for p in model.parameters())
+    mc.profiling(model)
+    logging.info('Model Shrink to FLOPS: {}'.format(model.n_macs))
+    logging.info('Current model: {}'.format(mb.output_network(model)))
+
+
+def validate(epoch, model_wrapper, ema, criterion, meters, steps):
+    """EMA model -> BN calibration (cumulative statistics) -> evaluation (train.py:419-458), on synthetic batches."""
+    import common as mc
+    FLAGS = cfg.FLAGS
+    eval_wrapper = mc.get_ema_model(ema, model_wrapper)
+    model = mc.unwrap_model(eval_wrapper)
+    if FLAGS.get('bn_calibration', False):
+        model.eval()
+        model.apply(bn_calibration)
+        with torch.no_grad():
+            for x, y in fake_batches(FLAGS.bn_calibration_per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'],
+                                     FLAGS.bn_calibration_steps, 7 + epoch):
+                model(x)
+        if FLAGS.use_distributed:
+            udist.allreduce_bn(model)
+    model.eval()
+    with torch.no_grad():
+        for x, y in fake_batches(FLAGS.per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'], steps, 11):
+            mc.forward_loss(model, criterion, x, y, meters)
+    return meters.flush(), eval_wrapper
+
+
+def train_val_test():
+    import common as mc
+    FLAGS = cfg.FLAGS
+    model, model_wrapper = mc.get_model()
+    ema = mc.setup_ema(model)
+    optimizer = optim.get_optimizer(model_wrapper, FLAGS)
+    lr_scheduler = optim.get_lr_scheduler(optimizer, FLAGS)
+    last_epoch, best_val = -1, 1.0
+    FLAGS._global_step = 0
+    if FLAGS.resume:
+        ckpt = torch.load(os.path.join(FLAGS.resume, 'latest_checkpoint.pt'), map_location='cpu')
+        model_wrapper.load_state_dict(ckpt['model'])
+        optimizer.load_state_dict(ckpt['optimizer'])
+        if ema:
+            ema.load_state_dict(ckpt['ema'])
+        last_epoch = ckpt['last_epoch']
+        best_val = ckpt['best_val']
+        lr_scheduler.last_epoch = (last_epoch + 1) * FLAGS._steps_per_epoch
+        FLAGS._global_step = (last_epoch + 1) * FLAGS._steps_per_epoch
+    assert FLAGS.profiling, '`m.macs` is used for calculating penalty'
+    mc.profiling(model)
+    FLAGS._bn_to_prune = prune.get_bn_to_prune(model, FLAGS.prune_params, verbose=udist.is_master())
+    rho_scheduler = prune.get_rho_scheduler(FLAGS.prune_params, FLAGS._steps_per_epoch)
+    step = engine.TrainStep(model, optimizer, ema, FLAGS._bn_to_prune, weight_decay=FLAGS.weight_decay,
+                            wd_method=FLAGS.weight_decay_method, label_smoothing=FLAGS.label_smoothing,
+                            batch_size=FLAGS.per_gpu_batch_size, image_size=FLAGS.image_size,
+                            world_size=udist.get_world_size_fallback())
+    val_criterion = optim.CrossEntropyLabelSmooth(FLAGS.model_kwparams['num_classes'], 0.0, reduction='none')
+    val_meters = mc.get_meters('val')
+    steps_per_epoch = FLAGS.get('max_steps_per_epoch', None) or FLAGS._steps_per_epoch
+    rank = udist.get_rank_fallback()
+    for epoch in range(last_epoch + 1, FLAGS.num_epochs):
+        model.train()
+        t0, seen = time.time(), 0
+        for x, y in fake_batches(FLAGS.per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'], steps_per_epoch,
+                                 FLAGS.get('random_seed', 0) + rank + 1000 * epoch):
+            step.set_batch(x, y)
+            step.global_step = FLAGS._global_step
+            step.step(lr=optimizer.param_groups[0]['lr'], rho=rho_scheduler(FLAGS._global_step))
+            lr_scheduler.step()
+            if FLAGS.use_distributed and FLAGS.allreduce_bn:
+                udist.allreduce_bn(model)
+            FLAGS._global_step += 1
+            seen += x.shape[0]
+            if FLAGS._global_step % FLAGS.log_interval == 0 and udist.is_master():
+                ce, l2, l1 = step.loss.tolist()   # the only host synchronisation of the interval
+                dt = time.time() - t0
+                logging.info('Epoch {}/{} step {} loss {:.4f} l2 {:.4f} l1 {:.4f} lr {:.5f} {:.0f} img/s/GPU'.format(
+                    epoch, FLAGS.num_epochs, FLAGS._global_step, ce, l2, l1, optimizer.param_groups[0]['lr'], seen / dt))
+        results, eval_wrapper = validate(epoch, model_wrapper, ema, val_criterion, val_meters, FLAGS.get('val_steps', 4))
+        if udist.is_master():
+            logging.info('Epoch {} val: {}'.format(epoch, results))
+        if FLAGS.prune_params['method'] is not None:
+            thr = FLAGS.model_shrink_threshold
+            eval_model = mc.unwrap_model(eval_wrapper)
+            masks = prune.cal_mask_network_slimming_by_threshold(get_params_by_name(eval_model, FLAGS._bn_to_prune.weight), thr)
+            FLAGS._bn_to_prune.add_info_list('mask', masks)
+            flops_pruned, infos = prune.cal_pruned_flops(FLAGS._bn_to_prune)
+            if udist.is_master():
+                logging.info('Prune threshold: {}, flops pruned: {}, flops remain: {}'.format(thr, flops_pruned, model.n_macs - flops_pruned))
+            if flops_pruned >= FLAGS.model_shrink_delta_flops or epoch == FLAGS.num_epochs - 1:
+                shrink_model(model_wrapper, ema, optimizer, FLAGS._bn_to_prune, thr, ema_only=(epoch == FLAGS.num_epochs - 1))
+        if udist.is_master() and FLAGS.get('log_dir', None):
+            os.makedirs(FLAGS.log_dir, exist_ok=True)
+            kw = mb.output_network(model)
+            state = {'model': {k: v.detach().clone() for k, v in model_wrapper.state_dict().items()}, 'optimizer': optimizer.state_dict(),
+                     'ema': ema.state_dict() if ema else None, 'last_epoch': epoch, 'best_val': min(best_val, results['top1_error']),
+                     'meters': None}
+            torch.save(state, os.path.join(FLAGS.log_dir, 'latest_checkpoint.pt'))
+            with open(os.path.join(FLAGS.log_dir, 'latest_checkpoint.yml'), 'w') as f:
+                f.write(str(kw))
+            if results['top1_error'] < best_val:
+                best_val = results['top1_error']
+                torch.save(state, os.path.join(FLAGS.log_dir, 'best_model.pt'))
+                with open(os.path.join(FLAGS.log_dir, 'best_model.yml'), 'w') as f:
+                    f.write(str(kw))
+
+
+def main():
+    import common as mc
+    FLAGS = cfg.load_app(sys.argv[1:])
+    logging.basicConfig(stream=sys.stdout, level=logging.INFO, format='%(asctime)s %(message)s')
+    if FLAGS.get('dataset', 'imagenet1k_fake') != 'imagenet1k_fake':
+        raise NotImplementedError('only the synthetic `imagenet1k_fake` source is implemented (input pipeline is out of scope)')
+    mc.setup_distributed(NUM_IMAGENET_TRAIN)
+    if udist.is_master():
+        logging.info(FLAGS)
+    set_random_seed(FLAGS.get('random_seed', 0))
+    train_val_test()
+
+
+if __name__ == '__main__':
+    main()
