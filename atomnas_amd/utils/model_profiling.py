@@ -81,7 +81,7 @@ def model_profiling(model, height, width, batch=1, channel=3, use_cuda=True, num
     h, w = _stamp_seq(model.features, height, width, batch)
     _stamp_seq(model.classifier, 1, 1, batch)
     model.n_macs = model.features.n_macs + model.classifier.n_macs
-    model.n_params = sum(p.numel() for p in model.parameters())
+    model.n_params = model.features.n_params + model.classifier.n_params   # conv / linear parameters, as the reference's table
     model.n_seconds = 0
     if verbose:
         logging.info('Total params {:,} macs {:,}'.format(model.n_params, model.n_macs))
