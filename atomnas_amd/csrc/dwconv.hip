@@ -18,6 +18,7 @@
 // LDS rows are padded so that the two tile rows a 32-lane LDS group touches fall into different bank halves.
 #include "common.h"
 #include <unordered_map>
+#include <cstdlib>
 #ifndef DW_EXP
 #define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute
 #endif
@@ -160,27 +161,24 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
     it_j[q] = rs % nstrips;
   }
 
-  // tile walk with carried (n, ty, tx) for the current and the prefetched tile
-  int tile = worker;
+  // tile walk: every worker owns a CONTIGUOUS range of tiles (raster order inside an image), so the halo rows / columns it
+  // shares with its previous tiles are still in its XCD's L2; (n, ty, tx) are carried, not re-derived
+  const int t_beg = (int)((long)worker * ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * ntiles / g.nworkers);
+  int tile = t_beg;
   int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
-  const int dtx = g.nworkers % g.tiles_x, dty = (g.nworkers / g.tiles_x) % g.tiles_y, dn = g.nworkers / (g.tiles_x * g.tiles_y);
   auto advance = [&](int& an, int& aty, int& atx) {
-    atx += dtx;
-    if (atx >= g.tiles_x) { atx -= g.tiles_x; aty += 1; }
-    aty += dty;
-    if (aty >= g.tiles_y) { aty -= g.tiles_y; an += 1; }
-    an += dn;
+    if (++atx == g.tiles_x) { atx = 0; if (++aty == g.tiles_y) { aty = 0; ++an; } }
   };
   int ntx = tx, nty = ty, nn = n;
-  if (tile < ntiles) issue(n, ty, tx);
-  for (; tile < ntiles; tile += g.nworkers) {
+  if (tile < t_end) issue(n, ty, tx);
+  for (; tile < t_end; ++tile) {
     const int ho0 = ty * g.TH, wo0 = tx * g.TW;
     __syncthreads();  // previous tile fully consumed (also orders the s_w / s_st initialisation)
     if (DW_EXP != 3) commit();
     __syncthreads();
     ntx = tx; nty = ty; nn = n;
     advance(nn, nty, ntx);
-    if (tile + g.nworkers < ntiles) issue(nn, nty, ntx);
+    if (tile + 1 < t_end) issue(nn, nty, ntx);
 
 #pragma unroll
     for (int q = 0; q < (DW_EXP == 2 ? 0 : NIT); ++q) {
@@ -364,19 +362,15 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     it_j[q] = rs % nstrips;
   }
 
-  int tile = worker;
+  const int t_beg = (int)((long)worker * ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * ntiles / g.nworkers);
+  int tile = t_beg;   // contiguous tile range per worker (halo reuse in the XCD's L2), see k_dwconv_fwd
   int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
-  const int dtx = g.nworkers % g.tiles_x, dty = (g.nworkers / g.tiles_x) % g.tiles_y, dn = g.nworkers / (g.tiles_x * g.tiles_y);
   auto advance = [&](int& an, int& aty, int& atx) {
-    atx += dtx;
-    if (atx >= g.tiles_x) { atx -= g.tiles_x; aty += 1; }
-    aty += dty;
-    if (aty >= g.tiles_y) { aty -= g.tiles_y; an += 1; }
-    an += dn;
+    if (++atx == g.tiles_x) { atx = 0; if (++aty == g.tiles_y) { aty = 0; ++an; } }
   };
   int ntx = tx, nty = ty, nn = n;
-  if (tile < ntiles) issue(n, ty, tx);
-  for (; tile < ntiles; tile += g.nworkers) {
+  if (tile < t_end) issue(n, ty, tx);
+  for (; tile < t_end; ++tile) {
     const int hi0 = ty * g.TH, wi0 = tx * g.TW;                 // multiples of S (TH, TW even when S == 2)
     const int hob = cdiv(hi0 + P - (K - 1), S);                 // first output row held in LDS
     __syncthreads();
@@ -384,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     __syncthreads();
     ntx = tx; nty = ty; nn = n;
     advance(nn, nty, ntx);
-    if (tile + g.nworkers < ntiles) issue(nn, nty, ntx);
+    if (tile + 1 < t_end) issue(nn, nty, ntx);
 
 #pragma unroll
     for (int q = 0; q < (DW_EXP == 5 ? 0 : NIT); ++q) {
@@ -565,9 +559,10 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
   const int cpad = (C + 7) / 8 * 8;
   // 14x14 output tiles of 16 channels (several workgroups per CU); small maps take the whole image and 64 channels
   const int sw = 7;
-  const int cb = slab_width((g.Wo <= 7 && g.Ho <= 7) ? 64 : 16, cpad);
+  static const int cb_env = getenv("ATOMNAS_DW_FWD_CB") ? atoi(getenv("ATOMNAS_DW_FWD_CB")) : 0;
+  const int cb = slab_width((g.Wo <= 7 && g.Ho <= 7) ? 64 : (cb_env ? cb_env : 16), cpad);
   pick_tiles(g, g.Ho, g.Wo, sw, cb, 0);
-  ATOMNAS_REQUIRE(cb <= 16 || (g.TH <= 7 && g.TW <= 7), "dwconv_fwd: internal tile configuration error");
+  ATOMNAS_REQUIRE(cb <= 32 || (g.TH <= 7 && g.TW <= 7), "dwconv_fwd: internal tile configuration error");
   g.LH = (g.TH - 1) * S + K;
   g.LW = (g.TW - 1) * S + K;
   g.RP = lds_pitch(g.LW, cb);
@@ -585,7 +580,7 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
   const bool small = g.TH <= 7 && g.TW <= 7;
   if (cb == 8) { if (small) FWD_CASE(8, 7) else FWD_CASE(8, 14) }
   else if (cb == 16) { if (small) FWD_CASE(16, 7) else FWD_CASE(16, 14) }
-  else if (cb == 32) FWD_CASE(32, 7)
+  else if (cb == 32) { if (small) FWD_CASE(32, 7) else FWD_CASE(32, 14) }
   else FWD_CASE(64, 7)
 #undef FWD_CASE
   return check_launch("dwconv_fwd");
@@ -601,7 +596,9 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   g.N = N; g.H = H; g.W = W; g.C = C;
   g.Ho = (H + 2 * P - K) / S + 1; g.Wo = (W + 2 * P - K) / S + 1;
   const int cpad = (C + 7) / 8 * 8;
-  const int cb = slab_width(16, cpad);
+  // measured (tools/dwbench.py): 32-channel slabs win for stride 2 and for maps <= 14x14, 16-channel slabs for large maps
+  static const int cb_env = getenv("ATOMNAS_DW_BWD_CB") ? atoi(getenv("ATOMNAS_DW_BWD_CB")) : 0;
+  const int cb = slab_width(cb_env ? cb_env : ((S == 2 || (H <= 14 && W <= 14)) ? 32 : 16), cpad);
   pick_tiles(g, H, W, SW, cb, S == 2);
   // output window of an input tile: rows ceil((hi0+P-K+1)/S) .. floor((hi0+TH-1+P)/S)
   g.LH = fdiv(g.TH - 1 + P, S) - cdiv(P - (K - 1), S) + 1;
@@ -619,7 +616,7 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2, c3, (const T*)x, ldx, sc, \
                        sh, relu, w, ldw, (T*)h, ldh, dw, stats, stat_ld, g);                                              \
   }
-  if (cb == 8) BWD_CASE(8) else BWD_CASE(16)
+  if (cb == 8) BWD_CASE(8) else if (cb == 16) BWD_CASE(16) else BWD_CASE(32)
 #undef BWD_CASE
   return check_launch("dwconv_bwd");
 }

@@ -129,18 +129,24 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
     __syncthreads();
   }
 
+  // work item = (16-row tile, group of NCG 64-channel chunks): small-M problems (classifier, 7x7 maps) still fill the chip
   const long mtiles = (M + 15) / 16;
-  for (long mt = (long)blockIdx.x * 4 + wave; mt < mtiles; mt += (long)gridDim.x * 4) {
+  const int ngroups = (N + 64 * NCG - 1) / (64 * NCG);
+  const long nitems = mtiles * ngroups;
+  for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+    const long mt = item / ngroups;
     const long m0 = mt * 16;
     const long row = m0 + j;
     const bool rowvalid = row < M;
-    for (int nc0 = 0; nc0 < N; nc0 += 64 * NCG) {
+    {
+      const int nc0 = (int)(item % ngroups) * 64 * NCG;
       f32x4 acc[NCG][4];
 #pragma unroll
       for (int g = 0; g < NCG; ++g)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#pragma unroll 2
       for (int k0 = 0; k0 < Kpad; k0 += KS) {
         const int k = k0 + q * E;
         float av[E];
@@ -482,6 +488,94 @@ __global__ __launch_bounds__(256) void k_gemm_tn(Operand U, int NU, Operand V, i
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ gemm_tn, bf16, transposed LDS
+// Same contract as k_gemm_tn, restructured for bandwidth: 128-row slabs (4x more bytes in flight per barrier), and the
+// operands are written to LDS TRANSPOSED ([column][row], two rows packed per 32-bit store, conflict-free) so that every MFMA
+// fragment -- 8 consecutive rows of one column -- is a single ds_read_b128 instead of eight 16-bit reads.
+constexpr int TN2_ROWS = 128;
+constexpr int TN2_RP = TN2_ROWS + 8;   // transposed row pitch (elements): 16 consecutive columns land on 16 distinct 16-byte slots
+
+template <int UMODE, int VMODE, int UTT>
+__global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj, long M,
+                                                  long rows_per_block, int ut_max) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* s_v = reinterpret_cast<T*>(smem_raw);          // [64][TN2_RP]
+  T* s_u = s_v + 64 * TN2_RP;                       // [16*ut_max][TN2_RP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int u0 = blockIdx.z * (16 * UTT);
+  const int nu = min(NU - u0, 16 * UTT);
+  const int ut = (nu + 15) / 16;
+  const int v0 = blockIdx.y * 64;
+  const long r_beg = (long)blockIdx.x * rows_per_block;
+  const long r_end = min(M, r_beg + rows_per_block);
+
+  f32x4 acc[UTT];
+#pragma unroll
+  for (int t = 0; t < UTT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ugroups = ut * 2;   // 8-channel groups per row
+  for (long r0 = r_beg; r0 < r_end; r0 += TN2_ROWS) {
+    // stage: a work unit is (row pair, 8-channel group); both rows are loaded, transformed, packed and stored transposed
+    for (int idx = tid; idx < (TN2_ROWS / 2) * 8; idx += 256) {
+      const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
+      float a[8], b[8];
+      load_pro<T, VMODE>(V, r0 + 2 * rp, (r0 + 2 * rp) < r_end, v0 + cg * 8, NV, a);
+      load_pro<T, VMODE>(V, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, v0 + cg * 8, NV, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bf16x2 pk;
+        pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
+        *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * TN2_RP + 2 * rp]) = pk;
+      }
+    }
+    for (int idx = tid; idx < (TN2_ROWS / 2) * ugroups; idx += 256) {
+      const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
+      float a[8], b[8];
+      load_pro<T, UMODE>(U, r0 + 2 * rp, (r0 + 2 * rp) < r_end, u0 + cg * 8, NU, a);
+      load_pro<T, UMODE>(U, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, u0 + cg * 8, NU, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bf16x2 pk;
+        pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
+        *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * TN2_RP + 2 * rp]) = pk;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < TN2_ROWS / 32; ++ks) {
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&s_v[(16 * wave + j) * TN2_RP + 32 * ks + 8 * q]);
+#pragma unroll
+      for (int t = 0; t < UTT; ++t) {
+        if (t < ut) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(&s_u[(16 * t + j) * TN2_RP + 32 * ks + 8 * q]);
+          acc[t] = MM::mma(af, bf, acc[t]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int vc = v0 + 16 * wave + j;
+  if (vc < NV) {
+#pragma unroll
+    for (int t = 0; t < UTT; ++t) {
+      if (t < ut) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int uc = u0 + 16 * t + 4 * q + r;
+          if (uc < NU) atomicAdd(&out[uc * si + vc * sj], acc[t][r]);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 template <int KSTEPS>
 static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
@@ -514,11 +608,12 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
   constexpr int KS = 4 * Mma<T>::EPL;
   const int Kpad = (K + KS - 1) / KS * KS;
   const long mtiles = (M + 15) / 16;
-  long blocks = (mtiles + 3) / 4;
+  const bool wide = N > 64;  // keep two 64-channel chunks live when there is more than one
+  const int ngroups = wide ? (N + 127) / 128 : 1;
+  long blocks = (mtiles * ngroups + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   dim3 grid((unsigned)blocks), block(256);
   const T* W = (const T*)Wp;
-  const bool wide = N > 64;  // keep two 64-channel chunks live when there is more than one
 #define NT_CASE(MODE)                                                                                           \
   if (wide) hipLaunchKernelGGL((k_gemm_nt<T, MODE, 2>), grid, block, 0, st, A, W, ldw, ep, M, N, K, Kpad);       \
   else hipLaunchKernelGGL((k_gemm_nt<T, MODE, 1>), grid, block, 0, st, A, W, ldw, ep, M, N, K, Kpad);
@@ -529,9 +624,52 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
   return check_launch("gemm_nt");
 }
 
+template <int UTT>
+static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
+                         hipStream_t st) {
+  const int vt = (NV + 63) / 64, uz = (NU + 16 * UTT - 1) / (16 * UTT);
+  long chunks = (2048 + (long)vt * uz - 1) / ((long)vt * uz);
+  long rows = (M + chunks - 1) / chunks;
+  if (rows < 2 * TN2_ROWS) rows = 2 * TN2_ROWS;
+  rows = (rows + TN2_ROWS - 1) / TN2_ROWS * TN2_ROWS;
+  chunks = (M + rows - 1) / rows;
+  dim3 grid((unsigned)chunks, vt, uz), block(256);
+  const size_t lds = (size_t)(64 + 16 * UTT) * TN2_RP * sizeof(bf16_t);
+#define TN2_CASE(UM, VM)                                                                                                      \
+  {                                                                                                                           \
+    auto kern = k_gemm_tn2<UM, VM, UTT>;                                                                                      \
+    static bool granted = false;                                                                                              \
+    if (lds > 64 * 1024 && !granted) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      granted = true;                                                                                                         \
+    }                                                                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, U, NU, V, NV, out, si, sj, M, rows, UTT);                                  \
+  }
+  if (umode == PRO_NONE && vmode == PRO_NONE) TN2_CASE(PRO_NONE, PRO_NONE)
+  else if (umode == PRO_NONE && vmode == PRO_BNBWD) TN2_CASE(PRO_NONE, PRO_BNBWD)
+  else if (umode == PRO_BNBWD && vmode == PRO_BNRELU) TN2_CASE(PRO_BNBWD, PRO_BNRELU)
+  else if (umode == PRO_BNRELU && vmode == PRO_BNBWD) TN2_CASE(PRO_BNRELU, PRO_BNBWD)
+  else if (umode == PRO_BNBWD && vmode == PRO_NONE) TN2_CASE(PRO_BNBWD, PRO_NONE)
+  else { set_error("gemm_tn: unsupported prologue pair (%d,%d)", umode, vmode); return 1; }
+#undef TN2_CASE
+  return check_launch("gemm_tn2");
+}
+
+static int launch_tn2(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
+                      hipStream_t st) {
+  // accumulator tiles per wave (= U tiles of 16 columns): fewer tiles -> fewer AGPRs -> more waves per SIMD
+  const int ut = (NU + 15) / 16;
+  if (ut <= 2) return launch_tn2_ut<2>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  if (ut <= 4) return launch_tn2_ut<4>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  if (ut <= 6) return launch_tn2_ut<6>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  if (ut <= 12) return launch_tn2_ut<12>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  return launch_tn2_ut<20>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+}
+
 template <typename T>
 static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
                      hipStream_t st) {
+  if constexpr (sizeof(T) == 2) return launch_tn2(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
   const int vt = (NV + 63) / 64, uz = (NU + 16 * UT_MAX - 1) / (16 * UT_MAX);
   // enough row chunks to fill the chip, but at least 8 slabs of 32 rows per block
   long chunks = (1024 + (long)vt * uz - 1) / ((long)vt * uz);
