@@ -75,7 +75,7 @@ def test_train_steps_match_oracle(gpu_lib, use_graph):
     for k, v in sd.items():
         if v.is_floating_point():
             s = max(1e-3, float(v.abs().max()))
-            assert_close("param " + k, msd[k], v, rtol=2e-3, atol=2e-3 * s)
+            assert_close("param " + k, msd[k], v, rtol=5e-3, atol=5e-3 * s)
         else:
             assert int(msd[k]) == int(v) == 2, k
     for n, p in model.named_parameters():
