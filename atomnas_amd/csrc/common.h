@@ -118,6 +118,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Launch sizing.  The hot kernels are persistent: their grids are exactly the number of workgroups that are resident at
+// once (measured: a partial second round of workgroups cost the depthwise kernels up to 1.8x).  Host-side queries only,
+// cached per (kernel, dynamic LDS size): nothing is enqueued, so launches stay capturable into a hipGraph.
+int num_cus();
+int resident_per_cu_raw(const void* kern, int threads, size_t lds);
+template <typename KernelT>
+static inline int resident_per_cu(KernelT kern, int threads, size_t lds) {
+  return resident_per_cu_raw((const void*)kern, threads, lds);
+}
+
 #define ATOMNAS_REQUIRE(cond, ...)            \
   do {                                        \
     if (!(cond)) {                            \

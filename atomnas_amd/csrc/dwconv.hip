@@ -23,7 +23,25 @@
 #define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute
 #endif
 
+#ifndef DW_TIMING
+#define DW_TIMING 0  // s_memtime phase accounting (tools/dwbench.py, experiment builds only)
+#endif
+
 namespace atomnas {
+
+#if DW_TIMING
+__device__ unsigned long long g_dw_timing[8];
+#define TMARK(i)                                                       \
+  {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long tn_ = __builtin_readcyclecounter();       \
+    tacc[i] += tn_ - tlast;                                            \
+    tlast = tn_;                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  }
+#else
+#define TMARK(i)
+#endif
 
 constexpr __host__ __device__ int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 constexpr __host__ __device__ int cdiv(int a, int b) { return -fdiv(-a, b); }
@@ -42,13 +60,28 @@ template <> struct Raw8<float> {
   __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e] : b[e - 4]; }
 };
 
+// one channel pair of one pixel, raw
+template <typename T> struct Raw2;
+template <> struct Raw2<bf16_t> {
+  unsigned v;
+  __device__ __forceinline__ void zero() { v = 0u; }
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const unsigned*>(p); }
+  __device__ __forceinline__ float get(int e) const { return __uint_as_float(e ? (v & 0xffff0000u) : (v << 16)); }
+};
+template <> struct Raw2<float> {
+  f32x2 v;
+  __device__ __forceinline__ void zero() { v = f32x2{0.f, 0.f}; }
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const f32x2*>(p); }
+  __device__ __forceinline__ float get(int e) const { return v[e]; }
+};
+
 struct DwGeom {
   int N, H, W, C, Ho, Wo;
   int CB;                 // channels per slab (8, 16, 32 or 64)
   int TH, TW;             // tile: output pixels (forward) / input pixels (backward)
   int tiles_y, tiles_x;   // tiles per image
   int LH, LW, RP;         // LDS operand tile: rows, cols, row pitch (floats)
-  int nworkers;           // workgroups per slab (persistent loop over tiles), multiple of 8
+  int nworkers;           // workgroups per slab (persistent loop over tiles)
   int nslabs;             // channel slabs
 };
 
@@ -82,6 +115,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   // one XCD take the slabs of one worker (= one tile sequence).
   const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;
   const int slab = b_local % g.nslabs, worker = (b_local / g.nslabs) * 8 + b_xcd;
+  if (worker >= g.nworkers) return;
   const int c_base = slab * CB;
   const int cpad = (g.C + 7) & ~7;
 
@@ -274,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   constexpr int C2 = CB / 2, CG = CB / 8;
   const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;   // XCD-aware decode, see k_dwconv_fwd
   const int slab = b_local % g.nslabs, worker = (b_local / g.nslabs) * 8 + b_xcd;
+  if (worker >= g.nworkers) return;
   const int c_base = slab * CB;
   const int cpad = (g.C + 7) & ~7;
 
@@ -361,6 +396,28 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     it_r[q] = it < nitems ? rs / nstrips : -1;
     it_j[q] = rs % nstrips;
   }
+  // The strip's raw input pixels stay in registers from the weight-gradient operand to the ReLU mask / statistics of the
+  // epilogue.  (Measured: re-reading them in the epilogue cost 7k of 27k cycles per tile, loading them behind the next
+  // tile's prefetch another 8k; prefetching them a whole tile ahead as well gained nothing further and spills for k = 7.)
+  Raw2<T> xq[NIT][SW];
+  auto load_x = [&](int an, int aty, int atx) {
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int r = it_r[q];
+      const int hi = aty * g.TH + r, wis = atx * g.TW + it_j[q] * SW;
+      const bool rowok = r >= 0 && hi < g.H && ch_ok;
+      const T* xrow = x + (((long)an * g.H + hi) * g.W) * ldx + ch;
+#pragma unroll
+      for (int t = 0; t < SW; ++t) {
+        xq[q][t].zero();
+        if (rowok && wis + t < g.W) xq[q][t].load(xrow + (long)(wis + t) * ldx);
+      }
+    }
+  };
+#if DW_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
 
   const int t_beg = (int)((long)worker * ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * ntiles / g.nworkers);
   int tile = t_beg;   // contiguous tile range per worker (halo reuse in the XCD's L2), see k_dwconv_fwd
@@ -373,12 +430,18 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   for (; tile < t_end; ++tile) {
     const int hi0 = ty * g.TH, wi0 = tx * g.TW;                 // multiples of S (TH, TW even when S == 2)
     const int hob = cdiv(hi0 + P - (K - 1), S);                 // first output row held in LDS
+    TMARK(6)
     __syncthreads();
+    TMARK(0)
     commit();
+    TMARK(1)
     __syncthreads();
+    TMARK(2)
     ntx = tx; nty = ty; nn = n;
     advance(nn, nty, ntx);
+    load_x(n, ty, tx);   // needed first: ahead of the next tile's prefetch in the (in-order) memory queue
     if (tile + 1 < t_end) issue(nn, nty, ntx);
+    TMARK(3)
 
 #pragma unroll
     for (int q = 0; q < (DW_EXP == 5 ? 0 : NIT); ++q) {
@@ -388,14 +451,12 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       const int wis = wi0 + j * SW;  // first input column of this strip (multiple of S)
       // this strip's activated input pixels (for the weight gradient)
       f32x2 xa[SW];
-      const T* xr = x + (((long)n * g.H + hi) * g.W) * ldx + ch;
 #pragma unroll
       for (int t = 0; t < SW; ++t) {
         const int wi = wis + t;
         xa[t] = f32x2{0.f, 0.f};
         if (wi < g.W) {
-          float v[2];
-          VecIO<T, 2>::load(xr + (long)wi * ldx, v);
+          const float v[2] = {xq[q][t].get(0), xq[q][t].get(1)};
           const float a0 = v[0] * sc[0] + sh[0], a1 = v[1] * sc[1] + sh[1];
           xa[t] = in_relu ? f32x2{fmaxf(a0, 0.f), fmaxf(a1, 0.f)} : f32x2{a0, a1};
         }
@@ -429,14 +490,15 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
         __builtin_amdgcn_sched_barrier(0);  // keep one dY row live at a time (the loop is unrolled for static dwa indices)
       }
 
-      // epilogue: ReLU mask of the producer (x is re-read; it is hot in L1/L2), rounding, statistics
+      TMARK(4)
+      // epilogue: ReLU mask of the producer, rounding, statistics
       T* hr = h + (((long)n * g.H + hi) * g.W) * ldh + ch;
 #pragma unroll
       for (int t = 0; t < SW; ++t) {
         const int wi = wis + t;
         if (wi < g.W) {
-          float xv[2], o[2];
-          VecIO<T, 2>::load(xr + (long)wi * ldx, xv);
+          const float xv[2] = {xq[q][t].get(0), xq[q][t].get(1)};
+          float o[2];
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const float a = xv[c] * sc[c] + sh[c];
@@ -449,9 +511,17 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
           VecIO<T, 2>::store(hr + (long)wi * ldh, o);
         }
       }
+      TMARK(5)
     }
     tx = ntx; ty = nty; n = nn;
   }
+#if DW_TIMING
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_dw_timing[i], tacc[i]);
+    atomicAdd(&g_dw_timing[7], (unsigned long long)(t_end - t_beg));
+  }
+#endif
 
   // block reduction of the weight gradient and the statistics, one flush per workgroup: lanes l, l+C2, l+2*C2, ... of a
   // wave hold the same channel pair -> butterfly over those first, then one LDS atomic per value from the first C2 lanes
@@ -498,17 +568,6 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int g_num_cus = 0;
-static int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
-  }
-  return g_num_cus;
-}
-
 static int slab_width(int preferred, int cpad) {
   int need = cpad <= 8 ? 8 : (cpad <= 16 ? 16 : (cpad <= 32 ? 32 : 64));
   return preferred < need ? preferred : need;
@@ -525,29 +584,19 @@ static void pick_tiles(DwGeom& g, int rows, int cols, int sw, int cb, int even) 
   g.tiles_x = (cols + g.TW - 1) / g.TW;
 }
 
-static void set_workers(DwGeom& g, int nslabs, size_t lds_bytes) {
+// Persistent grid: exactly as many workgroups as are resident at once (a partial second round of workgroups costs up to 2x).
+static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap) {
   const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
-  int per_cu = (int)(160 * 1024 / (lds_bytes + 1024));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 4) per_cu = 4;
-  long want = ((long)num_cus() * per_cu + nslabs - 1) / nslabs;
+  if (per_cu > cap) per_cu = cap;
+  long want = ((long)num_cus() * per_cu) / nslabs;
   if (want > ntiles) want = ntiles;
-  want = (want + 7) / 8 * 8;   // one worker group per XCD
+  if (want < 1) want = 1;
   g.nworkers = (int)want;
   g.nslabs = nslabs;
 }
-
-template <typename KernelT>
-static void allow_big_lds(KernelT kern, size_t lds) {
-  // dynamic LDS above 64 KiB must be opted into once per kernel (not a stream operation; done at first use)
-  static std::unordered_map<const void*, size_t> granted;
-  if (lds <= 64 * 1024) return;
-  size_t& have = granted[(const void*)kern];
-  if (lds > have) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    have = lds;
-  }
-}
+// grid for the XCD-aware decode (worker w lives on XCD w % 8): whole worker groups per XCD; surplus workgroups exit at once
+static inline unsigned dw_grid(const DwGeom& g) { return (unsigned)((g.nworkers + 7) / 8 * 8 * g.nslabs); }
 
 template <typename T, int K, int S>
 static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y,
@@ -569,12 +618,13 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
   const int nslabs = (cpad + cb - 1) / cb;
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 2 * cb) * sizeof(float);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
-  set_workers(g, nslabs, lds);
-  dim3 grid(g.nworkers * nslabs);
+  static const int cap_env = getenv("ATOMNAS_DW_FWD_PERCU") ? atoi(getenv("ATOMNAS_DW_FWD_PERCU")) : 0;
+  const int cap = cap_env ? cap_env : 8;
 #define FWD_CASE(CBV, TMV)                                                                                                   \
   {                                                                                                                      \
     auto kern = k_dwconv_fwd<T, K, S, 7, CBV, TMV>;                                                                           \
-    allow_big_lds(kern, lds);                                                                                            \
+    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap);                                                             \
+    dim3 grid(dw_grid(g));                                                                                      \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy, stats, stat_ld, g); \
   }
   const bool small = g.TH <= 7 && g.TW <= 7;
@@ -596,9 +646,10 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   g.N = N; g.H = H; g.W = W; g.C = C;
   g.Ho = (H + 2 * P - K) / S + 1; g.Wo = (W + 2 * P - K) / S + 1;
   const int cpad = (C + 7) / 8 * 8;
-  // measured (tools/dwbench.py): 32-channel slabs win for stride 2 and for maps <= 14x14, 16-channel slabs for large maps
+  // measured (tools/dwbench.py): 32-channel slabs win for stride 2 and for 7x7 maps with k <= 5, 16-channel slabs elsewhere
+  // (k = 7 with 32 channels spills its 98 weight-gradient accumulators)
   static const int cb_env = getenv("ATOMNAS_DW_BWD_CB") ? atoi(getenv("ATOMNAS_DW_BWD_CB")) : 0;
-  const int cb = slab_width(cb_env ? cb_env : ((S == 2 || (H <= 14 && W <= 14)) ? 32 : 16), cpad);
+  const int cb = slab_width(cb_env ? cb_env : ((S == 2 || (H <= 7 && W <= 7 && K <= 5)) ? 32 : 16), cpad);
   pick_tiles(g, H, W, SW, cb, S == 2);
   // output window of an input tile: rows ceil((hi0+P-K+1)/S) .. floor((hi0+TH-1+P)/S)
   g.LH = fdiv(g.TH - 1 + P, S) - cdiv(P - (K - 1), S) + 1;
@@ -607,12 +658,13 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   const int nslabs = (cpad + cb - 1) / cb;
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2)) * sizeof(float);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
-  set_workers(g, nslabs, lds);
-  dim3 grid(g.nworkers * nslabs);
+  static const int cap_env2 = getenv("ATOMNAS_DW_BWD_PERCU") ? atoi(getenv("ATOMNAS_DW_BWD_PERCU")) : 0;
+  const int cap = cap_env2 ? cap_env2 : 8;
 #define BWD_CASE(CBV)                                                                                                     \
   {                                                                                                                       \
     auto kern = k_dwconv_bwd<T, K, S, SW, CBV>;                                                                           \
-    allow_big_lds(kern, lds);                                                                                             \
+    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap);                                                              \
+    dim3 grid(dw_grid(g));                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2, c3, (const T*)x, ldx, sc, \
                        sh, relu, w, ldw, (T*)h, ldh, dw, stats, stat_ld, g);                                              \
   }
@@ -620,6 +672,18 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
 #undef BWD_CASE
   return check_launch("dwconv_bwd");
 }
+
+#if DW_TIMING
+}  // namespace atomnas
+extern "C" int atomnas_debug_dw_timing(unsigned long long* out8, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(atomnas::g_dw_timing), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(atomnas::g_dw_timing), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+namespace atomnas {
+#endif
 
 #define DW_DISPATCH(FN, ...)                                                                   \
   do {                                                                                         \

@@ -103,7 +103,7 @@ struct Epilogue {
   float* stats; int stat_mode;         // [STAT_ROWS][2][N] fp32 partial rows, accumulated atomically
 };
 
-constexpr int NT_MAX_STAT = 3520;  // largest hidden width of the supernet (3*1152) rounded up to 64
+constexpr int NT_MAX_STAT = 8192;  // dynamic LDS [2][N] floats stays within the 64 KiB default limit
 
 // ------------------------------------------------------------------------------------------------ gemm_nt
 // One wave owns 16 rows of A per step and produces 64 output channels at a time with 4 MFMA tiles whose weight rows
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
   using MM = Mma<T>;
   constexpr int E = MM::EPL;
   constexpr int KS = 4 * E;
-  __shared__ float s_stat[2 * NT_MAX_STAT];
+  extern __shared__ float s_stat[];  // [2][N] when statistics are taken
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -581,15 +581,21 @@ template <int KSTEPS>
 static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
   const int nchunks = (N + 63) / 64;
   const long mtiles = (M + 15) / 16;
-  // about 16 waves per CU in flight, but at least 8 row tiles per item so that the register-resident weights pay off
-  long tiles_per_item = (mtiles * nchunks + 4095) / 4096;
-  if (tiles_per_item < 8) tiles_per_item = 8;
-  const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;
-  dim3 grid((unsigned)((items + 3) / 4)), block(256);
   const bf16_t* W = (const bf16_t*)Wp;
-  if (mode == PRO_NONE) hipLaunchKernelGGL((k_gemm_nt_cs<PRO_NONE, KSTEPS>), grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);
-  else if (mode == PRO_BNRELU) hipLaunchKernelGGL((k_gemm_nt_cs<PRO_BNRELU, KSTEPS>), grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);
-  else hipLaunchKernelGGL((k_gemm_nt_cs<PRO_BNBWD, KSTEPS>), grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);
+  // one item per resident wave (a single round of workgroups), but at least 8 row tiles per item so that the
+  // register-resident weights pay off
+#define CS_CASE(MODE)                                                                                                   \
+  {                                                                                                                     \
+    auto kern = k_gemm_nt_cs<MODE, KSTEPS>;                                                                             \
+    const long waves = (long)num_cus() * resident_per_cu(kern, 256, 0) * 4;                                             \
+    long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;                                                       \
+    if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
+    const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;                                      \
+    dim3 grid((unsigned)((items + 3) / 4)), block(256);                                                                 \
+    hipLaunchKernelGGL(kern, grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);                 \
+  }
+  if (mode == PRO_NONE) CS_CASE(PRO_NONE) else if (mode == PRO_BNRELU) CS_CASE(PRO_BNRELU) else CS_CASE(PRO_BNBWD)
+#undef CS_CASE
 }
 
 template <typename T>
@@ -610,17 +616,24 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
   const long mtiles = (M + 15) / 16;
   const bool wide = N > 64;  // keep two 64-channel chunks live when there is more than one
   const int ngroups = wide ? (N + 127) / 128 : 1;
-  long blocks = (mtiles * ngroups + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
-  dim3 grid((unsigned)blocks), block(256);
+  const long need = (mtiles * ngroups + 3) / 4;
+  const size_t lds = (ep.stats && ep.stat_mode != STAT_NONE) ? (size_t)2 * N * sizeof(float) : 0;
   const T* W = (const T*)Wp;
-#define NT_CASE(MODE)                                                                                           \
-  if (wide) hipLaunchKernelGGL((k_gemm_nt<T, MODE, 2>), grid, block, 0, st, A, W, ldw, ep, M, N, K, Kpad);       \
-  else hipLaunchKernelGGL((k_gemm_nt<T, MODE, 1>), grid, block, 0, st, A, W, ldw, ep, M, N, K, Kpad);
+  // persistent grid-stride loop over (row tile, channel group) items: one round of resident workgroups
+#define NT_LAUNCH(MODE, NCGV)                                                                                  \
+  {                                                                                                            \
+    auto kern = k_gemm_nt<T, MODE, NCGV>;                                                                      \
+    long blocks = (long)num_cus() * resident_per_cu(kern, 256, lds);                                           \
+    if (blocks > need) blocks = need;                                                                          \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, A, W, ldw, ep, M, N, K, Kpad);        \
+  }
+#define NT_CASE(MODE) \
+  if (wide) NT_LAUNCH(MODE, 2) else NT_LAUNCH(MODE, 1)
   if (mode == PRO_NONE) { NT_CASE(PRO_NONE) }
   else if (mode == PRO_BNRELU) { NT_CASE(PRO_BNRELU) }
   else { NT_CASE(PRO_BNBWD) }
 #undef NT_CASE
+#undef NT_LAUNCH
   return check_launch("gemm_nt");
 }
 
@@ -628,21 +641,19 @@ template <int UTT>
 static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
                          hipStream_t st) {
   const int vt = (NV + 63) / 64, uz = (NU + 16 * UTT - 1) / (16 * UTT);
-  long chunks = (2048 + (long)vt * uz - 1) / ((long)vt * uz);
-  long rows = (M + chunks - 1) / chunks;
-  if (rows < 2 * TN2_ROWS) rows = 2 * TN2_ROWS;
-  rows = (rows + TN2_ROWS - 1) / TN2_ROWS * TN2_ROWS;
-  chunks = (M + rows - 1) / rows;
-  dim3 grid((unsigned)chunks, vt, uz), block(256);
   const size_t lds = (size_t)(64 + 16 * UTT) * TN2_RP * sizeof(bf16_t);
+  // row chunks so that the grid is one round of resident workgroups (at least two slabs per workgroup)
 #define TN2_CASE(UM, VM)                                                                                                      \
   {                                                                                                                           \
     auto kern = k_gemm_tn2<UM, VM, UTT>;                                                                                      \
-    static bool granted = false;                                                                                              \
-    if (lds > 64 * 1024 && !granted) {                                                                                        \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-      granted = true;                                                                                                         \
-    }                                                                                                                         \
+    const long resident = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                  \
+    long chunks = resident / ((long)vt * uz);                                                                                 \
+    if (chunks < 1) chunks = 1;                                                                                               \
+    long rows = (M + chunks - 1) / chunks;                                                                                    \
+    if (rows < 2 * TN2_ROWS) rows = 2 * TN2_ROWS;                                                                             \
+    rows = (rows + TN2_ROWS - 1) / TN2_ROWS * TN2_ROWS;                                                                       \
+    chunks = (M + rows - 1) / rows;                                                                                           \
+    dim3 grid((unsigned)chunks, vt, uz), block(256);                                                                          \
     hipLaunchKernelGGL(kern, grid, block, lds, st, U, NU, V, NV, out, si, sj, M, rows, UTT);                                  \
   }
   if (umode == PRO_NONE && vmode == PRO_NONE) TN2_CASE(PRO_NONE, PRO_NONE)

@@ -3,6 +3,8 @@
 #include "common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <unordered_map>
 
 namespace atomnas {
 static thread_local char g_err[512] = "";
@@ -21,6 +23,43 @@ int check_launch(const char* what) {
     return 2;
   }
   return 0;
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+int resident_per_cu_raw(const void* kern, int threads, size_t lds) {
+  static std::mutex mu;
+  static std::unordered_map<size_t, int> cache;
+  static std::unordered_map<const void*, size_t> granted;
+  std::lock_guard<std::mutex> lock(mu);
+  if (lds > 64 * 1024) {  // dynamic LDS above 64 KiB must be opted into once per kernel
+    size_t& have = granted[kern];
+    if (lds > have) {
+      (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      have = lds;
+    }
+  }
+  const size_t key = ((size_t)kern * 1000003u + lds) * 31u + (size_t)threads;
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) {
+    (void)hipGetLastError();
+    nb = (int)(160 * 1024 / (lds + 1024));
+    if (nb > 2) nb = 2;
+    if (nb < 1) nb = 1;
+  }
+  cache[key] = nb;
+  return nb;
 }
 }  // namespace atomnas
 

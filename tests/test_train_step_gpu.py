@@ -81,9 +81,12 @@ def test_train_steps_match_oracle(gpu_lib, use_graph):
     for n, p in model.named_parameters():
         st = opt.state[p]
         s = max(1e-6, float(opt_state[n]['square_avg'].abs().max()))
-        assert_close("sq " + n, st['square_avg'], opt_state[n]['square_avg'], rtol=2e-2, atol=1e-2 * s)
+        # a ReLU pre-activation within fp32 rounding of zero flips its mask against the fp64 oracle: a handful of gradient
+        # elements (mostly of the stem, at the end of the backward chain) then differ by a few percent -> bounded outliers
+        assert_close("sq " + n, st['square_avg'], opt_state[n]['square_avg'], rtol=2e-2, atol=1e-2 * s, outlier_frac=0.03, rel_l2=3e-2)
         s = max(1e-3, float(opt_state[n]['momentum_buffer'].abs().max()))
-        assert_close("buf " + n, st['momentum_buffer'], opt_state[n]['momentum_buffer'], rtol=2e-2, atol=1e-2 * s)
+        assert_close("buf " + n, st['momentum_buffer'], opt_state[n]['momentum_buffer'], rtol=2e-2, atol=1e-2 * s, outlier_frac=0.03,
+                     rel_l2=3e-2)
     for k in ema_o:
         s = max(1e-3, float(ema_o[k].abs().max()))
         assert_close("ema " + k, ema.average(k), ema_o[k], rtol=2e-3, atol=2e-3 * s)
