@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libatomnas_hip.so")
+LIB_PATH = os.environ.get("ATOMNAS_HIP_LIB") or os.path.join(_HERE, "libatomnas_hip.so")  # override: experiment builds
 
 vp, i32, i64, f32, f64, u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double,
                                ctypes.c_ulonglong)

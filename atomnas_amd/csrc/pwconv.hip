@@ -18,6 +18,7 @@
 //     16 consecutive output channels of one pixel, i.e. whole 32-byte runs, with no LDS transpose.
 // fp32 storage uses mfma_f32_16x16x4f32 through the same code (exact f32; for parity tests, not for speed).
 #include "common.h"
+#include <cstdlib>
 
 namespace atomnas {
 
@@ -493,26 +494,49 @@ __global__ __launch_bounds__(256) void k_gemm_tn(Operand U, int NU, Operand V, i
 // Same contract as k_gemm_tn, restructured for bandwidth: 128-row slabs (4x more bytes in flight per barrier), and the
 // operands are written to LDS TRANSPOSED ([column][row], two rows packed per 32-bit store, conflict-free) so that every MFMA
 // fragment -- 8 consecutive rows of one column -- is a single ds_read_b128 instead of eight 16-bit reads.
+#ifndef TN2_COALESCED
+#define TN2_COALESCED 0   // staging loads: 0 = lanes along rows (16 bytes of 64 different lines per instruction, revisited from L1
+                          // by the next channel groups), 1 = lanes along channels (whole 128-byte segments).  Measured in situ
+                          // (bs 256 step): 11.8 ms vs 13.0 ms per step for all weight-gradient GEMMs -- rows win.
+#endif
+#ifndef TN2_KS_UNROLL
+#define TN2_KS_UNROLL 2
+#endif
 constexpr int TN2_ROWS = 128;
 constexpr int TN2_RP = TN2_ROWS + 8;   // transposed row pitch (elements): 16 consecutive columns land on 16 distinct 16-byte slots
 
 template <int UMODE, int VMODE, int UTT>
 __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj, long M,
-                                                  long rows_per_block, int ut_max) {
+                                                  long rows_per_block, int nchunks, int vt, int uz, int xcd_aware) {
   using T = bf16_t;
   using MM = Mma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_v = reinterpret_cast<T*>(smem_raw);          // [64][TN2_RP]
-  T* s_u = s_v + 64 * TN2_RP;                       // [16*ut_max][TN2_RP]
+  T* s_u = s_v + 64 * TN2_RP;                       // [16*UTT][TN2_RP]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & 15;
-  const int u0 = blockIdx.z * (16 * UTT);
+  // Workgroup b runs on XCD b % 8.  All column tiles (V tile, U tile) of one row chunk are consecutive workgroups of ONE XCD:
+  // they re-read the chunk's narrow operand and share the 128-byte lines that 64-column tiles straddle, so those hit that
+  // XCD's L2 instead of going back to HBM once per tile.
+  const int ntile = vt * uz;
+  int tile; long chunk;
+  if (xcd_aware) {
+    const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;
+    tile = b_local % ntile;
+    chunk = (long)(b_local / ntile) * 8 + b_xcd;
+  } else {
+    chunk = blockIdx.x % nchunks;
+    tile = blockIdx.x / nchunks;
+    if (tile >= ntile) return;
+  }
+  if (chunk >= nchunks) return;
+  const int u0 = (tile / vt) * (16 * UTT);
   const int nu = min(NU - u0, 16 * UTT);
   const int ut = (nu + 15) / 16;
-  const int v0 = blockIdx.y * 64;
-  const long r_beg = (long)blockIdx.x * rows_per_block;
+  const int v0 = (tile % vt) * 64;
+  const long r_beg = chunk * rows_per_block;
   const long r_end = min(M, r_beg + rows_per_block);
 
   f32x4 acc[UTT];
@@ -521,33 +545,49 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
 
   const int ugroups = ut * 2;   // 8-channel groups per row
   for (long r0 = r_beg; r0 < r_end; r0 += TN2_ROWS) {
-    // stage: a work unit is (row pair, 8-channel group); both rows are loaded, transformed, packed and stored transposed
+    // stage: a work unit is (row pair, 8-channel group), channel groups fastest across lanes (whole 128-byte row segments per
+    // load instruction); both rows are loaded, transformed, packed and stored transposed.  The element order is rotated
+    // per channel group so that the 64 lanes of each ds_write_b32 hit 64 distinct banks (RP = 136: bank = 32*(cg&1) +
+    // 4*e + rp; rotating e by 2*(cg>>1) spreads the four groups that would collide).
     for (int idx = tid; idx < (TN2_ROWS / 2) * 8; idx += 256) {
+#if TN2_COALESCED
+      const int cg = idx % 8, rp = idx / 8;
+#else
       const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
+#endif
       float a[8], b[8];
       load_pro<T, VMODE>(V, r0 + 2 * rp, (r0 + 2 * rp) < r_end, v0 + cg * 8, NV, a);
       load_pro<T, VMODE>(V, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, v0 + cg * 8, NV, b);
+      const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int i = 0; i < 8; ++i) {
+        const int e = (i + rot) & 7;
         bf16x2 pk;
         pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
         *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * TN2_RP + 2 * rp]) = pk;
       }
     }
+#pragma unroll 2
     for (int idx = tid; idx < (TN2_ROWS / 2) * ugroups; idx += 256) {
+#if TN2_COALESCED
+      const int cg = idx % ugroups, rp = idx / ugroups;
+#else
       const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
+#endif
       float a[8], b[8];
       load_pro<T, UMODE>(U, r0 + 2 * rp, (r0 + 2 * rp) < r_end, u0 + cg * 8, NU, a);
       load_pro<T, UMODE>(U, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, u0 + cg * 8, NU, b);
+      const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int i = 0; i < 8; ++i) {
+        const int e = (i + rot) & 7;
         bf16x2 pk;
         pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
         *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * TN2_RP + 2 * rp]) = pk;
       }
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll TN2_KS_UNROLL   // full unrolling hoists all fragment reads: 162 VGPRs for 6 accumulator tiles, 2 waves per SIMD
     for (int ks = 0; ks < TN2_ROWS / 32; ++ks) {
       const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&s_v[(16 * wave + j) * TN2_RP + 32 * ks + 8 * q]);
 #pragma unroll
@@ -643,18 +683,21 @@ static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const O
   const int vt = (NV + 63) / 64, uz = (NU + 16 * UTT - 1) / (16 * UTT);
   const size_t lds = (size_t)(64 + 16 * UTT) * TN2_RP * sizeof(bf16_t);
   // row chunks so that the grid is one round of resident workgroups (at least two slabs per workgroup)
+  static const int xcd_env = getenv("ATOMNAS_TN_XCD") ? atoi(getenv("ATOMNAS_TN_XCD")) : 1;
 #define TN2_CASE(UM, VM)                                                                                                      \
   {                                                                                                                           \
     auto kern = k_gemm_tn2<UM, VM, UTT>;                                                                                      \
     const long resident = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                  \
     long chunks = resident / ((long)vt * uz);                                                                                 \
+    if (chunks > M / (2 * TN2_ROWS)) chunks = M / (2 * TN2_ROWS);                                                             \
+    int xcd = xcd_env;                                                                                                        \
+    if (chunks < 8) xcd = 0; /* fewer chunks than XCDs: plain order */                                                        \
+    if (xcd) chunks = chunks / 8 * 8; /* equal work per XCD */                                                                \
     if (chunks < 1) chunks = 1;                                                                                               \
-    long rows = (M + chunks - 1) / chunks;                                                                                    \
-    if (rows < 2 * TN2_ROWS) rows = 2 * TN2_ROWS;                                                                             \
-    rows = (rows + TN2_ROWS - 1) / TN2_ROWS * TN2_ROWS;                                                                       \
+    const long rows = (M + chunks - 1) / chunks;                                                                              \
     chunks = (M + rows - 1) / rows;                                                                                           \
-    dim3 grid((unsigned)chunks, vt, uz), block(256);                                                                          \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, U, NU, V, NV, out, si, sj, M, rows, UTT);                                  \
+    dim3 grid((unsigned)((xcd ? (chunks + 7) / 8 * 8 : chunks) * vt * uz)), block(256);                                       \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, U, NU, V, NV, out, si, sj, M, rows, (int)chunks, vt, uz, xcd);             \
   }
   if (umode == PRO_NONE && vmode == PRO_NONE) TN2_CASE(PRO_NONE, PRO_NONE)
   else if (umode == PRO_NONE && vmode == PRO_BNBWD) TN2_CASE(PRO_NONE, PRO_BNBWD)

@@ -6,7 +6,7 @@ NAME=$1; SRC=$2; EXTRA=$3
 B=atomnas_amd/csrc/build
 mkdir -p tools/variants/obj
 O=tools/variants/obj/${NAME}_$(basename $SRC .hip).o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $EXTRA -c atomnas_amd/csrc/$SRC -o $O
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed $EXTRA -c atomnas_amd/csrc/$SRC -o $O
 OBJS=$(ls $B/*.o | grep -v "/$(basename $SRC .hip).o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/variants/lib$NAME.so $O $OBJS
 echo built tools/variants/lib$NAME.so
