@@ -106,6 +106,94 @@ struct Epilogue {
 
 constexpr int NT_MAX_STAT = 8192;  // dynamic LDS [2][N] floats stays within the 64 KiB default limit
 
+// Epilogue of one 16-pixel x 64-channel accumulator tile: the lane holds channels nb .. nb+15 of pixel `row`, ordered [t][r].
+// bias, residual add, ReLU mask of the producer, rounding to the storage type, store, and the per-channel statistics
+// (reduced over the 16 pixels with cross-lane adds, then one LDS atomic per channel into s_stat[2][N]).
+template <typename T>
+__device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&acc)[4], long row, bool rowvalid, int nb, int N,
+                                            bool do_stats, float* s_stat, int j) {
+  float c[16], zv[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[4 * t + r] = acc[t][r];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zv[i] = 0.f;
+
+  if (rowvalid) {
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+      const int n8 = nb + 8 * h8;
+      if (n8 >= N) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[8 * h8 + i] = 0.f;
+        continue;
+      }
+      float tmp[8];
+      if (ep.bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[8 * h8 + i] += (n8 + i < N) ? ep.bias[n8 + i] : 0.f;
+      }
+      if (ep.add) {
+        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.add) + row * ep.ldadd + n8, tmp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
+      }
+      if (ep.z) {
+        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + row * ep.ldz + n8, tmp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zv[8 * h8 + i] = tmp[i];
+        if (ep.mask) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int n = n8 + i;
+            const float a = (n < N) ? tmp[i] * ep.zscale[n] + ep.zshift[n] : 0.f;
+            if (!(a > 0.f)) c[8 * h8 + i] = 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n8 + i >= N) c[8 * h8 + i] = 0.f;
+      if (ep.out_f32) {
+        float* cp = reinterpret_cast<float*>(ep.c) + row * ep.ldc + n8;
+        float o8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
+        VecIO<float, 8>::store(cp, o8);
+      } else {
+        float o8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
+          c[8 * h8 + i] = o8[i];  // statistics see the stored value
+        }
+        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + row * ep.ldc + n8, o8);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+  }
+
+  if (do_stats) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s1 = c[i];
+      float s2 = (ep.stat_mode == STAT_SQ) ? c[i] * c[i] : c[i] * zv[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      if (j == 0 && nb + i < N) {
+        atomicAdd(&s_stat[nb + i], s1);
+        atomicAdd(&s_stat[N + nb + i], s2);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ gemm_nt
 // One wave owns 16 rows of A per step and produces 64 output channels at a time with 4 MFMA tiles whose weight rows
 // are interleaved (row i of tile t is channel nc + 16*(i>>2) + 4*t + (i&3)) so that lane (q = lane>>4, j = lane&15)
@@ -169,89 +257,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
       // epilogue: lane holds channels nb .. nb+15 of pixel `row`, ordered [t][r]
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
-        const int nb = nc0 + 64 * g + 16 * q;
         if (nc0 + 64 * g >= N) continue;
-        float c[16], zv[16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) c[4 * t + r] = acc[g][t][r];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) zv[i] = 0.f;
-
-        if (rowvalid) {
-#pragma unroll
-          for (int h8 = 0; h8 < 2; ++h8) {
-            const int n8 = nb + 8 * h8;
-            if (n8 >= N) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) c[8 * h8 + i] = 0.f;
-              continue;
-            }
-            float tmp[8];
-            if (ep.bias) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) c[8 * h8 + i] += (n8 + i < N) ? ep.bias[n8 + i] : 0.f;
-            }
-            if (ep.add) {
-              VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.add) + row * ep.ldadd + n8, tmp);
-#pragma unroll
-              for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
-            }
-            if (ep.z) {
-              VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + row * ep.ldz + n8, tmp);
-#pragma unroll
-              for (int i = 0; i < 8; ++i) zv[8 * h8 + i] = tmp[i];
-              if (ep.mask) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                  const int n = n8 + i;
-                  const float a = (n < N) ? tmp[i] * ep.zscale[n] + ep.zshift[n] : 0.f;
-                  if (!(a > 0.f)) c[8 * h8 + i] = 0.f;
-                }
-              }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if (n8 + i >= N) c[8 * h8 + i] = 0.f;
-            if (ep.out_f32) {
-              float* cp = reinterpret_cast<float*>(ep.c) + row * ep.ldc + n8;
-              float o8[8];
-#pragma unroll
-              for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
-              VecIO<float, 8>::store(cp, o8);
-            } else {
-              float o8[8];
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
-                c[8 * h8 + i] = o8[i];  // statistics see the stored value
-              }
-              VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + row * ep.ldc + n8, o8);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) c[i] = 0.f;
-        }
-
-        if (do_stats) {
-          // reduce over the 16 pixels (lanes with equal q), then one LDS atomic per channel from lane j == 0
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float s1 = c[i];
-            float s2 = (ep.stat_mode == STAT_SQ) ? c[i] * c[i] : c[i] * zv[i];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-              s1 += __shfl_xor(s1, o, 64);
-              s2 += __shfl_xor(s2, o, 64);
-            }
-            if (j == 0 && nb + i < N) {
-              atomicAdd(&s_stat[nb + i], s1);
-              atomicAdd(&s_stat[N + nb + i], s2);
-            }
-          }
-        }
+        nt_epilogue<T>(ep, acc[g], row, rowvalid, nc0 + 64 * g + 16 * q, N, do_stats, s_stat, j);
       }
     }
   }
@@ -394,6 +401,202 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
         atomicAdd(&srow[nb + i], a);
         atomicAdd(&srow[N + nb + i], b);
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gemm_nt, weights shared in LDS
+// For the contraction-heavy shapes (K > 192: the linear projection forward, the expand input-gradient): the 6x-wide hidden
+// tensor is the INPUT, streamed once from HBM straight into MFMA B fragments (prologue applied in registers).  In the
+// row-stationary kernel every wave re-loads the weight fragments and the prologue coefficients of every k-step from
+// L1/L2 -- 8..12 vector-memory instructions per 1 KiB of activations, which bounds it at the texture-address rate, not at
+// HBM.  Here a workgroup owns 64*RT rows, and the weights (64*NCG channels x 64 k) and coefficients of a k-chunk are
+// staged ONCE per workgroup into LDS (double-buffered, one barrier per chunk) and read back as ds_read_b128 fragments:
+// the only vector-memory traffic left in the k-loop is the activation stream itself, prefetched one chunk ahead.
+constexpr int WS_KC = 64;            // k per chunk (two MFMA k-steps)
+constexpr int WS_WP = WS_KC + 8;     // LDS row pitch (elements): 16 consecutive rows -> 16 distinct 16-byte bank groups
+
+template <int MODE> struct WsRaw { bf16x8 a; };
+template <> struct WsRaw<PRO_BNBWD> { bf16x8 a, x; };
+
+template <int MODE, int NCG, int RT>
+__global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __restrict__ Wp, int ldw, int wrows, Epilogue ep, long M,
+                                                    int N, int K) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  constexpr int WROWS = 64 * NCG;
+  constexpr int WBUF = WROWS * WS_WP;
+  constexpr int NVEC = (MODE == PRO_BNRELU) ? 2 : (MODE == PRO_BNBWD ? 3 : 0);
+  constexpr int WPASS = WROWS * 8 / 256;   // 16-byte weight pieces per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_ws[];
+  T* s_w = reinterpret_cast<T*>(smem_ws);                     // [2][WROWS][WS_WP], rows permuted (see below)
+  float* s_c = reinterpret_cast<float*>(s_w + 2 * WBUF);      // [2][3][WS_KC]
+  float* s_stat = s_c + 2 * 3 * WS_KC;                        // [2][N]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+  if (do_stats) {
+    for (int i = tid; i < 2 * N; i += 256) s_stat[i] = 0.f;
+  }
+  const int nchunk = (K + WS_KC - 1) / WS_KC;
+  const int K8 = (K + 7) & ~7;
+  const long rblocks = (M + 64 * RT - 1) / (64 * RT);
+  const int ngroups = (N + WROWS - 1) / WROWS;
+
+  // staging role: piece p of this thread is weight row (tid + 256 p) / 8 of the group, 16-byte segment tid % 8.  MFMA tile t of
+  // a 64-channel chunk uses channels 16*(jj>>2) + 4*t + (jj&3) for its 16 rows jj: they are stored as LDS rows t*16 + jj, so
+  // that the 16 rows one fragment read touches are consecutive (conflict-free at pitch 72).
+  const int sseg = tid & 7;
+  int srow_g[WPASS], srow_l[WPASS];
+#pragma unroll
+  for (int p = 0; p < WPASS; ++p) {
+    const int r = (tid + 256 * p) >> 3;
+    const int g = r >> 6, n = r & 63;
+    srow_g[p] = r;
+    srow_l[p] = g * 64 + ((n >> 2) & 3) * 16 + (((n >> 4) << 2) | (n & 3));
+  }
+  bf16x8 wreg[WPASS];
+  f32x4 creg = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage_load = [&](int nc0, int c) {
+    const int k = c * WS_KC + sseg * 8;
+#pragma unroll
+    for (int p = 0; p < WPASS; ++p) {
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+      wreg[p] = z;
+      if (k < ldw && nc0 + srow_g[p] < wrows) wreg[p] = *reinterpret_cast<const bf16x8*>(Wp + (long)(nc0 + srow_g[p]) * ldw + k);
+    }
+    if constexpr (NVEC > 0) {
+      if (tid < NVEC * 16) {
+        const int v = tid >> 4, kk = c * WS_KC + (tid & 15) * 4;
+        const float* src = (v == 0) ? A.c1 : (v == 1 ? A.c2 : A.c3);
+        creg = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kk < K8) creg = *reinterpret_cast<const f32x4*>(src + kk);
+      }
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < WPASS; ++p) *reinterpret_cast<bf16x8*>(s_w + buf * WBUF + srow_l[p] * WS_WP + sseg * 8) = wreg[p];
+    if constexpr (NVEC > 0) {
+      if (tid < NVEC * 16) *reinterpret_cast<f32x4*>(s_c + buf * 3 * WS_KC + (tid >> 4) * WS_KC + (tid & 15) * 4) = creg;
+    }
+  };
+
+  for (long item = blockIdx.x; item < rblocks * ngroups; item += gridDim.x) {
+    const long rb = item / ngroups;
+    const int nc0 = (int)(item % ngroups) * WROWS;
+    long row[RT];
+    bool rowvalid[RT];
+#pragma unroll
+    for (int s = 0; s < RT; ++s) {
+      row[s] = rb * (64 * RT) + (wave * RT + s) * 16 + j;
+      rowvalid[s] = row[s] < M;
+    }
+    f32x4 acc[RT][NCG][4];
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[s][g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // raw activations of one chunk: [subtile][k-step], 8 consecutive k of one pixel per lane
+    WsRaw<MODE> anx[RT][2], acur[RT][2];
+    auto load_a = [&](int c) {
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int k = c * WS_KC + ks * 32 + 8 * q;
+          bf16x8 z;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+          anx[s][ks].a = z;
+          if constexpr (MODE == PRO_BNBWD) anx[s][ks].x = z;
+          if (rowvalid[s] && k < K) {   // beyond K the packed weights are zero: no masking needed, but never read past a row
+            anx[s][ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + row[s] * A.ld1 + k);
+            if constexpr (MODE == PRO_BNBWD)
+              anx[s][ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + row[s] * A.ld2 + k);
+          }
+        }
+    };
+
+    stage_load(nc0, 0);
+    load_a(0);
+    stage_store(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      const int buf = c & 1;
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acur[s][ks] = anx[s][ks];
+      if (c + 1 < nchunk) {
+        stage_load(nc0, c + 1);
+        load_a(c + 1);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kl = ks * 32 + 8 * q;
+        float c1v[8], c2v[8], c3v[8];
+        if constexpr (NVEC > 0) {
+          const float* cb = s_c + buf * 3 * WS_KC;
+          VecIO<float, 8>::load(cb + kl, c1v);
+          VecIO<float, 8>::load(cb + WS_KC + kl, c2v);
+          if constexpr (NVEC > 2) VecIO<float, 8>::load(cb + 2 * WS_KC + kl, c3v);
+        }
+        bf16x8 af[RT];
+#pragma unroll
+        for (int s = 0; s < RT; ++s) {
+          if constexpr (MODE == PRO_NONE) {
+            af[s] = acur[s][ks].a;
+          } else {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float a = (float)acur[s][ks].a[e];
+              if constexpr (MODE == PRO_BNRELU) {
+                const float t = a * c1v[e] + c2v[e];
+                v[e] = A.relu ? fmaxf(t, 0.f) : t;
+              } else {
+                v[e] = c1v[e] * a + c2v[e] * (float)acur[s][ks].x[e] + c3v[e];
+              }
+            }
+            af[s] = MM::pack(v);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(s_w + buf * WBUF + (g * 64 + t * 16 + j) * WS_WP + kl);
+#pragma unroll
+            for (int s = 0; s < RT; ++s) acc[s][g][t] = MM::mma(wf, af[s], acc[s][g][t]);
+          }
+      }
+      if (c + 1 < nchunk) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        if (nc0 + 64 * g >= N) continue;
+        nt_epilogue<T>(ep, acc[s][g], row[s], rowvalid[s], nc0 + 64 * g + 16 * q, N, do_stats, s_stat, j);
+      }
+  }
+
+  if (do_stats) {
+    __syncthreads();
+    float* srow = ep.stats + (long)(blockIdx.x % STAT_ROWS) * 2 * N;
+    for (int i = tid; i < 2 * N; i += 256) {
+      const float v = s_stat[i];
+      if (v != 0.f) atomicAdd(&srow[i], v);
     }
   }
 }
@@ -638,6 +841,35 @@ static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, co
 #undef CS_CASE
 }
 
+static int launch_nt_ws(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
+  const bf16_t* W = (const bf16_t*)Wp;
+  const int wrows = (N + 63) / 64 * 64;   // rows of the packed weight matrix
+  const int ncg = N > 64 ? 2 : 1;
+  const int ngroups = (N + 64 * ncg - 1) / (64 * ncg);
+  const size_t lds_stat = (ep.stats && ep.stat_mode != STAT_NONE) ? (size_t)2 * N * sizeof(float) : 0;
+  // two 16-row subtiles per wave (each weight fragment read feeds two MFMAs) when there are enough 128-row blocks
+  static const int rt_env = getenv("ATOMNAS_NT_WS_RT") ? atoi(getenv("ATOMNAS_NT_WS_RT")) : 0;
+  const int rt = rt_env ? rt_env : (M >= 32768 ? 2 : 1);   // measured in situ: 7x7 maps (M = 12544) prefer 64-row blocks
+#define WS_LAUNCH(MODE, NCGV, RTV)                                                                                       \
+  {                                                                                                                      \
+    auto kern = k_gemm_nt_ws<MODE, NCGV, RTV>;                                                                           \
+    const size_t lds = (size_t)2 * 64 * NCGV * WS_WP * sizeof(bf16_t) + 2 * 3 * WS_KC * sizeof(float) + lds_stat;        \
+    const long need = ((M + 64 * RTV - 1) / (64 * RTV)) * ngroups;                                                       \
+    long blocks = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                     \
+    if (blocks > need) blocks = need;                                                                                    \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, A, W, ldw, wrows, ep, M, N, K);                 \
+  }
+#define WS_MODE(MODE)                                                                  \
+  if (ncg == 1) { if (rt == 2) WS_LAUNCH(MODE, 1, 2) else WS_LAUNCH(MODE, 1, 1) }      \
+  else { if (rt == 2) WS_LAUNCH(MODE, 2, 2) else WS_LAUNCH(MODE, 2, 1) }
+  if (mode == PRO_NONE) { WS_MODE(PRO_NONE) }
+  else if (mode == PRO_BNRELU) { WS_MODE(PRO_BNRELU) }
+  else { WS_MODE(PRO_BNBWD) }
+#undef WS_MODE
+#undef WS_LAUNCH
+  return check_launch("gemm_nt_ws");
+}
+
 template <typename T>
 static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
@@ -650,6 +882,10 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
       else launch_nt_cs<6>(mode, A, Wp, ldw, ep, M, N, K, st);
       return check_launch("gemm_nt_cs");
     }
+  }
+  if constexpr (sizeof(T) == 2) {
+    static const int ws_env = getenv("ATOMNAS_NT_WS") ? atoi(getenv("ATOMNAS_NT_WS")) : 1;
+    if (ws_env && K > 192 && M >= 4096) return launch_nt_ws(mode, A, Wp, ldw, ep, M, N, K, st);
   }
   constexpr int KS = 4 * Mma<T>::EPL;
   const int Kpad = (K + KS - 1) / KS * KS;

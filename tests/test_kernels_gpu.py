@@ -121,7 +121,10 @@ def pack_w(w, dtype, transposed=False):
 GEMM_SHAPES = [(100, 24, 16), (1000, 432, 24), (333, 40, 139), (64, 16, 432), (257, 100, 40), (50, 7, 3), (4096, 320, 1152),
                # column-stationary kernel (M >= 1024, K <= 192, N >= 2K): 1, 2, 3 and 6 k-steps, ragged N and M
                (2000, 432, 24), (1500, 288, 16), (1100, 720, 40), (1031, 203, 96), (1200, 400, 192), (2048, 139, 24),
-               (20000, 1440, 80)]
+               (20000, 1440, 80),
+               # weight-shared kernel (bf16, K > 192, M >= 4096): one / two 64-channel chunks, channel groups, ragged M, K and N,
+               # and enough rows for two subtiles per wave
+               (4100, 24, 432), (5000, 80, 1440), (4097, 139, 203), (4200, 192, 3456), (140000, 40, 720), (70000, 96, 250)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
