@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   float* s_dy = smem;                        // [LH][RP]
   float* s_w = s_dy + g.LH * g.RP;           // [KK][CB]
   float* s_red = s_w + KK * CB;              // [CB][KK + 2]
+  float* s_cf = s_red + CB * (KK + 2);       // [3][CB] BN-backward coefficients of the slab (c1 = 1, c2 = c3 = 0 without them)
 
   const int tid = threadIdx.x;
   constexpr int C2 = CB / 2, CG = CB / 8;
@@ -317,6 +318,11 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     s_w[i] = (c_base + c < g.C) ? w[(long)t * ldw + c_base + c] : 0.f;
   }
   for (int i = tid; i < CB * (KK + 2); i += 256) s_red[i] = 0.f;
+  for (int i = tid; i < 3 * CB; i += 256) {
+    const int v = i / CB, c = c_base + i % CB;
+    const float* src = (v == 0) ? c1 : (v == 1 ? c2p : c3);
+    s_cf[i] = (c1 && src && c < cpad) ? src[c] : (v == 0 ? 1.f : 0.f);
+  }
 
   const int cg = tid % CG;
   const bool cg_ok = c_base + cg * 8 < cpad;
@@ -367,14 +373,10 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       if (p_iy[i] >= 0) {
         float v[8];
         const bool ok = (pfmask >> i) & 1u;
-        float q1[8], q2[8], q3[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { q1[e] = 1.f; q2[e] = 0.f; q3[e] = 0.f; }
-        if (c1 && cg_ok) {  // reloaded per tile (L1-resident): keeps 24 registers free during the FMA phase
-          VecIO<float, 8>::load(c1 + c_base + cg * 8, q1);
-          VecIO<float, 8>::load(c2p + c_base + cg * 8, q2);
-          VecIO<float, 8>::load(c3 + c_base + cg * 8, q3);
-        }
+        float q1[8], q2[8], q3[8];   // re-read from LDS per tile: keeps 24 registers free during the FMA phase
+        VecIO<float, 8>::load(s_cf + cg * 8, q1);
+        VecIO<float, 8>::load(s_cf + CB + cg * 8, q2);
+        VecIO<float, 8>::load(s_cf + 2 * CB + cg * 8, q3);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float a = q1[e] * pfg[i].get(e);
@@ -656,7 +658,7 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   g.LW = fdiv(g.TW - 1 + P, S) - fdiv(-P, S) + 1;
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
-  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2)) * sizeof(float);
+  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2) + 3 * (size_t)cb) * sizeof(float);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env2 = getenv("ATOMNAS_DW_BWD_PERCU") ? atoi(getenv("ATOMNAS_DW_BWD_PERCU")) : 0;
   const int cap = cap_env2 ? cap_env2 : 8;

@@ -95,6 +95,50 @@ __device__ __forceinline__ void load_pro(const Operand& o, long row, bool rowval
   }
 }
 
+// Same as load_pro for 8 bf16 channels, with the prologue coefficients read from LDS copies (lc1..lc3 point at the lane's first
+// channel; entries of channels >= K are zero, which also zeroes those channels).  Per-channel vectors fetched through the
+// vector-memory path in an inner loop cost more texture-address cycles than the activation stream itself.
+template <int MODE>
+__device__ __forceinline__ void load_pro_lds(const Operand& o, long row, bool rowvalid, int k, int K, const float* lc1, const float* lc2,
+                                             const float* lc3, float (&v)[8]) {
+  if (!rowvalid || k >= K) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    return;
+  }
+  VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(o.p1) + row * o.ld1 + k, v);
+  if constexpr (MODE == PRO_BNRELU) {
+    float s[8], h[8];
+    VecIO<float, 8>::load(lc1, s);
+    VecIO<float, 8>::load(lc2, h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = v[e] * s[e] + h[e];
+      v[e] = o.relu ? fmaxf(a, 0.f) : a;
+    }
+  } else if constexpr (MODE == PRO_BNBWD) {
+    float x[8], a1[8], a2[8], a3[8];
+    VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(o.p2) + row * o.ld2 + k, x);
+    VecIO<float, 8>::load(lc1, a1);
+    VecIO<float, 8>::load(lc2, a2);
+    VecIO<float, 8>::load(lc3, a3);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a1[e] * v[e] + a2[e] * x[e] + a3[e];
+  }
+}
+
+// copies the coefficient vectors of columns col0 .. col0+n-1 into LDS as [3][n] (zeros for columns >= ncols)
+template <int MODE>
+__device__ __forceinline__ void stage_coeffs(const Operand& o, int col0, int n, int ncols, float* dst, int tid) {
+  if constexpr (MODE != PRO_NONE) {
+    for (int i = tid; i < 3 * n; i += 256) {
+      const int v = i / n, c = col0 + i % n;
+      const float* src = (v == 0) ? o.c1 : (v == 1 ? o.c2 : o.c3);
+      dst[i] = (c < ncols && src != nullptr && (MODE == PRO_BNBWD || v < 2)) ? src[c] : 0.f;
+    }
+  }
+}
+
 struct Epilogue {
   void* c; int ldc; int out_f32;       // output [M, N] (storage T, or fp32 when out_f32)
   const void* add; int ldadd;          // optional residual stream (storage T)
@@ -716,6 +760,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_v = reinterpret_cast<T*>(smem_raw);          // [64][TN2_RP]
   T* s_u = s_v + 64 * TN2_RP;                       // [16*UTT][TN2_RP]
+  float* s_cv = reinterpret_cast<float*>(s_u + 16 * UTT * TN2_RP);   // [3][64]      prologue coefficients of the V tile
+  float* s_cu = s_cv + 3 * 64;                                       // [3][16*UTT]  ... of the U tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -746,6 +792,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
 #pragma unroll
   for (int t = 0; t < UTT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  stage_coeffs<VMODE>(V, v0, 64, NV, s_cv, tid);
+  stage_coeffs<UMODE>(U, u0, 16 * UTT, NU, s_cu, tid);
+  __syncthreads();
+
   const int ugroups = ut * 2;   // 8-channel groups per row
   for (long r0 = r_beg; r0 < r_end; r0 += TN2_ROWS) {
     // stage: a work unit is (row pair, 8-channel group), channel groups fastest across lanes (whole 128-byte row segments per
@@ -759,8 +809,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
 #endif
       float a[8], b[8];
-      load_pro<T, VMODE>(V, r0 + 2 * rp, (r0 + 2 * rp) < r_end, v0 + cg * 8, NV, a);
-      load_pro<T, VMODE>(V, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, v0 + cg * 8, NV, b);
+      const float* lc = s_cv + cg * 8;
+      load_pro_lds<VMODE>(V, r0 + 2 * rp, (r0 + 2 * rp) < r_end, v0 + cg * 8, NV, lc, lc + 64, lc + 128, a);
+      load_pro_lds<VMODE>(V, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, v0 + cg * 8, NV, lc, lc + 64, lc + 128, b);
       const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -778,8 +829,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
 #endif
       float a[8], b[8];
-      load_pro<T, UMODE>(U, r0 + 2 * rp, (r0 + 2 * rp) < r_end, u0 + cg * 8, NU, a);
-      load_pro<T, UMODE>(U, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, u0 + cg * 8, NU, b);
+      const float* lc = s_cu + cg * 8;
+      load_pro_lds<UMODE>(U, r0 + 2 * rp, (r0 + 2 * rp) < r_end, u0 + cg * 8, NU, lc, lc + 16 * UTT, lc + 32 * UTT, a);
+      load_pro_lds<UMODE>(U, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, u0 + cg * 8, NU, lc, lc + 16 * UTT, lc + 32 * UTT, b);
       const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -917,7 +969,7 @@ template <int UTT>
 static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
                          hipStream_t st) {
   const int vt = (NV + 63) / 64, uz = (NU + 16 * UTT - 1) / (16 * UTT);
-  const size_t lds = (size_t)(64 + 16 * UTT) * TN2_RP * sizeof(bf16_t);
+  const size_t lds = (size_t)(64 + 16 * UTT) * TN2_RP * sizeof(bf16_t) + (size_t)3 * (64 + 16 * UTT) * sizeof(float);
   // row chunks so that the grid is one round of resident workgroups (at least two slabs per workgroup)
   static const int xcd_env = getenv("ATOMNAS_TN_XCD") ? atoi(getenv("ATOMNAS_TN_XCD")) : 1;
 #define TN2_CASE(UM, VM)                                                                                                      \
