@@ -20,7 +20,7 @@
 #include <unordered_map>
 #include <cstdlib>
 #ifndef DW_EXP
-#define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute
+#define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute, 6 no h stores, 7 no x loads, 8 no dY loads, 9 no yraw loads
 #endif
 
 #ifndef DW_TIMING
@@ -51,11 +51,18 @@ constexpr __host__ __device__ int pmod(int a, int b) { return ((a % b) + b) % b;
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
   bf16x8 v;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
   __device__ __forceinline__ float get(int e) const { return (float)v[e]; }
 };
 template <> struct Raw8<float> {
   f32x4 a, b;
+  __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
   __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
   __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e] : b[e - 4]; }
 };
@@ -304,6 +311,8 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   float* s_w = s_dy + g.LH * g.RP;           // [KK][CB]
   float* s_red = s_w + KK * CB;              // [CB][KK + 2]
   float* s_cf = s_red + CB * (KK + 2);       // [3][CB] BN-backward coefficients of the slab (c1 = 1, c2 = c3 = 0 without them)
+  T* s_x = reinterpret_cast<T*>(s_cf + 3 * CB);   // [TH*TW][CB] raw input pixels of the tile (staged with 16-byte loads)
+  T* s_h = s_x + 14 * 14 * CB;                    // [TH*TW][CB] the tile's input gradient, written out with 16-byte stores
 
   const int tid = threadIdx.x;
   constexpr int C2 = CB / 2, CG = CB / 8;
@@ -359,10 +368,10 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int ho = hob + p_iy[i], wo = wob + p_ix[i];
-      if (cg_ok && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
+      if (DW_EXP != 8 && cg_ok && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
         const long off = (long)ho * g.Wo + wo;
         pfg[i].load(gn + off * ldg);
-        if (yn) pfy[i].load(yn + off * ldyr);
+        if (yn && DW_EXP != 9) pfy[i].load(yn + off * ldyr);
         pfmask |= 1u << i;
       }
     }
@@ -398,24 +407,45 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     it_r[q] = it < nitems ? rs / nstrips : -1;
     it_j[q] = rs % nstrips;
   }
-  // The strip's raw input pixels stay in registers from the weight-gradient operand to the ReLU mask / statistics of the
-  // epilogue.  (Measured: re-reading them in the epilogue cost 7k of 27k cycles per tile, loading them behind the next
-  // tile's prefetch another 8k; prefetching them a whole tile ahead as well gained nothing further and spills for k = 7.)
-  Raw2<T> xq[NIT][SW];
-  auto load_x = [&](int an, int aty, int atx) {
+  // The tile's input pixels x and its result h move between HBM and LDS in 16-byte pieces (pixel, 8 channels); the work
+  // items read / write their channel pairs in LDS.  Measured (cold caches, 56x56x144, k = 3): with 4-byte-per-lane global
+  // accesses the x loads alone cost 31 % of the kernel (65 % for stride 2) and the h stores 14 %.  The strip's raw pixels
+  // stay in registers from the weight-gradient operand to the ReLU mask / statistics of the epilogue.
+  constexpr int XP = (14 * 14 * CG + 255) / 256;
+  int xp_r[XP], xp_c[XP];
 #pragma unroll
-    for (int q = 0; q < NIT; ++q) {
-      const int r = it_r[q];
-      const int hi = aty * g.TH + r, wis = atx * g.TW + it_j[q] * SW;
-      const bool rowok = r >= 0 && hi < g.H && ch_ok;
-      const T* xrow = x + (((long)an * g.H + hi) * g.W) * ldx + ch;
+  for (int p = 0; p < XP; ++p) {
+    const int pix = (tid + 256 * p) / CG;
+    xp_r[p] = pix < g.TH * g.TW ? pix / g.TW : -100000;
+    xp_c[p] = pix % g.TW;
+  }
+  Raw8<T> xr[XP];
+  auto issue_x = [&](int an, int aty, int atx) {
 #pragma unroll
-      for (int t = 0; t < SW; ++t) {
-        xq[q][t].zero();
-        if (rowok && wis + t < g.W) xq[q][t].load(xrow + (long)(wis + t) * ldx);
+    for (int p = 0; p < XP; ++p) {
+      const int hi = aty * g.TH + xp_r[p], wi = atx * g.TW + xp_c[p];
+      xr[p].zero();
+      if (DW_EXP != 7 && cg_ok && hi >= 0 && hi < g.H && wi < g.W)
+        xr[p].load(x + (((long)an * g.H + hi) * g.W + wi) * ldx + c_base + cg * 8);
+    }
+  };
+  auto commit_x = [&]() {
+#pragma unroll
+    for (int p = 0; p < XP; ++p)
+      if (xp_r[p] >= 0) xr[p].store(s_x + (xp_r[p] * g.TW + xp_c[p]) * CB + cg * 8);
+  };
+  auto store_h = [&](int an, int aty, int atx) {
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int hi = aty * g.TH + xp_r[p], wi = atx * g.TW + xp_c[p];
+      if (DW_EXP != 6 && cg_ok && hi >= 0 && hi < g.H && wi < g.W) {
+        Raw8<T> v;
+        v.load(s_h + (xp_r[p] * g.TW + xp_c[p]) * CB + cg * 8);
+        v.store(h + (((long)an * g.H + hi) * g.W + wi) * ldh + c_base + cg * 8);
       }
     }
   };
+  Raw2<T> xq[NIT][SW];
 #if DW_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_readcyclecounter();
@@ -428,21 +458,28 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     if (++atx == g.tiles_x) { atx = 0; if (++aty == g.tiles_y) { aty = 0; ++an; } }
   };
   int ntx = tx, nty = ty, nn = n;
-  if (tile < t_end) issue(n, ty, tx);
+#ifndef DW_XPRE
+#define DW_XPRE 1
+#endif
+  constexpr bool XPRE = DW_XPRE && (K < 7);   // x joins the one-tile-ahead prefetch where the registers allow it
+  if (tile < t_end) { issue(n, ty, tx); if (XPRE) issue_x(n, ty, tx); }
+  int hn = -1, hty = 0, htx = 0;   // tile whose result is waiting in s_h
   for (; tile < t_end; ++tile) {
     const int hi0 = ty * g.TH, wi0 = tx * g.TW;                 // multiples of S (TH, TW even when S == 2)
     const int hob = cdiv(hi0 + P - (K - 1), S);                 // first output row held in LDS
     TMARK(6)
-    __syncthreads();
+    if (!XPRE) issue_x(n, ty, tx);
+    __syncthreads();   // previous tile fully consumed, its result complete in s_h
     TMARK(0)
+    if (hn >= 0) store_h(hn, hty, htx);
     commit();
+    commit_x();
     TMARK(1)
     __syncthreads();
     TMARK(2)
     ntx = tx; nty = ty; nn = n;
     advance(nn, nty, ntx);
-    load_x(n, ty, tx);   // needed first: ahead of the next tile's prefetch in the (in-order) memory queue
-    if (tile + 1 < t_end) issue(nn, nty, ntx);
+    if (tile + 1 < t_end) { issue(nn, nty, ntx); if (XPRE) issue_x(nn, nty, ntx); }
     TMARK(3)
 
 #pragma unroll
@@ -453,6 +490,9 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       const int wis = wi0 + j * SW;  // first input column of this strip (multiple of S)
       // this strip's activated input pixels (for the weight gradient)
       f32x2 xa[SW];
+      const int pix0 = r * g.TW + j * SW;   // first pixel of the strip inside the tile
+#pragma unroll
+      for (int t = 0; t < SW; ++t) xq[q][t].load(s_x + (pix0 + t) * CB + 2 * cc2);
 #pragma unroll
       for (int t = 0; t < SW; ++t) {
         const int wi = wis + t;
@@ -493,8 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       }
 
       TMARK(4)
-      // epilogue: ReLU mask of the producer, rounding, statistics
-      T* hr = h + (((long)n * g.H + hi) * g.W) * ldh + ch;
+      // epilogue: ReLU mask of the producer, rounding, statistics; the result goes to LDS and leaves with the next tile
 #pragma unroll
       for (int t = 0; t < SW; ++t) {
         const int wi = wis + t;
@@ -510,13 +549,16 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
             s0[c] += v;
             s1[c] += v * xv[c];
           }
-          VecIO<T, 2>::store(hr + (long)wi * ldh, o);
+          VecIO<T, 2>::store(s_h + (pix0 + t) * CB + 2 * cc2, o);
         }
       }
       TMARK(5)
     }
+    hn = n; hty = ty; htx = tx;
     tx = ntx; ty = nty; n = nn;
   }
+  __syncthreads();
+  if (hn >= 0) store_h(hn, hty, htx);
 #if DW_TIMING
   if ((tid & 63) == 0) {
 #pragma unroll
@@ -658,7 +700,8 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   g.LW = fdiv(g.TW - 1 + P, S) - fdiv(-P, S) + 1;
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
-  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2) + 3 * (size_t)cb) * sizeof(float);
+  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2) + 3 * (size_t)cb) * sizeof(float) +
+                     (size_t)2 * 14 * 14 * cb * sizeof(T);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env2 = getenv("ATOMNAS_DW_BWD_PERCU") ? atoi(getenv("ATOMNAS_DW_BWD_PERCU")) : 0;
   const int cap = cap_env2 ? cap_env2 : 8;

@@ -32,23 +32,35 @@ CASES = [(112, 32, 3, 1), (112, 96, 3, 2), (112, 96, 7, 2), (56, 144, 3, 1), (56
          (14, 480, 7, 1), (14, 576, 5, 1), (7, 1152, 5, 1), (7, 1152, 7, 1)]
 print(os.path.basename(libpath), "N", N)
 totf = totb = 0.0
+NSET = int(os.environ.get("DWBENCH_SETS", "3"))   # rotate over several tensor sets: the 256 MiB Infinity Cache must not serve re-runs
 for (H, C, k, s) in CASES:
     Ho = (H - 1) // s + 1
-    x = torch.randn(N * H * H, C, device="cuda").bfloat16()
-    y = torch.zeros(N * Ho * Ho, C, device="cuda", dtype=torch.bfloat16)
-    g = torch.randn(N * Ho * Ho, C, device="cuda").bfloat16()
-    h = torch.zeros(N * H * H, C, device="cuda", dtype=torch.bfloat16)
+    sets = []
+    for i in range(NSET):
+        x = torch.randn(N * H * H, C, device="cuda").bfloat16()
+        y = torch.randn(N * Ho * Ho, C, device="cuda").bfloat16()
+        g = torch.randn(N * Ho * Ho, C, device="cuda").bfloat16()
+        h = torch.zeros(N * H * H, C, device="cuda", dtype=torch.bfloat16)
+        sets.append((x, y, g, h))
     w = torch.randn(k * k, C, device="cuda")
     sc = torch.rand(C, device="cuda") + 0.5; sh = torch.randn(C, device="cuda")
     c1, c2, c3 = torch.rand(C, device="cuda"), torch.randn(C, device="cuda") * 0.1, torch.randn(C, device="cuda") * 0.1
     st = torch.zeros(ops.STAT_ROWS * 2 * C, device="cuda"); dw = torch.zeros(C * k * k, device="cuda")
     line = "H%-3d C%-4d k%d s%d:" % (H, C, k, s)
+    cnt = [0]
+    def fwd():
+        x, y, g, h = sets[cnt[0] % NSET]; cnt[0] += 1
+        ops.dwconv_fwd(x, sc, sh, True, w, y, st, C, N, H, H, C, k, s)
+    def bwd():
+        x, y, g, h = sets[cnt[0] % NSET]; cnt[0] += 1
+        ops.dwconv_bwd(g, y, c1, c2, c3, x, sc, sh, True, w, h, dw, st, C, N, H, H, C, k, s)
+    x, y, g, h = sets[0]
     if which in ("fwd", "both"):
-        tf = bench(lambda: ops.dwconv_fwd(x, sc, sh, True, w, y, st, C, N, H, H, C, k, s))
+        tf = bench(fwd)
         bf = (x.numel() + y.numel()) * 2; totf += tf
         line += "  fwd %.3f ms %5.0f GB/s" % (tf, bf / tf / 1e6)
     if which in ("bwd", "both"):
-        tb = bench(lambda: ops.dwconv_bwd(g, y, c1, c2, c3, x, sc, sh, True, w, h, dw, st, C, N, H, H, C, k, s))
+        tb = bench(bwd)
         bb = (2 * x.numel() + y.numel()) * 2; totb += tb
         line += "  bwd %.3f ms %5.0f GB/s" % (tb, bb / tb / 1e6)
         if timing:
@@ -57,5 +69,5 @@ for (H, C, k, s) in CASES:
             tiles = max(1, out[7])  # summed over waves
             line += "  | cyc/tile/wave " + " ".join("%s %d" % (PH[i], out[i] // tiles) for i in range(7))
     print(line, flush=True)
-    del x, y, g, h
+    del sets, x, y, g, h
 print("sum fwd %.3f ms  bwd %.3f ms" % (totf, totb))

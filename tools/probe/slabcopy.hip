@@ -31,12 +31,14 @@ __global__ __launch_bounds__(256) void k_slabcopy(const unsigned short* __restri
     for (int u = 0; u < UNROLL; ++u) {
       const long rr = r + (long)u * RPB;
       v[u] = u32x4{0, 0, 0, 0};
-      if (rr < r_end) v[u] = *reinterpret_cast<const u32x4*>(x + rr * ld + coff);
+      if (rr < r_end && do_write != 3) v[u] = *reinterpret_cast<const u32x4*>(x + rr * ld + coff);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const long rr = r + (long)u * RPB;
-      if (do_write) { if (rr < r_end) *reinterpret_cast<u32x4*>(y + rr * ld + coff) = v[u]; }
+      if (do_write == 1) { if (rr < r_end) *reinterpret_cast<u32x4*>(y + rr * ld + coff) = v[u]; }
+      else if (do_write == 2) { if (rr < r_end) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(y + rr * ld + coff)); }
+      else if (do_write == 3) { if (rr < r_end) { u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + rr * ld + coff)); __builtin_nontemporal_store(t + v[u], reinterpret_cast<u32x4*>(y + rr * ld + coff)); } }
       else acc += v[u];
     }
   }
@@ -54,11 +56,11 @@ int main() {
   hipMemset(x, 1, bytes * NBUF); hipMemset(y, 0, bytes * NBUF);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   printf("M=%ld C=%d  (%.0f MB per tensor)\n", M, C, bytes / 1e6);
-  for (int do_write = 1; do_write >= 0; --do_write)
-  for (int xcd = 1; xcd >= 0; --xcd)
-  for (int CB : {16, 48, 144})
+  for (int do_write : {1, 2, 3, 0})
+  for (int xcd = 1; xcd >= 1; --xcd)
+  for (int CB : {16, 144})
   for (int percu : {4, 8})
-  for (int unroll : {1, 4}) {
+  for (int unroll : {4}) {
     if (CB == 48 && 256 % (CB / 8)) continue;
     if (256 % (CB / 8)) { /* CG must divide 256: 144/8=18 does not -> use 128-thread rows */ }
     int cb = CB; if (cb == 144) cb = 128;  // 128 channels = two full lines (tail 16 channels ignored)
@@ -79,7 +81,8 @@ int main() {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= IT;
     const double moved = (double)M * cb * nslabs * 2 * (do_write ? 2 : 1);
-    printf("%s xcd=%d CB=%3d nslabs=%d percu=%d unroll=%d : %.3f ms  %.0f GB/s\n", do_write ? "copy" : "read", xcd, cb, nslabs, percu, unroll,
+    const char* names[] = {"read", "copy", "copy-nt-store", "copy-nt-both"};
+    printf("%s xcd=%d CB=%3d nslabs=%d percu=%d unroll=%d : %.3f ms  %.0f GB/s\n", names[do_write], xcd, cb, nslabs, percu, unroll,
            ms, moved / ms / 1e6);
   }
   return 0;
