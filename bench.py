@@ -99,6 +99,20 @@ def kernel_profile(ts, itemsize):
     return agg
 
 
+def pmc_traffic(entry):
+    """HBM bytes per launch of `entry` from the committed PMC pass of this same command (tools/pmc_bench.sh ->
+    tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json; counters need their own rocprofv3 run).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return int(d["kernels"][entry]["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(model_name, seconds_budget=20.0):
     """The oracle's full training step on the host cores, bs 16, same synthetic data recipe."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -202,8 +216,12 @@ def main():
         tot = sum(a["ms"] for a in agg.values())
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["bytes"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dom_name)
         out["roofline"] = dict(kernel=dom_name, bound="hbm", achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
-                               frac=round(ach / HBM_PEAK, 4), traffic=None, launches_per_step=dom["launches"],
+                               frac=round(ach / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_src,
+                               launches_per_step=dom["launches"],
+                               algorithmic_bytes_per_launch=int(dom["bytes"] / max(dom["launches"], 1)),
+                               avg_launch_us=round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
                                algorithmic_bytes_per_step=dom["bytes"], kernel_ms_per_step=round(dom["ms"], 3),
                                share_of_step=round(dom["ms"] / tot, 3))
         out["kernels"] = {k[8:]: dict(n=a["launches"], ms=round(a["ms"], 3), GBps=(round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["bytes"] else None))
