@@ -20,7 +20,7 @@
 #include <unordered_map>
 #include <cstdlib>
 #ifndef DW_EXP
-#define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute, 6 no h stores, 7 no x loads, 8 no dY loads, 9 no yraw loads
+#define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute, 6 no h stores, 7 no x loads, 8 no dY loads, 9 no yraw loads, 10 no FMA loop, 11 no global memory traffic
 #endif
 
 #ifndef DW_TIMING
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int ho = hob + p_iy[i], wo = wob + p_ix[i];
-      if (DW_EXP != 8 && cg_ok && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
+      if (DW_EXP != 8 && DW_EXP != 11 && cg_ok && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
         const long off = (long)ho * g.Wo + wo;
         pfg[i].load(gn + off * ldg);
         if (yn && DW_EXP != 9) pfy[i].load(yn + off * ldyr);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     for (int p = 0; p < XP; ++p) {
       const int hi = aty * g.TH + xp_r[p], wi = atx * g.TW + xp_c[p];
       xr[p].zero();
-      if (DW_EXP != 7 && cg_ok && hi >= 0 && hi < g.H && wi < g.W)
+      if (DW_EXP != 7 && DW_EXP != 11 && cg_ok && hi >= 0 && hi < g.H && wi < g.W)
         xr[p].load(x + (((long)an * g.H + hi) * g.W + wi) * ldx + c_base + cg * 8);
     }
   };
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       const int hi = aty * g.TH + xp_r[p], wi = atx * g.TW + xp_c[p];
-      if (DW_EXP != 6 && cg_ok && hi >= 0 && hi < g.H && wi < g.W) {
+      if (DW_EXP != 6 && DW_EXP != 11 && cg_ok && hi >= 0 && hi < g.H && wi < g.W) {
         Raw8<T> v;
         v.load(s_h + (xp_r[p] * g.TW + xp_c[p]) * CB + cg * 8);
         v.store(h + (((long)an * g.H + hi) * g.W + wi) * ldh + c_base + cg * 8);
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       for (int t = 0; t < SW; ++t) dx[t] = f32x2{0.f, 0.f};
 
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
+      for (int ky = 0; ky < (DW_EXP == 10 ? 0 : K); ++ky) {
         const int numr = hi + P - ky;
         if (S > 1 && pmod(numr, S) != 0) continue;
         const int ho = fdiv(numr, S);
@@ -618,6 +618,8 @@ static int slab_width(int preferred, int cpad) {
 }
 
 // Tile configuration.  rows/cols: extent of the tiled space (output pixels forward, input pixels backward).
+// (Measured and dropped: 7 x 28 tiles walked column-major, which keep the vertical halo in L2 and cut the HBM-side re-fetch,
+// run exactly as fast -- the kernels are bound by the number of L1/L2-side requests, halo included, not by HBM-side bytes.)
 static void pick_tiles(DwGeom& g, int rows, int cols, int sw, int cb, int even) {
   g.CB = cb;
   g.TH = rows < 14 ? rows : 14;
