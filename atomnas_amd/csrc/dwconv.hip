@@ -23,6 +23,10 @@
 #define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute, 6 no h stores, 7 no x loads, 8 no dY loads, 9 no yraw loads, 10 no FMA loop, 11 no global memory traffic
 #endif
 
+#ifndef DW_RING
+#define DW_RING 1  // 1 = tiles are walked column-major and the LDS operand tile is a ring over rows: a tile below the previous one
+                   // loads only its new rows (the (K-1)/S halo rows stay); 0 = every tile loads its whole haloed window
+#endif
 #ifndef DW_TIMING
 #define DW_TIMING 0  // s_memtime phase accounting (tools/dwbench.py, experiment builds only)
 #endif
@@ -160,23 +164,24 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   // software pipeline: the next tile's HBM loads are issued before the current tile is computed and land in registers
   Raw8<T> pf[PF];
   unsigned pfmask = 0;
-  auto issue = [&](int n, int ty, int tx) {
+  // rowmin: first tile row that has to be (re)loaded; rows below it are still in the LDS ring from the tile above
+  auto issue = [&](int n, int ty, int tx, int rowmin) {
     const int hi0 = ty * g.TH * S - P, wi0 = tx * g.TW * S - P;
     const T* xn = x + (long)n * g.H * g.W * ldx + c_base + cg * 8;
     pfmask = 0;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int hi = hi0 + p_iy[i], wi = wi0 + p_ix[i];
-      if (cg_ok && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
+      if (cg_ok && p_iy[i] >= rowmin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
         pf[i].load(xn + ((long)hi * g.W + wi) * ldx);
         pfmask |= 1u << i;
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int rowmin, int base) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      if (p_iy[i] >= 0) {
+      if (p_iy[i] >= rowmin) {
         float v[8];
         const bool ok = (pfmask >> i) & 1u;
 #pragma unroll
@@ -185,7 +190,9 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
           a = in_relu ? fmaxf(a, 0.f) : a;
           v[e] = ok ? a : 0.f;
         }
-        float* d = s_in + p_iy[i] * g.RP + p_ix[i] * CB + cg * 8;
+        int slot = p_iy[i] + base;
+        if (slot >= g.LH) slot -= g.LH;
+        float* d = s_in + slot * g.RP + p_ix[i] * CB + cg * 8;
         *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
       }
@@ -202,24 +209,36 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
     it_j[q] = rs % nstrips;
   }
 
-  // tile walk: every worker owns a CONTIGUOUS range of tiles (raster order inside an image), so the halo rows / columns it
-  // shares with its previous tiles are still in its XCD's L2; (n, ty, tx) are carried, not re-derived
+  // tile walk: every worker owns a CONTIGUOUS range of tiles, column-major inside an image (ty fastest); (n, ty, tx) are
+  // carried, not re-derived.  The LDS tile is a ring over rows: when the next tile is the one BELOW the current one, its
+  // first LH - TH*S rows are the current tile's last rows and stay where they are (slot of tile row r = (r + base) mod LH);
+  // only the new rows are loaded.  That removes the vertical halo from the request stream: the kernels are bound by the
+  // number of L1/L2-side requests, not by HBM-side bytes.
   const int t_beg = (int)((long)worker * ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * ntiles / g.nworkers);
   int tile = t_beg;
-  int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
+  int ty = tile % g.tiles_y, tx = (tile / g.tiles_y) % g.tiles_x, n = tile / (g.tiles_x * g.tiles_y);
   auto advance = [&](int& an, int& aty, int& atx) {
-    if (++atx == g.tiles_x) { atx = 0; if (++aty == g.tiles_y) { aty = 0; ++an; } }
+    if (++aty == g.tiles_y) { aty = 0; if (++atx == g.tiles_x) { atx = 0; ++an; } }
   };
+  const int vshift = g.TH * S;                                       // rows the window moves down per tile
+  const int keep = (DW_RING && vshift < g.LH) ? g.LH - vshift : 0;   // rows shared with the tile above
   int ntx = tx, nty = ty, nn = n;
-  if (tile < t_end) issue(n, ty, tx);
+  int rowmin = 0, base = 0, nrowmin = 0, nbase = 0;
+  if (tile < t_end) issue(n, ty, tx, 0);
   for (; tile < t_end; ++tile) {
     const int ho0 = ty * g.TH, wo0 = tx * g.TW;
     __syncthreads();  // previous tile fully consumed (also orders the s_w / s_st initialisation)
-    if (DW_EXP != 3) commit();
+    if (DW_EXP != 3) commit(rowmin, base);
     __syncthreads();
     ntx = tx; nty = ty; nn = n;
     advance(nn, nty, ntx);
-    if (tile + 1 < t_end) issue(nn, nty, ntx);
+    {
+      const bool below = keep > 0 && nn == n && ntx == tx && nty == ty + 1;
+      nrowmin = below ? keep : 0;
+      nbase = below ? base + vshift : 0;
+      if (nbase >= g.LH) nbase -= g.LH;
+    }
+    if (tile + 1 < t_end) issue(nn, nty, ntx, nrowmin);
 
 #pragma unroll
     for (int q = 0; q < (DW_EXP == 2 ? 0 : NIT); ++q) {
@@ -231,7 +250,9 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
       for (int t = 0; t < SW; ++t) acc[t] = f32x2{0.f, 0.f};
 #pragma unroll 1
       for (int ky = 0; ky < K; ++ky) {  // not unrolled: keeps one LDS row (IWS pairs) live instead of K of them
-        const float* row = s_in + (r * S + ky) * g.RP + (j * SW * S) * CB + 2 * c2;
+        int slot = r * S + ky + base;
+        if (slot >= g.LH) slot -= g.LH;
+        const float* row = s_in + slot * g.RP + (j * SW * S) * CB + 2 * c2;
         f32x2 in[IWS];
 #pragma unroll
         for (int i = 0; i < IWS; ++i) in[i] = *reinterpret_cast<const f32x2*>(row + i * CB);
@@ -259,6 +280,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
       }
     }
     tx = ntx; ty = nty; n = nn;
+    rowmin = nrowmin; base = nbase;
   }
 
   if (stats) {
@@ -360,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   }
   Raw8<T> pfg[PF], pfy[PF];
   unsigned pfmask = 0;
-  auto issue = [&](int n, int ty, int tx) {
+  auto issue = [&](int n, int ty, int tx, int rowmin) {
     const int hob = cdiv(ty * g.TH + P - (K - 1), S), wob = (tx * g.TW) / S + RELMIN;
     const T* gn = gup + (long)n * g.Ho * g.Wo * ldg + c_base + cg * 8;
     const T* yn = yraw ? yraw + (long)n * g.Ho * g.Wo * ldyr + c_base + cg * 8 : nullptr;
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int ho = hob + p_iy[i], wo = wob + p_ix[i];
-      if (DW_EXP != 8 && DW_EXP != 11 && cg_ok && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
+      if (DW_EXP != 8 && DW_EXP != 11 && cg_ok && p_iy[i] >= rowmin && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
         const long off = (long)ho * g.Wo + wo;
         pfg[i].load(gn + off * ldg);
         if (yn && DW_EXP != 9) pfy[i].load(yn + off * ldyr);
@@ -376,10 +398,10 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int rowmin, int base) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      if (p_iy[i] >= 0) {
+      if (p_iy[i] >= rowmin) {
         float v[8];
         const bool ok = (pfmask >> i) & 1u;
         float q1[8], q2[8], q3[8];   // re-read from LDS per tile: keeps 24 registers free during the FMA phase
@@ -392,7 +414,9 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
           if (yraw) a += q2[e] * pfy[i].get(e) + q3[e];
           v[e] = ok ? a : 0.f;
         }
-        float* d = s_dy + p_iy[i] * g.RP + p_ix[i] * CB + cg * 8;
+        int slot = p_iy[i] + base;
+        if (slot >= g.LH) slot -= g.LH;
+        float* d = s_dy + slot * g.RP + p_ix[i] * CB + cg * 8;
         *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
       }
@@ -453,16 +477,18 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 
   const int t_beg = (int)((long)worker * ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * ntiles / g.nworkers);
   int tile = t_beg;   // contiguous tile range per worker (halo reuse in the XCD's L2), see k_dwconv_fwd
-  int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
+  int ty = tile % g.tiles_y, tx = (tile / g.tiles_y) % g.tiles_x, n = tile / (g.tiles_x * g.tiles_y);   // column-major, see k_dwconv_fwd
   auto advance = [&](int& an, int& aty, int& atx) {
-    if (++atx == g.tiles_x) { atx = 0; if (++aty == g.tiles_y) { aty = 0; ++an; } }
+    if (++aty == g.tiles_y) { aty = 0; if (++atx == g.tiles_x) { atx = 0; ++an; } }
   };
+  auto hob_of = [&](int aty) { return cdiv(aty * g.TH + P - (K - 1), S); };
   int ntx = tx, nty = ty, nn = n;
+  int rowmin = 0, base = 0, nrowmin = 0, nbase = 0;   // ring state of the dY tile, see k_dwconv_fwd
 #ifndef DW_XPRE
 #define DW_XPRE 1
 #endif
   constexpr bool XPRE = DW_XPRE && (K < 7);   // x joins the one-tile-ahead prefetch where the registers allow it
-  if (tile < t_end) { issue(n, ty, tx); if (XPRE) issue_x(n, ty, tx); }
+  if (tile < t_end) { issue(n, ty, tx, 0); if (XPRE) issue_x(n, ty, tx); }
   int hn = -1, hty = 0, htx = 0;   // tile whose result is waiting in s_h
   for (; tile < t_end; ++tile) {
     const int hi0 = ty * g.TH, wi0 = tx * g.TW;                 // multiples of S (TH, TW even when S == 2)
@@ -472,14 +498,21 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     __syncthreads();   // previous tile fully consumed, its result complete in s_h
     TMARK(0)
     if (hn >= 0) store_h(hn, hty, htx);
-    commit();
+    commit(rowmin, base);
     commit_x();
     TMARK(1)
     __syncthreads();
     TMARK(2)
     ntx = tx; nty = ty; nn = n;
     advance(nn, nty, ntx);
-    if (tile + 1 < t_end) { issue(nn, nty, ntx); if (XPRE) issue_x(nn, nty, ntx); }
+    {
+      const int vshift = hob_of(ty + 1) - hob;   // rows the dY window moves down to the tile below
+      const bool below = DW_RING && vshift < g.LH && nn == n && ntx == tx && nty == ty + 1;
+      nrowmin = below ? g.LH - vshift : 0;
+      nbase = below ? base + vshift : 0;
+      if (nbase >= g.LH) nbase -= g.LH;
+    }
+    if (tile + 1 < t_end) { issue(nn, nty, ntx, nrowmin); if (XPRE) issue_x(nn, nty, ntx); }
     TMARK(3)
 
 #pragma unroll
@@ -513,7 +546,9 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
         if (S > 1 && pmod(numr, S) != 0) continue;
         const int ho = fdiv(numr, S);
         if (ho < 0 || ho >= g.Ho) continue;   // rows outside the image hold zeros anyway; skip the work
-        const float* row = s_dy + (ho - hob) * g.RP + ((wis - wi0) / S) * CB + 2 * cc2;
+        int slot = ho - hob + base;
+        if (slot >= g.LH) slot -= g.LH;
+        const float* row = s_dy + slot * g.RP + ((wis - wi0) / S) * CB + 2 * cc2;
         f32x2 dy[DWN];
 #pragma unroll
         for (int i = 0; i < DWN; ++i) dy[i] = *reinterpret_cast<const f32x2*>(row + i * CB);
@@ -556,6 +591,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     }
     hn = n; hty = ty; htx = tx;
     tx = ntx; ty = nty; n = nn;
+    rowmin = nrowmin; base = nbase;
   }
   __syncthreads();
   if (hn >= 0) store_h(hn, hty, htx);

@@ -46,7 +46,7 @@ def assert_close(name, got, ref, rtol, atol, outlier_frac=0.0, rel_l2=None):
     ref = ref.double().cpu()
     err = (got - ref).abs()
     if rel_l2 is not None:
-        rl = float(err.norm() / max(float(ref.norm()), 1e-30))
+        rl = float(err.norm() / max(float(ref.norm()), float(atol) * ref.numel() ** 0.5, 1e-30))   # atol floors the scale
         if rl > rel_l2:
             raise AssertionError("%s: relative L2 error %.4g > %.4g" % (name, rl, rel_l2))
     bound = atol + rtol * ref.abs()

