@@ -80,15 +80,16 @@ def algorithmic_bytes(tag_name, tag, itemsize):
 def kernel_profile(ts, itemsize):
     """Eager pass of the same step with HIP events around every C-ABI launch (on the launch stream)."""
     from atomnas_amd import _lib
-    was = ts.use_graph
+    was, world = ts.use_graph, ts.world_size
     ts.use_graph = False
+    ts.world_size = 1   # rank 0 profiles alone: no collective in this pass (the other ranks wait at the barrier)
     ts.step(rho=1e-4)
     torch.cuda.synchronize()
     _lib.PROFILE = []
     ts.step(rho=1e-4)
     torch.cuda.synchronize()
     prof, _lib.PROFILE = _lib.PROFILE, None
-    ts.use_graph = was
+    ts.use_graph, ts.world_size = was, world
     agg = collections.OrderedDict()
     for name, tag, e0, e1 in prof:
         a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
@@ -159,6 +160,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (the measured path); gloo only to "
+                    "exercise the multi-rank code on a single-GPU box together with --same-device")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (validation of the multi-rank path only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,10 +170,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path runs in libatomnas_hip.so only (no CPU fallback)")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(0 if args.same_device else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")   # RCCL on ROCm
+        dist.init_process_group(args.backend)   # "nccl" is RCCL on ROCm
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model, ts, hp = build(args.model, dtype, args.batch, seed=1995)
     ts.use_graph = not args.no_graph
@@ -216,7 +220,8 @@ def main():
         tot = sum(a["ms"] for a in agg.values())
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["bytes"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(dom_name)
+        # the committed PMC pass was taken on the default workload (bf16, per-GPU batch 256): only valid for that
+        traffic, traffic_src = pmc_traffic(dom_name) if (args.batch == 256 and dtype == torch.bfloat16) else (None, None)
         out["roofline"] = dict(kernel=dom_name, bound="hbm", achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                                frac=round(ach / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_src,
                                launches_per_step=dom["launches"],

@@ -1,0 +1,91 @@
+"""Data-parallel training step on the GPU with a process group: two ranks share cuda:0 and reduce through gloo (the box
+has one GPU; RCCL refuses two ranks on one device).  What is checked is what the RCCL run relies on: the two captured graphs
+with the collective on the flat gradient arena between them, the 1/world scaling inside the optimizer graph, rank-identical
+parameters after the steps although every rank sees its own batch and keeps its own BatchNorm statistics."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from atomnas_amd import engine
+        from atomnas_amd.models import mobilenet_base as mb
+        from atomnas_amd.models import mobilenet_supernet as ms
+        from atomnas_amd.utils import model_profiling as mp_
+        from atomnas_amd.utils import optim as aopt
+        from atomnas_amd.utils import prune as aprune
+        from atomnas_amd.utils import rmsprop
+        torch.manual_seed(7)   # same initialisation on every rank (bench.py broadcasts rank 0's instead)
+        model = ms.Model(num_classes=10, input_size=64, input_channel=16, last_channel=64, dropout_ratio=0.0, batch_norm_momentum=0.01,
+                         batch_norm_epsilon=1e-3, active_fn="nn.ReLU",
+                         inverted_residual_setting=[[1, 8, 1, 1, [3]], [6, 16, 2, 2, [3, 5, 7]], [6, 24, 1, 2, [3, 5, 7]], [6, 32, 1, 2, [3, 5, 7]],
+                                                    [6, 40, 1, 2, [3, 5, 7]]])
+        model.apply(mb.init_weights_mnas)
+        mp_.model_profiling(model, 64, 64, verbose=False)
+        model.cuda().train()
+        pinfo = aprune.get_bn_to_prune(model, {'bn_prune_filter': 'expansion_only_skip_expand1'}, verbose=False)
+        opt = rmsprop.RMSprop(model.parameters(), lr=0.01, alpha=0.9, momentum=0.9, eps=1e-3, eps_inside_sqrt=True)
+        ema = aopt.ExponentialMovingAverage(0.99)
+        for n, p in model.named_parameters():
+            ema.register(n, p)
+        ts = engine.TrainStep(model, opt, ema, pinfo, batch_size=8, image_size=64, use_graph=True, world_size=world)
+        g = torch.Generator().manual_seed(100 + rank)   # every rank its own batch
+        ts.set_batch(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 10, (8,), generator=g).cuda())
+        p0 = ts.mgr.P.clone()
+        losses = []
+        for _ in range(3):
+            ts.step(lr=0.003, rho=1e-4)
+            losses.append(float(ts.loss[0]))
+        torch.cuda.synchronize()
+        assert all(l == l for l in losses)
+        assert float((ts.mgr.P - p0).abs().max()) > 0, "parameters did not move"
+        mine = ts.mgr.P.detach().cpu()
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        assert all(torch.equal(q, parts[0]) for q in parts), "ranks diverged: max diff %g" % float((parts[0] - parts[1]).abs().max())
+        lo = torch.tensor(losses)
+        both = [torch.zeros_like(lo) for _ in range(world)]
+        dist.all_gather(both, lo)
+        assert not torch.equal(both[0], both[1]), "ranks were supposed to see different batches"
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_graph_step(gpu_lib):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(out.keys()) == list(range(world))
