@@ -749,19 +749,36 @@ __global__ __launch_bounds__(256) void k_gemm_tn(Operand U, int NU, Operand V, i
 #ifndef TN2_KS_UNROLL
 #define TN2_KS_UNROLL 2
 #endif
-constexpr int TN2_ROWS = 128;
-constexpr int TN2_RP = TN2_ROWS + 8;   // transposed row pitch (elements): 16 consecutive columns land on 16 distinct 16-byte slots
+#ifndef TN_TIMING
+#define TN_TIMING 0   // s_memtime phase accounting of k_gemm_tn2 (tools/tnbench2.py, experiment builds only)
+#endif
+#if TN_TIMING
+__device__ unsigned long long g_tn_timing[8];
+#define TN_MARK(i)                                                     \
+  {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long tn_ = __builtin_readcyclecounter();       \
+    tacc[i] += tn_ - tlast;                                            \
+    tlast = tn_;                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  }
+#else
+#define TN_MARK(i)
+#endif
 
-template <int UMODE, int VMODE, int UTT>
+template <int UMODE, int VMODE, int UTT, int VTT, int ROWS>
 __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj, long M,
                                                   long rows_per_block, int nchunks, int vt, int uz, int xcd_aware) {
   using T = bf16_t;
   using MM = Mma<T>;
+  constexpr int VW = 64 * VTT;      // V columns per workgroup: each wave owns VTT tiles of 16 (the U tile is re-read per V tile:
+                                    // wider V tiles halve that traffic where U is not narrow)
+  constexpr int RP = ROWS + 8;      // transposed row pitch (elements): 16 consecutive columns land on 16 distinct 16-byte slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* s_v = reinterpret_cast<T*>(smem_raw);          // [64][TN2_RP]
-  T* s_u = s_v + 64 * TN2_RP;                       // [16*UTT][TN2_RP]
-  float* s_cv = reinterpret_cast<float*>(s_u + 16 * UTT * TN2_RP);   // [3][64]      prologue coefficients of the V tile
-  float* s_cu = s_cv + 3 * 64;                                       // [3][16*UTT]  ... of the U tile
+  T* s_v = reinterpret_cast<T*>(smem_raw);          // [VW][RP]
+  T* s_u = s_v + VW * RP;                           // [16*UTT][RP]
+  float* s_cv = reinterpret_cast<float*>(s_u + 16 * UTT * RP);       // [3][VW]      prologue coefficients of the V tile
+  float* s_cu = s_cv + 3 * VW;                                       // [3][16*UTT]  ... of the U tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -784,49 +801,57 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
   const int u0 = (tile / vt) * (16 * UTT);
   const int nu = min(NU - u0, 16 * UTT);
   const int ut = (nu + 15) / 16;
-  const int v0 = (tile % vt) * 64;
+  const int v0 = (tile % vt) * VW;
   const long r_beg = chunk * rows_per_block;
   const long r_end = min(M, r_beg + rows_per_block);
 
-  f32x4 acc[UTT];
+  f32x4 acc[VTT][UTT];
 #pragma unroll
-  for (int t = 0; t < UTT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int v = 0; v < VTT; ++v)
+#pragma unroll
+    for (int t = 0; t < UTT; ++t) acc[v][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_coeffs<VMODE>(V, v0, 64, NV, s_cv, tid);
+  stage_coeffs<VMODE>(V, v0, VW, NV, s_cv, tid);
   stage_coeffs<UMODE>(U, u0, 16 * UTT, NU, s_cu, tid);
   __syncthreads();
 
   const int ugroups = ut * 2;   // 8-channel groups per row
-  for (long r0 = r_beg; r0 < r_end; r0 += TN2_ROWS) {
+#if TN_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+  for (long r0 = r_beg; r0 < r_end; r0 += ROWS) {
+    TN_MARK(5)
     // stage: a work unit is (row pair, 8-channel group), channel groups fastest across lanes (whole 128-byte row segments per
     // load instruction); both rows are loaded, transformed, packed and stored transposed.  The element order is rotated
     // per channel group so that the 64 lanes of each ds_write_b32 hit 64 distinct banks (RP = 136: bank = 32*(cg&1) +
     // 4*e + rp; rotating e by 2*(cg>>1) spreads the four groups that would collide).
-    for (int idx = tid; idx < (TN2_ROWS / 2) * 8; idx += 256) {
+    for (int idx = tid; idx < (ROWS / 2) * (VW / 8); idx += 256) {
 #if TN2_COALESCED
-      const int cg = idx % 8, rp = idx / 8;
+      const int cg = idx % (VW / 8), rp = idx / (VW / 8);
 #else
-      const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
+      const int rp = idx % (ROWS / 2), cg = idx / (ROWS / 2);
 #endif
       float a[8], b[8];
       const float* lc = s_cv + cg * 8;
-      load_pro_lds<VMODE>(V, r0 + 2 * rp, (r0 + 2 * rp) < r_end, v0 + cg * 8, NV, lc, lc + 64, lc + 128, a);
-      load_pro_lds<VMODE>(V, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, v0 + cg * 8, NV, lc, lc + 64, lc + 128, b);
+      load_pro_lds<VMODE>(V, r0 + 2 * rp, (r0 + 2 * rp) < r_end, v0 + cg * 8, NV, lc, lc + VW, lc + 2 * VW, a);
+      load_pro_lds<VMODE>(V, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, v0 + cg * 8, NV, lc, lc + VW, lc + 2 * VW, b);
       const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int e = (i + rot) & 7;
         bf16x2 pk;
         pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
-        *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * TN2_RP + 2 * rp]) = pk;
+        *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * RP + 2 * rp]) = pk;
       }
     }
+    TN_MARK(0)
 #pragma unroll 2
-    for (int idx = tid; idx < (TN2_ROWS / 2) * ugroups; idx += 256) {
+    for (int idx = tid; idx < (ROWS / 2) * ugroups; idx += 256) {
 #if TN2_COALESCED
       const int cg = idx % ugroups, rp = idx / ugroups;
 #else
-      const int rp = idx % (TN2_ROWS / 2), cg = idx / (TN2_ROWS / 2);
+      const int rp = idx % (ROWS / 2), cg = idx / (ROWS / 2);
 #endif
       float a[8], b[8];
       const float* lc = s_cu + cg * 8;
@@ -838,33 +863,50 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
         const int e = (i + rot) & 7;
         bf16x2 pk;
         pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
-        *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * TN2_RP + 2 * rp]) = pk;
+        *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * RP + 2 * rp]) = pk;
       }
     }
+    TN_MARK(1)
     __syncthreads();
+    TN_MARK(2)
 #pragma unroll TN2_KS_UNROLL   // full unrolling hoists all fragment reads: 162 VGPRs for 6 accumulator tiles, 2 waves per SIMD
-    for (int ks = 0; ks < TN2_ROWS / 32; ++ks) {
-      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&s_v[(16 * wave + j) * TN2_RP + 32 * ks + 8 * q]);
+    for (int ks = 0; ks < ROWS / 32; ++ks) {
+      bf16x8 bf[VTT];
+#pragma unroll
+      for (int v = 0; v < VTT; ++v) bf[v] = *reinterpret_cast<const bf16x8*>(&s_v[(64 * v + 16 * wave + j) * RP + 32 * ks + 8 * q]);
 #pragma unroll
       for (int t = 0; t < UTT; ++t) {
         if (t < ut) {
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(&s_u[(16 * t + j) * TN2_RP + 32 * ks + 8 * q]);
-          acc[t] = MM::mma(af, bf, acc[t]);
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(&s_u[(16 * t + j) * RP + 32 * ks + 8 * q]);
+#pragma unroll
+          for (int v = 0; v < VTT; ++v) acc[v][t] = MM::mma(af, bf[v], acc[v][t]);
         }
       }
     }
+    TN_MARK(3)
     __syncthreads();
+    TN_MARK(4)
   }
+#if TN_TIMING
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_tn_timing[i], tacc[i]);
+    atomicAdd(&g_tn_timing[7], (unsigned long long)((r_end - r_beg + ROWS - 1) / ROWS));
+  }
+#endif
 
-  const int vc = v0 + 16 * wave + j;
-  if (vc < NV) {
 #pragma unroll
-    for (int t = 0; t < UTT; ++t) {
-      if (t < ut) {
+  for (int v = 0; v < VTT; ++v) {
+    const int vc = v0 + 64 * v + 16 * wave + j;
+    if (vc < NV) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int uc = u0 + 16 * t + 4 * q + r;
-          if (uc < NU) atomicAdd(&out[uc * si + vc * sj], acc[t][r]);
+      for (int t = 0; t < UTT; ++t) {
+        if (t < ut) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int uc = u0 + 16 * t + 4 * q + r;
+            if (uc < NU) atomicAdd(&out[uc * si + vc * sj], acc[v][t][r]);
+          }
         }
       }
     }
@@ -965,19 +1007,19 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
   return check_launch("gemm_nt");
 }
 
-template <int UTT>
-static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
-                         hipStream_t st) {
-  const int vt = (NV + 63) / 64, uz = (NU + 16 * UTT - 1) / (16 * UTT);
-  const size_t lds = (size_t)(64 + 16 * UTT) * TN2_RP * sizeof(bf16_t) + (size_t)3 * (64 + 16 * UTT) * sizeof(float);
+template <int UTT, int VTT, int ROWS>
+static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
+                          hipStream_t st) {
+  const int vt = (NV + 64 * VTT - 1) / (64 * VTT), uz = (NU + 16 * UTT - 1) / (16 * UTT);
+  const size_t lds = (size_t)(64 * VTT + 16 * UTT) * (ROWS + 8) * sizeof(bf16_t) + (size_t)3 * (64 * VTT + 16 * UTT) * sizeof(float);
   // row chunks so that the grid is one round of resident workgroups (at least two slabs per workgroup)
   static const int xcd_env = getenv("ATOMNAS_TN_XCD") ? atoi(getenv("ATOMNAS_TN_XCD")) : 1;
 #define TN2_CASE(UM, VM)                                                                                                      \
   {                                                                                                                           \
-    auto kern = k_gemm_tn2<UM, VM, UTT>;                                                                                      \
+    auto kern = k_gemm_tn2<UM, VM, UTT, VTT, ROWS>;                                                                           \
     const long resident = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                  \
     long chunks = resident / ((long)vt * uz);                                                                                 \
-    if (chunks > M / (2 * TN2_ROWS)) chunks = M / (2 * TN2_ROWS);                                                             \
+    if (chunks > M / (2 * ROWS)) chunks = M / (2 * ROWS);                                                                     \
     int xcd = xcd_env;                                                                                                        \
     if (chunks < 8) xcd = 0; /* fewer chunks than XCDs: plain order */                                                        \
     if (xcd) chunks = chunks / 8 * 8; /* equal work per XCD */                                                                \
@@ -997,6 +1039,19 @@ static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const O
   return check_launch("gemm_tn2");
 }
 
+// V tile width.  Staging U (re-read per V tile) costs 2-3x staging V in the late layers (-DTN_TIMING), but 128-column V tiles on
+// 64-row slabs (same LDS) measured 10-25 % SLOWER there (tools/tnbench2.py), so they stay an experiment (ATOMNAS_TN_WIDE=1);
+// what did help the 320-column case is two U tiles of 160 columns instead of one of 320 (fewer accumulator registers).
+template <int UTT>
+static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
+                         hipStream_t st) {
+  static const int wide_env = getenv("ATOMNAS_TN_WIDE") ? atoi(getenv("ATOMNAS_TN_WIDE")) : 0;
+  if constexpr (UTT >= 4 && UTT <= 12) {
+    if (wide_env && NV >= 256) return launch_tn2_cfg<UTT, 2, 64>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  }
+  return launch_tn2_cfg<UTT, 1, 128>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+}
+
 static int launch_tn2(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
                       hipStream_t st) {
   // accumulator tiles per wave (= U tiles of 16 columns): fewer tiles -> fewer AGPRs -> more waves per SIMD
@@ -1005,6 +1060,7 @@ static int launch_tn2(int umode, const Operand& U, int NU, int vmode, const Oper
   if (ut <= 4) return launch_tn2_ut<4>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
   if (ut <= 6) return launch_tn2_ut<6>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
   if (ut <= 12) return launch_tn2_ut<12>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  if (ut <= 20) return launch_tn2_ut<10>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);   // two U tiles of <= 160 columns
   return launch_tn2_ut<20>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
 }
 
@@ -1039,6 +1095,16 @@ static int check_operand(const char* who, const Operand& o, int mode, int C) {
 }
 
 }  // namespace atomnas
+
+#if TN_TIMING
+extern "C" int atomnas_debug_tn_timing(unsigned long long* out8, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(atomnas::g_tn_timing), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(atomnas::g_tn_timing), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 
 using namespace atomnas;
 
