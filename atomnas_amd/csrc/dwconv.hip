@@ -691,7 +691,14 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
   // 14x14 output tiles of 16 channels (several workgroups per CU); small maps take the whole image and 64 channels
   const int sw = 7;
   static const int cb_env = getenv("ATOMNAS_DW_FWD_CB") ? atoi(getenv("ATOMNAS_DW_FWD_CB")) : 0;
-  const int cb = slab_width((g.Wo <= 7 && g.Ho <= 7) ? 64 : (cb_env ? cb_env : 16), cpad);
+  // default 16; deviations measured in situ on the supernet's own shapes (bs 256 step, tools/bringup.py DETAIL=1 +
+  // tools/cmpdetail.py): 8-channel slabs for the stride-2 layers with few channels per pixel, 32 for 28x28x240 and C <= 32
+  int cb_rule = 16;
+  if (S == 2 && C <= 96) cb_rule = 8;
+  else if (S == 2 && K >= 5 && H <= 56) cb_rule = 8;
+  else if (S == 1 && C <= 32) cb_rule = 32;
+  else if (S == 1 && H == 28 && K <= 5) cb_rule = 32;
+  const int cb = slab_width((g.Wo <= 7 && g.Ho <= 7) ? 64 : (cb_env ? cb_env : cb_rule), cpad);
   pick_tiles(g, g.Ho, g.Wo, sw, cb, 0);
   ATOMNAS_REQUIRE(cb <= 32 || (g.TH <= 7 && g.TW <= 7), "dwconv_fwd: internal tile configuration error");
   g.LH = (g.TH - 1) * S + K;
@@ -731,7 +738,13 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   // measured (tools/dwbench.py): 32-channel slabs win for stride 2 and for 7x7 maps with k <= 5, 16-channel slabs elsewhere
   // (k = 7 with 32 channels spills its 98 weight-gradient accumulators)
   static const int cb_env = getenv("ATOMNAS_DW_BWD_CB") ? atoi(getenv("ATOMNAS_DW_BWD_CB")) : 0;
-  const int cb = slab_width(cb_env ? cb_env : ((S == 2 || (H <= 7 && W <= 7 && K <= 5)) ? 32 : 16), cpad);
+  // in-situ deviations (same sweep as the forward): 28x28 and 14x14 maps with k <= 5 prefer 32 (k = 3 at 14x14 does not),
+  // the 56x56 stride-2 layer prefers 16
+  int cb_rule = (S == 2 || (H <= 7 && W <= 7 && K <= 5)) ? 32 : 16;
+  if (S == 2 && H == 56) cb_rule = 16;
+  else if (S == 1 && H == 28 && K <= 5) cb_rule = 32;
+  else if (S == 1 && H == 14 && K == 5) cb_rule = 32;
+  const int cb = slab_width(cb_env ? cb_env : cb_rule, cpad);
   pick_tiles(g, H, W, SW, cb, S == 2);
   // output window of an input tile: rows ceil((hi0+P-K+1)/S) .. floor((hi0+TH-1+P)/S)
   g.LH = fdiv(g.TH - 1 + P, S) - cdiv(P - (K - 1), S) + 1;
