@@ -1,0 +1,23 @@
+"""`python train.py app:<yml>` end to end on the GPU (reference entry point train.py:310-330): two shortened epochs of the
+AtomNAS-C search -- graph-captured training steps, per-epoch validation of the EMA model with BN calibration, mask /
+pruned-MACs accounting, the final shrink, checkpoint + exported architecture."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_entry_runs_two_epochs(gpu_lib, tmp_path):
+    env = dict(os.environ, ATOMNAS_E2E_DIR=str(tmp_path), ARNOLD_OUTPUT=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "app:" + os.path.join(ROOT, "tests", "data", "tiny_search.yml")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert out.count(" val: ") >= 2, out[-4000:]
+    assert "Prune threshold" in out
+    assert os.path.exists(os.path.join(str(tmp_path), "latest_checkpoint.pt"))
+    assert os.path.exists(os.path.join(str(tmp_path), "latest_checkpoint.yml"))
