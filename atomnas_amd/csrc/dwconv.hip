@@ -672,6 +672,8 @@ static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap) {
   if (per_cu < 1) per_cu = 1;
   if (per_cu > cap) per_cu = cap;
   long want = ((long)num_cus() * per_cu) / nslabs;
+  static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: force long tile walks
+  if (max_env > 0 && want > max_env) want = max_env;
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
   g.nworkers = (int)want;

@@ -4,6 +4,8 @@ Inputs are first rounded to the storage dtype, the reference computes in float64
 tolerance of one output rounding (bf16) or accumulation order (fp32).  Integer results (masks, indices, counts) are exact.
 """
 import itertools
+import os
+import sys
 
 import pytest
 import torch
@@ -38,7 +40,7 @@ def taps(w):  # [C,1,k,k] -> [k*k][pad8(C)] fp32 on GPU
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k,stride", list(itertools.product([3, 5, 7], [1, 2])))
-@pytest.mark.parametrize("N,C,H,W", [(2, 1, 7, 7), (3, 13, 15, 15), (2, 32, 8, 14), (1, 70, 28, 28)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 1, 7, 7), (3, 13, 15, 15), (2, 32, 8, 14), (1, 70, 28, 28), (2, 24, 44, 37)])
 def test_dwconv_fwd(gpu_lib, dtype, k, stride, N, C, H, W):
     ops = _ops()
     g = torch.Generator().manual_seed(1000 * k + 10 * stride + C)
@@ -66,7 +68,7 @@ def test_dwconv_fwd(gpu_lib, dtype, k, stride, N, C, H, W):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k,stride", list(itertools.product([3, 5, 7], [1, 2])))
-@pytest.mark.parametrize("N,C,H,W", [(2, 1, 7, 7), (3, 13, 15, 15), (2, 32, 8, 14), (1, 70, 28, 28)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 1, 7, 7), (3, 13, 15, 15), (2, 32, 8, 14), (1, 70, 28, 28), (2, 24, 44, 37)])
 def test_dwconv_bwd(gpu_lib, dtype, k, stride, N, C, H, W):
     ops = _ops()
     g = torch.Generator().manual_seed(2000 * k + 10 * stride + C)
@@ -216,3 +218,14 @@ def test_gemm_tn(gpu_lib, dtype, M, NU, NV, variant):
         ops.gemm_tn(act2d(U, NU), NU, act2d(V, NV), NV, out, si, sj, M, **kw)
         torch.cuda.synchronize()
         assert_close("out", view(out), ref, rtol=2e-3 if dtype == torch.bfloat16 else 2e-4, atol=2e-3 * float(ref.abs().max()))
+
+
+def test_dwconv_long_tile_walks():
+    """The depthwise kernels keep the halo rows of the tile above in their LDS ring when a workgroup walks down a column of
+    tiles.  With the small tensors of the tests every workgroup normally gets a single tile, so the same cases are re-run
+    with the number of workgroups per slab capped (read once per process -> separate interpreter)."""
+    import subprocess
+    env = dict(os.environ, ATOMNAS_DW_MAX_WORKERS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "test_dwconv_fwd or test_dwconv_bwd"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
