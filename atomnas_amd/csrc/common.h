@@ -108,6 +108,16 @@ template <int V> struct VecIO<bf16_t, V> {
   }
 };
 
+// Activation modes carried by the integer `relu` / `mask` arguments of the C ABI: 0 none, 1 ReLU, 2 ReLU6
+// (models/mobilenet_base.py:407-415 `get_active_fn`).  act_pass = the derivative is non-zero at pre-activation a.
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
+__device__ __forceinline__ float act_apply(float a, int mode) {
+  return mode == ACT_NONE ? a : (mode == ACT_RELU ? fmaxf(a, 0.f) : fminf(fmaxf(a, 0.f), 6.f));
+}
+__device__ __forceinline__ bool act_pass(float a, int mode) {
+  return mode == ACT_NONE ? true : (mode == ACT_RELU ? (a > 0.f) : (a > 0.f && a < 6.f));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

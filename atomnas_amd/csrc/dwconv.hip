@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float a = pf[i].get(e) * sc[e] + sh[e];
-          a = in_relu ? fmaxf(a, 0.f) : a;
+          a = act_apply(a, in_relu);
           v[e] = ok ? a : 0.f;
         }
         int slot = p_iy[i] + base;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
         if (wi < g.W) {
           const float v[2] = {xq[q][t].get(0), xq[q][t].get(1)};
           const float a0 = v[0] * sc[0] + sh[0], a1 = v[1] * sc[1] + sh[1];
-          xa[t] = in_relu ? f32x2{fmaxf(a0, 0.f), fmaxf(a1, 0.f)} : f32x2{a0, a1};
+          xa[t] = f32x2{act_apply(a0, in_relu), act_apply(a1, in_relu)};
         }
       }
       f32x2 dx[SW];
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const float a = xv[c] * sc[c] + sh[c];
-            float v = (in_relu && !(a > 0.f)) ? 0.f : dx[t][c];
+            float v = act_pass(a, in_relu) ? dx[t][c] : 0.f;
             v = (ch + c < g.C) ? to_f32(from_f32<T>(v)) : 0.f;
             o[c] = v;
             s0[c] += v;

@@ -15,16 +15,18 @@ from . import ops
 from .ops import PRO_BNBWD, PRO_BNRELU, PRO_NONE, STAT_SQ, STAT_Z
 from .runtime import pad8
 
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2   # the integer `relu` / `mask` arguments of the C ABI
 
 
 def act_code(module):
     """Maps the activation module a ConvBNReLU holds to the kernels' activation flag."""
     if module is None:
         return ACT_NONE
+    if isinstance(module, nn.ReLU6):
+        return ACT_RELU6
     if isinstance(module, nn.ReLU):
         return ACT_RELU
-    raise NotImplementedError("activation %s is not supported by the HIP path yet (ReLU only)" % type(module).__name__)
+    raise NotImplementedError("activation %s is not supported by the HIP path yet (ReLU / ReLU6 only)" % type(module).__name__)
 
 
 # ---------------------------------------------------------------------------------------------- layout plumbing
@@ -132,7 +134,7 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     bsp = bn_uses_batch_stats(pl.bnp)
     Pr = torch.empty(M2, pl.oup, dtype=T, device=dev)
     stP = _stats(pl.oup, dev) if bsp else None
-    ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=bool(act), stats=stP,
+    ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=int(act), stats=stP,
                 stat_mode=STAT_SQ if bsp else 0)
     bP = bn_forward_coeffs(pl.bnp, stP, M2, dev)
     out = torch.empty(M2, pl.oup, dtype=T, device=dev)
@@ -156,12 +158,12 @@ def block_backward(pl, sv, G):
     p1, p2, p3 = bn_backward_coeffs(pl.bnp, bP, st2P, M2, dev)
     # projection weight gradient: dWp[n][k] = sum_m dP[m][n] * act(bn(D))[m][k]
     ops.gemm_tn(G, pl.oup, D, HT, pl.Wp_grad, HT, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
-                vc1=bD.scale, vc2=bD.shift, v_relu=bool(act))
+                vc1=bD.scale, vc2=bD.shift, v_relu=int(act))
     # projection input gradient, masked by the depthwise ReLU, with the depthwise-BN backward statistics
     g = torch.empty(M2, HT, dtype=T, device=dev)
     st2D = _stats(HT, dev)
     ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
-                zshift=bD.shift, mask=bool(act), stats=st2D, stat_mode=STAT_Z)
+                zshift=bD.shift, mask=int(act), stats=st2D, stat_mode=STAT_Z)
     d1, d2, d3 = bn_backward_coeffs(pl.bnd, bD, st2D, M2, dev)
     # depthwise backward per branch
     if pl.expand:
@@ -266,7 +268,7 @@ def convbn_forward(pl, x, need_grad):
         ops.gemm_nt(a2d, pl.W_pack, Y, M, pl.cout, K, stats=st, stat_mode=STAT_SQ if bs else 0)
     b = bn_forward_coeffs(pl.bn, st, M, dev)
     out = torch.empty(M, Cp, dtype=T, device=dev)
-    ops.bn_apply(Y, b.scale, b.shift, bool(act), None, out, M, pl.cout)
+    ops.bn_apply(Y, b.scale, b.shift, int(act), None, out, M, pl.cout)
     if need_grad:
         sv.update(a=a2d, Y=Y, b=b, dims=(N, H, W, Ho, Wo), K=K if sv["kind"] != "dw" else 0)
     return out, (N, Ho, Wo), sv
@@ -280,7 +282,7 @@ def convbn_backward(pl, sv, G, need_input_grad):
     Y, b, a2d = sv["Y"], sv["b"], sv["a"]
     g = torch.empty_like(Y)
     st2 = _stats(pl.cout, dev)
-    ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, bool(act), g, st2, M, pl.cout)
+    ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, int(act), g, st2, M, pl.cout)
     c1, c2, c3 = bn_backward_coeffs(pl.bn, b, st2, M, dev)
     if sv["kind"] == "dw":
         h = torch.zeros(N * H * W, pad8(pl.cout), dtype=T, device=dev)
@@ -343,7 +345,7 @@ def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
     pooled = torch.empty(N, lp.cout, dtype=T, device=dev)
     p = float(drop_p) if training else 0.0
     keep = torch.empty(N, lp.cout, dtype=torch.uint8, device=dev) if p > 0 else None
-    ops.bn_act_pool(L, b.scale, b.shift, bool(act), pooled, keep, p, seed, step_ptr, N, H * W, lp.cout)
+    ops.bn_act_pool(L, b.scale, b.shift, int(act), pooled, keep, p, seed, step_ptr, N, H * W, lp.cout)
     Kc = fp.cout
     logits = torch.empty(N, pad8(Kc), dtype=torch.float32, device=dev)
     ops.gemm_nt(pooled, fp.W_pack, logits, N, Kc, fp.cin, bias=fp.bias)
@@ -374,7 +376,7 @@ def tail_backward(lp, fp, sv, dlogits):
     L, b = sv["L"], sv["b"]
     gL = torch.empty(M, lp.cout, dtype=T, device=dev)
     st2 = _stats(lp.cout, dev)
-    ops.pool_act_bwd(dpooled, sv["keep"], sv["p"], L, b.scale, b.shift, bool(act), gL, st2, N, HW, lp.cout)
+    ops.pool_act_bwd(dpooled, sv["keep"], sv["p"], L, b.scale, b.shift, int(act), gL, st2, N, HW, lp.cout)
     c1, c2, c3 = bn_backward_coeffs(lp.bn, b, st2, M, dev)
     ops.gemm_tn(sv["a"], lp.cin, gL, lp.cout, lp.W_grad, 1, lp.cin, M, v_mode=PRO_BNBWD, v2=L, vc1=c1, vc2=c2, vc3=c3)
     Gx = torch.empty(M, lp.cin, dtype=T, device=dev)

@@ -28,6 +28,11 @@ extern "C" {
 #define ATOMNAS_DT_F32 0
 #define ATOMNAS_DT_BF16 1
 
+/* activation mode carried by every `*_relu`, `relu` and `mask` argument: models/mobilenet_base.py:407-415 get_active_fn */
+#define ATOMNAS_ACT_NONE 0
+#define ATOMNAS_ACT_RELU 1  /* max(a, 0);           backward passes where a > 0       */
+#define ATOMNAS_ACT_RELU6 2 /* min(max(a, 0), 6);   backward passes where 0 < a < 6   */
+
 /* prologue applied to a GEMM operand while it is loaded */
 #define ATOMNAS_PRO_NONE 0   /* a                                   */
 #define ATOMNAS_PRO_BNRELU 1 /* act(a * c1[k] + c2[k])              BatchNorm apply (+ReLU) of the producer */

@@ -48,19 +48,32 @@ BLOCKS = [
     dict(inp=16, oup=24, stride=2, channels=[96], ks=[5], expand=True),                  # single branch
     dict(inp=16, oup=8, stride=1, channels=[16], ks=[3], expand=False),                  # first block of the supernet
     dict(inp=24, oup=24, stride=1, channels=[1, 3], ks=[3, 7], expand=True),             # nearly pruned
+    # ReLU6 (the MobileNetV2 baseline of apps/mobilenet): BN scales x4 so that the upper clamp is active
+    dict(inp=8, oup=8, stride=1, channels=[16, 16, 16], ks=[3, 5, 7], expand=True, act="nn.ReLU6"),
+    dict(inp=8, oup=16, stride=2, channels=[12, 20, 7], ks=[3, 5, 7], expand=True, act="nn.ReLU6"),
 ]
+
+
+def _widen_bn(module, factor):
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() == 1 and "bias" not in n:
+                p.mul_(factor)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", BLOCKS)
 def test_block_forward_backward(gpu_lib, cfg, dtype):
     from atomnas_amd.models import mobilenet_base as mb
-    act = mb.get_active_fn("nn.ReLU")
+    act_name = cfg.get("act", "nn.ReLU")
+    act = mb.get_active_fn(act_name)
     bn_kw = {"momentum": 0.01, "eps": 1e-3}
     blk = mb.InvertedResidualChannels(cfg["inp"], cfg["oup"], cfg["stride"], cfg["channels"], cfg["ks"], cfg["expand"],
                                       active_fn=act, batch_norm_kwargs=bn_kw)
     blk.compute_dtype = dtype
     _randomize(blk, 7)
+    if act_name == "nn.ReLU6":
+        _widen_bn(blk, 4.0)
     N, H = 3, 14
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, cfg["inp"], H, H, generator=g)
@@ -78,7 +91,7 @@ def test_block_forward_backward(gpu_lib, cfg, dtype):
     torch.cuda.synchronize()
 
     # oracle in float64 on the same state_dict
-    spec = dict(eps=1e-3, momentum=0.01, act="nn.ReLU")
+    spec = dict(eps=1e-3, momentum=0.01, act=act_name)
     ob = dict(name="blk", inp=cfg["inp"], oup=cfg["oup"], stride=cfg["stride"], expand=cfg["expand"], channels=cfg["channels"],
               ks=cfg["ks"], res=cfg["stride"] == 1 and cfg["inp"] == cfg["oup"])
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
@@ -185,3 +198,43 @@ def test_model_forward_backward(gpu_lib, dtype):
             cos = float(torch.dot(gg, r.flatten()) / (gg.norm() * r.norm()))
             ratio = float(gg.norm() / r.norm())
             assert cos > 0.8 and 0.6 < ratio < 1.6, "grad %s: cosine %.3f norm ratio %.3f" % (name, cos, ratio)
+
+
+@pytest.mark.parametrize("act", ["nn.ReLU", "nn.ReLU6"])
+def test_cfg1_mobilenet_v2_on_the_gpu(gpu_lib, act):
+    """BASELINE config 1: MobileNetV2-1.0 from apps/mobilenet (single-branch 3x3 blocks, ReLU; ReLU6 as in the original
+    network) -- logits and loss against the oracle in fp32, gradients in aggregate."""
+    import os
+    os.environ.setdefault("ARNOLD_OUTPUT", "/tmp/atomnas_out")
+    from atomnas_amd.models import mobilenet_supernet as ms
+    from atomnas_amd.utils import config
+    from atomnas_amd.utils import optim as aopt
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = config.load_app(["app:" + os.path.join(root, "apps/mobilenet/mobilenet_v2_mnas.yml")])
+    kw = dict(flags.model_kwparams)
+    kw["active_fn"] = act
+    kw["dropout_ratio"] = 0.0
+    model = ms.Model(**kw, input_size=96)
+    model.set_compute_dtype(torch.float32)
+    _randomize(model, 13)
+    sd0 = _sd64(model)
+    spec = orc.spec_from_model(model)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 3, 96, 96, generator=g)
+    y = torch.randint(0, 1000, (4,), generator=g)
+    model.cuda().train()
+    logits = model(x.cuda())
+    loss = aopt.CrossEntropyLabelSmooth(1000, 0.1, reduction="none")(logits, y.cuda()).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
+    ref = orc.model_forward(x.double(), work, spec, True, {})
+    rl = orc.ce_label_smooth(ref, y, 0.1).mean()
+    rl.backward()
+    assert_close("logits", logits, ref, rtol=2e-3, atol=2e-3)
+    assert abs(float(loss.detach()) - float(rl.detach())) < 1e-4
+    num = den = 0.0
+    for name, p in model.named_parameters():
+        d = p.grad.double().cpu() - work[name].grad
+        num += float((d * d).sum()); den += float((work[name].grad ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
