@@ -21,3 +21,9 @@ def test_train_entry_runs_two_epochs(gpu_lib, tmp_path):
     assert "Prune threshold" in out
     assert os.path.exists(os.path.join(str(tmp_path), "latest_checkpoint.pt"))
     assert os.path.exists(os.path.join(str(tmp_path), "latest_checkpoint.yml"))
+    # resume from the checkpoint for one more epoch (train.py:181-196 of the reference: model, optimizer, EMA, epoch counters)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "app:" + os.path.join(ROOT, "tests", "data", "tiny_search.yml"),
+                         "--resume", str(tmp_path), "--num_epochs", "3"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out2 = r2.stdout + r2.stderr
+    assert r2.returncode == 0, out2[-4000:]
+    assert "Epoch 2/3" in out2 and "Epoch 0/3" not in out2, out2[-3000:]

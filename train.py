@@ -86,6 +86,12 @@ def train_val_test():
     if FLAGS.resume:
         ckpt = torch.load(os.path.join(FLAGS.resume, 'latest_checkpoint.pt'), map_location='cpu')
         model_wrapper.load_state_dict(ckpt['model'])
+        # torch maps saved optimizer state to parameters by POSITION; after a shrink the optimizer's order differs from the
+        # model's (re-keyed variables are appended, utils/rmsprop.py:134-165), so the saved order is restored by name first
+        names = ckpt.get('optimizer_param_names')
+        if names:
+            table = dict(model_wrapper.named_parameters())
+            optimizer.param_groups[0]['params'] = [table[n] for n in names]
         optimizer.load_state_dict(ckpt['optimizer'])
         if ema:
             ema.load_state_dict(ckpt['ema'])
@@ -139,7 +145,9 @@ def train_val_test():
         if udist.is_master() and FLAGS.get('log_dir', None):
             os.makedirs(FLAGS.log_dir, exist_ok=True)
             kw = mb.output_network(model)
+            pname = {id(p): n for n, p in model_wrapper.named_parameters()}
             state = {'model': {k: v.detach().clone() for k, v in model_wrapper.state_dict().items()}, 'optimizer': optimizer.state_dict(),
+                     'optimizer_param_names': [pname[id(p)] for p in optimizer.param_groups[0]['params']],
                      'ema': ema.state_dict() if ema else None, 'last_epoch': epoch, 'best_val': min(best_val, results['top1_error']),
                      'meters': None}
             torch.save(state, os.path.join(FLAGS.log_dir, 'latest_checkpoint.pt'))
