@@ -9,7 +9,8 @@
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __global__ __launch_bounds__(256) void k_tilecopy(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int N, int H, int W,
-                                                  int C, int CB, int TH, int TW, int HALO, int nslabs, int nworkers, int nstreams) {
+                                                  int C, int CB, int TH, int TW, int HALO, int nslabs, int nworkers, int nstreams,
+                                                  size_t stream_stride) {
   const int CG = CB / 8;
   const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;
   const int slab = b_local % nslabs, worker = (b_local / nslabs) * 8 + b_xcd;
@@ -20,7 +21,6 @@ __global__ __launch_bounds__(256) void k_tilecopy(const unsigned short* __restri
   const int cg = threadIdx.x % CG;
   const long coff = (long)slab * CB + cg * 8;
   const int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  const size_t stream_stride = (size_t)N * H * W * C;
   u32x4 acc = {0, 0, 0, 0};
   for (int t = t_beg; t < t_end; ++t) {
     const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -45,19 +45,19 @@ int main() {
   const size_t elems = (size_t)N * H * W * C;
   unsigned short *x, *y;
   const int NBUF = 2;
-  hipMalloc(&x, elems * 2 * 3 * NBUF); hipMalloc(&y, elems * 2 * NBUF);
-  hipMemset(x, 1, elems * 2 * 3 * NBUF); hipMemset(y, 0, elems * 2 * NBUF);
+  hipMalloc(&x, (elems + 200000) * 2 * 3 * NBUF + 4096); hipMalloc(&y, (elems + 600000) * 2 * NBUF);
+  hipMemset(x, 1, (elems + 200000) * 2 * 3 * NBUF); hipMemset(y, 0, (elems + 600000) * 2 * NBUF);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  struct Cfg { int th, tw, halo, streams, percu; };
-  const Cfg cfgs[] = {{14, 14, 0, 1, 4}, {14, 14, 1, 1, 4}, {14, 14, 1, 3, 3}, {14, 14, 3, 3, 2}, {7, 56, 0, 1, 4}, {7, 56, 1, 3, 3}, {4, 56, 1, 3, 3},
-                      {56, 56, 0, 1, 4}, {56, 56, 0, 3, 3}, {14, 28, 1, 3, 3}, {28, 14, 1, 3, 3}, {14, 14, 1, 3, 6}, {7, 56, 1, 3, 6}};
+  struct Cfg { int th, tw, halo, streams, percu; size_t pad; };   // pad: extra elements between the input streams (HBM channel skew)
+  const Cfg cfgs[] = {{14, 14, 1, 3, 3, 0}, {14, 14, 1, 3, 3, 2048}, {14, 14, 1, 3, 3, 6144}, {14, 14, 1, 3, 3, 34816}, {14, 14, 1, 3, 3, 133120},
+                      {14, 14, 3, 3, 2, 0}, {14, 14, 3, 3, 2, 6144}, {14, 14, 3, 3, 2, 133120}, {14, 14, 1, 1, 4, 0}, {14, 14, 1, 1, 4, 6144}};
   for (const Cfg& c : cfgs) {
     const int nslabs = C / CB;
     const int nworkers = 256 * c.percu / nslabs;
     const int grid = (nworkers + 7) / 8 * 8 * nslabs;
     auto launch = [&](int it) {
-      hipLaunchKernelGGL(k_tilecopy, dim3(grid), dim3(256), 0, 0, x + (size_t)(it % NBUF) * elems * 3, y + (size_t)(it % NBUF) * elems, N, H, W, C, CB,
-                         c.th, c.tw, c.halo, nslabs, nworkers, c.streams);
+      hipLaunchKernelGGL(k_tilecopy, dim3(grid), dim3(256), 0, 0, x + (size_t)(it % NBUF) * (elems + 200000) * 3, y + (size_t)(it % NBUF) * elems + c.pad * 3, N, H, W, C, CB,
+                         c.th, c.tw, c.halo, nslabs, nworkers, c.streams, elems + c.pad);
     };
     for (int i = 0; i < 2; ++i) launch(i);
     hipDeviceSynchronize();
@@ -67,7 +67,7 @@ int main() {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= IT;
     const double moved = (double)elems * 2 * (c.streams + 1);
-    printf("tile %2dx%2d halo %d streams %d percu %d : %.3f ms  %.0f GB/s (tensor bytes)\n", c.th, c.tw, c.halo, c.streams, c.percu, ms,
+    printf("tile %2dx%2d halo %d streams %d percu %d pad %6zu : %.3f ms  %.0f GB/s (tensor bytes)\n", c.th, c.tw, c.halo, c.streams, c.percu, c.pad, ms,
            moved / ms / 1e6);
   }
   return 0;
