@@ -104,7 +104,7 @@ static inline int lds_pitch(int lw, int cb) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int K, int S, int SW, int CB, int TM>
+template <typename T, int K, int S, int SW, int CB, int TM, bool R6>
 __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int ldx, const float* __restrict__ in_scale,
                                                     const float* __restrict__ in_shift, int in_relu,
                                                     const float* __restrict__ w, int ldw, T* __restrict__ y, int ldy,
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float a = pf[i].get(e) * sc[e] + sh[e];
-          a = act_apply(a, in_relu);
+          if constexpr (R6) a = fminf(fmaxf(a, 0.f), 6.f);   // ReLU6 instances are separate so that the ReLU code stays as tuned
+          else a = in_relu ? fmaxf(a, 0.f) : a;
           v[e] = ok ? a : 0.f;
         }
         int slot = p_iy[i] + base;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 // Tiles are in INPUT space (TH x TW input pixels); the LDS tile holds dYraw over the output window those pixels touch.
 // Work item = (channel pair, input row, strip of SW input pixels).  For stride 2 only taps of matching parity contribute:
 // per (t, kx) that is a compile-time fact (tile and strip origins are even), per ky it is uniform for a row.
-template <typename T, int K, int S, int SW, int CB>
+template <typename T, int K, int S, int SW, int CB, bool R6>
 __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, const T* __restrict__ yraw, int ldyr,
                                                     const float* __restrict__ c1, const float* __restrict__ c2p,
                                                     const float* __restrict__ c3, const T* __restrict__ x, int ldx,
@@ -533,7 +534,8 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
         if (wi < g.W) {
           const float v[2] = {xq[q][t].get(0), xq[q][t].get(1)};
           const float a0 = v[0] * sc[0] + sh[0], a1 = v[1] * sc[1] + sh[1];
-          xa[t] = f32x2{act_apply(a0, in_relu), act_apply(a1, in_relu)};
+          if constexpr (R6) xa[t] = f32x2{fminf(fmaxf(a0, 0.f), 6.f), fminf(fmaxf(a1, 0.f), 6.f)};
+          else xa[t] = in_relu ? f32x2{fmaxf(a0, 0.f), fmaxf(a1, 0.f)} : f32x2{a0, a1};
         }
       }
       f32x2 dx[SW];
@@ -578,7 +580,9 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const float a = xv[c] * sc[c] + sh[c];
-            float v = act_pass(a, in_relu) ? dx[t][c] : 0.f;
+            float v;
+            if constexpr (R6) v = (a > 0.f && a < 6.f) ? dx[t][c] : 0.f;
+            else v = (in_relu && !(a > 0.f)) ? 0.f : dx[t][c];
             v = (ch + c < g.C) ? to_f32(from_f32<T>(v)) : 0.f;
             o[c] = v;
             s0[c] += v;
@@ -713,7 +717,7 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
   const int cap = cap_env ? cap_env : 8;
 #define FWD_CASE(CBV, TMV)                                                                                                   \
   {                                                                                                                      \
-    auto kern = k_dwconv_fwd<T, K, S, 7, CBV, TMV>;                                                                           \
+    auto kern = (relu == ACT_RELU6) ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, true> : k_dwconv_fwd<T, K, S, 7, CBV, TMV, false>;                                                                           \
     set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap);                                                             \
     dim3 grid(dw_grid(g));                                                                                      \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy, stats, stat_ld, g); \
@@ -760,7 +764,7 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   const int cap = cap_env2 ? cap_env2 : 8;
 #define BWD_CASE(CBV)                                                                                                     \
   {                                                                                                                       \
-    auto kern = k_dwconv_bwd<T, K, S, SW, CBV>;                                                                           \
+    auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, true> : k_dwconv_bwd<T, K, S, SW, CBV, false>;                                                                           \
     set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap);                                                              \
     dim3 grid(dw_grid(g));                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2, c3, (const T*)x, ldx, sc, \

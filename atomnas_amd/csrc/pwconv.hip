@@ -77,7 +77,7 @@ __device__ __forceinline__ void load_pro(const Operand& o, long row, bool rowval
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       float a = v[e] * s[e] + h[e];
-      v[e] = act_apply(a, o.relu);
+      v[e] = act_apply(a, act_of(o.relu));
     }
   } else if constexpr (MODE == PRO_BNBWD) {
     float x[E], a1[E], a2[E], a3[E];
@@ -114,7 +114,7 @@ __device__ __forceinline__ void load_pro_lds(const Operand& o, long row, bool ro
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float a = v[e] * s[e] + h[e];
-      v[e] = act_apply(a, o.relu);
+      v[e] = act_apply(a, act_of(o.relu));
     }
   } else if constexpr (MODE == PRO_BNBWD) {
     float x[8], a1[8], a2[8], a3[8];
@@ -192,7 +192,7 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
           for (int i = 0; i < 8; ++i) {
             const int n = n8 + i;
             const float a = (n < N) ? tmp[i] * ep.zscale[n] + ep.zshift[n] : 0.f;
-            if (!act_pass(a, ep.mask)) c[8 * h8 + i] = 0.f;
+            if (!act_pass(a, act_of(ep.mask))) c[8 * h8 + i] = 0.f;
           }
         }
       }
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const float a = zv[i] * zs[i] + zh[i];
-            if (!act_pass(a, ep.mask)) c[8 * h8 + i] = 0.f;
+            if (!act_pass(a, act_of(ep.mask))) c[8 * h8 + i] = 0.f;
           }
         }
       }
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
               const float a = (float)acur[s][ks].a[e];
               if constexpr (MODE == PRO_BNRELU) {
                 const float t = a * c1v[e] + c2v[e];
-                v[e] = act_apply(t, A.relu);
+                v[e] = act_apply(t, act_of(A.relu));
               } else {
                 v[e] = c1v[e] * a + c2v[e] * (float)acur[s][ks].x[e] + c3v[e];
               }
