@@ -7,6 +7,8 @@ are launched on the capturing stream through the C ABI, so they become graph nod
 that change per iteration (lr, rho, EMA decay) are staged through a 4-float device vector, inputs through static buffers.
 With a process group, the gradient arena is all-reduced by RCCL between two graphs (backward | optimizer).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,6 +26,8 @@ class TrainStep:
         self.use_graph = use_graph
         self.world_size = world_size
         self.pg = process_group
+        # the collective can be forced on a single rank to exercise RCCL + graph capture on a one-GPU box
+        self._reduce = world_size > 1 or (bool(os.environ.get("ATOMNAS_FORCE_ALLREDUCE")) and dist.is_initialized())
         dev = next(model.parameters()).device
         self.mgr = runtime.manager_of(model)
         self.mgr.attach_optimizer(optimizer)
@@ -89,11 +93,13 @@ class TrainStep:
         torch.cuda.synchronize()
         mgr.S.copy_(keep_s)
         mgr.CNT.copy_(keep_c)
+        # thread_local: the RCCL watchdog thread of a process group polls events while we capture; in the default "global" mode
+        # such a call from another thread invalidates the capture
         self.g_fwd_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd_bwd):
+        with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode="thread_local"):
             self._fwd_bwd()
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
+        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self._opt()
         self._version = mgr.version
 
@@ -120,12 +126,12 @@ class TrainStep:
             if self.g_fwd_bwd is None:
                 self._capture()
             self.g_fwd_bwd.replay()
-            if self.world_size > 1:
+            if self._reduce:
                 dist.all_reduce(mgr.G, group=self.pg)
             self.g_opt.replay()
         else:
             self._fwd_bwd()
-            if self.world_size > 1:
+            if self._reduce:
                 dist.all_reduce(mgr.G, group=self.pg)
             self._opt()
         self.global_step += 1

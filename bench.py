@@ -171,7 +171,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path runs in libatomnas_hip.so only (no CPU fallback)")
     torch.cuda.set_device(0 if args.same_device else local)
-    if world > 1:
+    if world > 1 or os.environ.get("ATOMNAS_FORCE_ALLREDUCE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend)   # "nccl" is RCCL on ROCm
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -237,7 +237,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.model)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -10,6 +10,8 @@ SETTING = [[1, 16, 1, 1, [3]], [6, 24, 4, 2, [3, 5, 7]], [6, 40, 4, 2, [3, 5, 7]
            [6, 192, 4, 2, [3, 5, 7]], [6, 320, 1, 1, [3, 5, 7]]]
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
+if os.environ.get("PREALLOC_GB"):   # experiment: one large allocator segment up front (physical contiguity / TLB reach)
+    _big = torch.empty(int(float(os.environ["PREALLOC_GB"]) * 2**30), dtype=torch.uint8, device="cuda"); del _big
 torch.manual_seed(1995)
 model = ms.Model(inverted_residual_setting=SETTING, active_fn='nn.ReLU', batch_norm_momentum=0.01, batch_norm_epsilon=1e-3,
                  input_channel=32, input_size=224)
