@@ -23,6 +23,12 @@
 #define DW_EXP 0  // experiment switch for tools/dwbench.py: fwd: 1 no stores, 2 no compute, 3 no LDS commit; bwd: 4 no global flush, 5 no compute, 6 no h stores, 7 no x loads, 8 no dY loads, 9 no yraw loads, 10 no FMA loop, 11 no global memory traffic
 #endif
 
+#ifndef DW_DMA
+#define DW_DMA 0   // experiment (backward, bf16): the dY / yraw prefetch of the next tile goes global -> LDS directly
+                   // (global_load_lds_dwordx4) instead of through 2*PF*4 staging registers.  Correct (tests pass) and it removes
+                   // the spills of k = 7, but the extra raw LDS buffers cost residency: +2..4 % on 16-channel slabs, +50..90 % on
+                   // 32-channel ones, -5 % only for k = 7 stride 2 (tools/dwbench.py, same box) -> off
+#endif
 #ifndef DW_RING
 #define DW_RING 1  // 1 = tiles are walked column-major and the LDS operand tile is a ring over rows: a tile below the previous one
                    // loads only its new rows (the (K-1)/S halo rows stay); 0 = every tile loads its whole haloed window
@@ -85,6 +91,22 @@ template <> struct Raw2<float> {
   __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const f32x2*>(p); }
   __device__ __forceinline__ float get(int e) const { return v[e]; }
 };
+
+// LDS-DMA: every active lane copies 16 bytes from its own global address to LDS at lds_wave_base + lane * 16 (wave-uniform
+// base in M0; inactive lanes write nothing).  Issued through inline asm on purpose: hipcc then does not count it in its
+// s_waitcnt bookkeeping, so the copy stays in flight across barriers and LDS reads until lds_dma_wait() (with the builtin
+// the compiler drains it at the next LDS access; cdna_hip_programming.md "Pipelining across barriers").
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_wave_base)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
+}
 
 struct DwGeom {
   int N, H, W, C, Ho, Wo;
@@ -329,8 +351,12 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   constexpr int LMAXB = fdiv(14 - 1 + P, S) - cdiv(P - (K - 1), S) + 1;  // dY window of a 14-pixel input tile
   constexpr int PF = (LMAXB * (fdiv(14 - 1 + P, S) - fdiv(-P, S) + 1) * (CB / 8) + 255) / 256;
   static_assert(PF <= 32, "prefetch mask is 32 bits");
+  constexpr bool DMA = DW_DMA && sizeof(T) == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_dy = smem;                        // [LH][RP]
+  // raw staging of the next tile's dY / yraw pieces (lane-linear: piece i of thread t at (i*256 + t) * 16 bytes); first in LDS
+  T* s_rawg = reinterpret_cast<T*>(smem);                        // [PF][256][8]
+  T* s_rawy = s_rawg + (DMA ? PF * 256 * 8 : 0);                 // [PF][256][8]
+  float* s_dy = reinterpret_cast<float*>(s_rawy + (DMA ? PF * 256 * 8 : 0));   // [LH][RP]
   float* s_w = s_dy + g.LH * g.RP;           // [KK][CB]
   float* s_red = s_w + KK * CB;              // [CB][KK + 2]
   float* s_cf = s_red + CB * (KK + 2);       // [3][CB] BN-backward coefficients of the slab (c1 = 1, c2 = c3 = 0 without them)
@@ -381,8 +407,10 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     p_iy[i] = pidx < npix ? pidx / g.LW : -100000;
     p_ix[i] = pidx % g.LW;
   }
-  Raw8<T> pfg[PF], pfy[PF];
+  Raw8<T> pfg[DMA ? 1 : PF], pfy[DMA ? 1 : PF];
   unsigned pfmask = 0;
+  const unsigned rawg_base = lds_addr(s_rawg) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 64u * 16u;
+  const unsigned rawy_base = lds_addr(s_rawy) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 64u * 16u;
   auto issue = [&](int n, int ty, int tx, int rowmin) {
     const int hob = cdiv(ty * g.TH + P - (K - 1), S), wob = (tx * g.TW) / S + RELMIN;
     const T* gn = gup + (long)n * g.Ho * g.Wo * ldg + c_base + cg * 8;
@@ -393,26 +421,42 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       const int ho = hob + p_iy[i], wo = wob + p_ix[i];
       if (DW_EXP != 8 && DW_EXP != 11 && cg_ok && p_iy[i] >= rowmin && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
         const long off = (long)ho * g.Wo + wo;
-        pfg[i].load(gn + off * ldg);
-        if (yn && DW_EXP != 9) pfy[i].load(yn + off * ldyr);
+        if constexpr (DMA) {
+          lds_dma16(gn + off * ldg, rawg_base + (unsigned)i * 256u * 16u);
+          if (yn && DW_EXP != 9) lds_dma16(yn + off * ldyr, rawy_base + (unsigned)i * 256u * 16u);
+        } else {
+          pfg[i].load(gn + off * ldg);
+          if (yn && DW_EXP != 9) pfy[i].load(yn + off * ldyr);
+        }
         pfmask |= 1u << i;
       }
     }
   };
   auto commit = [&](int rowmin, int base) {
+    if constexpr (DMA) lds_dma_wait();   // this thread's own pieces have landed (no other thread reads them)
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       if (p_iy[i] >= rowmin) {
         float v[8];
         const bool ok = (pfmask >> i) & 1u;
+        Raw8<T> rg, ry;
+        if constexpr (DMA) {
+          rg.zero(); ry.zero();
+          if (ok) {
+            rg.load(s_rawg + (i * 256 + tid) * 8);
+            if (yraw) ry.load(s_rawy + (i * 256 + tid) * 8);
+          }
+        } else {
+          rg = pfg[i]; ry = pfy[i];
+        }
         float q1[8], q2[8], q3[8];   // re-read from LDS per tile: keeps 24 registers free during the FMA phase
         VecIO<float, 8>::load(s_cf + cg * 8, q1);
         VecIO<float, 8>::load(s_cf + CB + cg * 8, q2);
         VecIO<float, 8>::load(s_cf + 2 * CB + cg * 8, q3);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float a = q1[e] * pfg[i].get(e);
-          if (yraw) a += q2[e] * pfy[i].get(e) + q3[e];
+          float a = q1[e] * rg.get(e);
+          if (yraw) a += q2[e] * ry.get(e) + q3[e];
           v[e] = ok ? a : 0.f;
         }
         int slot = p_iy[i] + base;
@@ -757,8 +801,11 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
   g.LW = fdiv(g.TW - 1 + P, S) - fdiv(-P, S) + 1;
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
+  // + raw LDS-DMA staging of the dY / yraw prefetch (bf16): 2 streams x PF pieces x 256 threads x 16 bytes
+  const int lmaxb = fdiv(14 - 1 + P, S) - cdiv(P - (K - 1), S) + 1, lmaxw = fdiv(14 - 1 + P, S) - fdiv(-P, S) + 1;
+  const int pf = (lmaxb * lmaxw * (cb / 8) + 255) / 256;
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2) + 3 * (size_t)cb) * sizeof(float) +
-                     (size_t)2 * 14 * 14 * cb * sizeof(T);
+                     (size_t)2 * 14 * 14 * cb * sizeof(T) + ((DW_DMA && sizeof(T) == 2) ? (size_t)2 * pf * 256 * 16 : 0);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env2 = getenv("ATOMNAS_DW_BWD_PERCU") ? atoi(getenv("ATOMNAS_DW_BWD_PERCU")) : 0;
   const int cap = cap_env2 ? cap_env2 : 8;
