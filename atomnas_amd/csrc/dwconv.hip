@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 // Work item = (channel pair, input row, strip of SW input pixels).  For stride 2 only taps of matching parity contribute:
 // per (t, kx) that is a compile-time fact (tile and strip origins are even), per ky it is uniform for a row.
 template <typename T, int K, int S, int SW, int CB, bool R6>
+// (launch bounds for 3 resident workgroups, i.e. <= 168 VGPRs, make k = 5 spill 136 bytes and run 2.3x slower: measured, dropped)
 __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, const T* __restrict__ yraw, int ldyr,
                                                     const float* __restrict__ c1, const float* __restrict__ c2p,
                                                     const float* __restrict__ c3, const T* __restrict__ x, int ldx,
