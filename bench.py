@@ -16,6 +16,7 @@ import argparse
 import collections
 import json
 import os
+import re
 import sys
 import time
 
@@ -64,7 +65,7 @@ def build(model_name, dtype, batch, seed):
 def algorithmic_bytes(tag_name, tag, itemsize):
     """Algorithmic bytes of one launch from its shape tag (DESIGN.md 'roofline accounting'):
     depthwise fwd reads X writes Y; depthwise bwd reads X and dY, writes dX; gemm_nt reads A writes C; gemm_tn reads U, V."""
-    f = dict(kv.lstrip("MNHCKksUV") and (kv.rstrip("0123456789"), int("".join(ch for ch in kv if ch.isdigit()))) for kv in tag.split() if any(c.isdigit() for c in kv) and not kv.startswith("pro") and not kv.startswith("st"))
+    f = {k: int(v) for k, v in re.findall(r"([A-Za-z]+)(\d+)", tag)}   # "M802816 N24 K432 pro1 st1", "N256 H56 C144 k7 s1", ...
     if tag_name.startswith("atomnas_dwconv"):
         N, H, C, k, s = f["N"], f["H"], f["C"], f["k"], f["s"]
         Ho = (H - 1) // s + 1
