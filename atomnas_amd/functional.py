@@ -53,9 +53,15 @@ def _f32(n, dev, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
 
 
-def _stats(c, dev):
-    """zeroed statistics buffer [STAT_ROWS][2][c]"""
-    return torch.zeros(ops.STAT_ROWS * 2 * c, dtype=torch.float32, device=dev)
+def _stats(c, dev, mgr=None):
+    """Zeroed [STAT_ROWS][2][c] partial-row statistics buffer.  With a manager it is a slice of the per-step workspace that one
+    memset clears at the top-level forward (134 separate fill launches per step otherwise)."""
+    n = ops.STAT_ROWS * 2 * c
+    if mgr is not None:
+        v = mgr.take_stats(n)
+        if v is not None:
+            return v
+    return torch.zeros(n, dtype=torch.float32, device=dev)
 
 
 # ---------------------------------------------------------------------------------------------- batch norm helpers
@@ -117,14 +123,14 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     if pl.expand:
         bs = bn_uses_batch_stats(pl.bne)
         E = torch.empty(M, HT, dtype=T, device=dev)
-        stE = _stats(HT, dev) if bs else None
+        stE = _stats(HT, dev, pl.bne["mgr"]) if bs else None
         ops.gemm_nt(x2d, pl.We_pack, E, M, HT, pl.inp, stats=stE, stat_mode=STAT_SQ if bs else 0)
         bE = bn_forward_coeffs(pl.bne, stE, M, dev)
     else:
         E, bE = x2d, None
     bsd = bn_uses_batch_stats(pl.bnd)
     D = torch.empty(M2, HT, dtype=T, device=dev)
-    stD = _stats(HT, dev) if bsd else None
+    stD = _stats(HT, dev, pl.bnd["mgr"]) if bsd else None
     for i in range(pl.nb):
         o, c = pl.seg[i], pad8(pl.hid[i])
         xin = E[:, o:] if pl.expand else E
@@ -133,7 +139,7 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     bD = bn_forward_coeffs(pl.bnd, stD, M2, dev)
     bsp = bn_uses_batch_stats(pl.bnp)
     Pr = torch.empty(M2, pl.oup, dtype=T, device=dev)
-    stP = _stats(pl.oup, dev) if bsp else None
+    stP = _stats(pl.oup, dev, pl.bnp["mgr"]) if bsp else None
     ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=int(act), stats=stP,
                 stat_mode=STAT_SQ if bsp else 0)
     bP = bn_forward_coeffs(pl.bnp, stP, M2, dev)
@@ -153,7 +159,7 @@ def block_backward(pl, sv, G):
     HT, s, act = pl.HT, pl.stride, pl.act
     x2d, E, D, Pr, bE, bD, bP = sv["x"], sv["E"], sv["D"], sv["P"], sv["bE"], sv["bD"], sv["bP"]
     # shared pw_bn backward: statistics pass over (G, P), then coefficients
-    st2P = _stats(pl.oup, dev)
+    st2P = _stats(pl.oup, dev, pl.bnp["mgr"])
     ops.act_bwd_stats(G, Pr, None, None, False, None, st2P, M2, pl.oup)
     p1, p2, p3 = bn_backward_coeffs(pl.bnp, bP, st2P, M2, dev)
     # projection weight gradient: dWp[n][k] = sum_m dP[m][n] * act(bn(D))[m][k]
@@ -161,14 +167,14 @@ def block_backward(pl, sv, G):
                 vc1=bD.scale, vc2=bD.shift, v_relu=int(act))
     # projection input gradient, masked by the depthwise ReLU, with the depthwise-BN backward statistics
     g = torch.empty(M2, HT, dtype=T, device=dev)
-    st2D = _stats(HT, dev)
+    st2D = _stats(HT, dev, pl.bnd["mgr"])
     ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
                 zshift=bD.shift, mask=int(act), stats=st2D, stat_mode=STAT_Z)
     d1, d2, d3 = bn_backward_coeffs(pl.bnd, bD, st2D, M2, dev)
     # depthwise backward per branch
     if pl.expand:
         h = torch.empty(M, HT, dtype=T, device=dev)
-        st2E = _stats(HT, dev)
+        st2E = _stats(HT, dev, pl.bne["mgr"])
     else:
         h = torch.zeros(M, pl.inp, dtype=T, device=dev) if pl.nb > 1 else torch.empty(M, pl.inp, dtype=T, device=dev)
         st2E = None
@@ -261,7 +267,7 @@ def convbn_forward(pl, x, need_grad):
     bs = bn_uses_batch_stats(pl.bn)
     Cp = pad8(pl.cout)
     Y = torch.empty(M, Cp, dtype=T, device=dev) if sv["kind"] != "dw" else torch.zeros(M, Cp, dtype=T, device=dev)
-    st = _stats(pl.cout, dev) if bs else None
+    st = _stats(pl.cout, dev, pl.bn["mgr"]) if bs else None
     if sv["kind"] == "dw":
         ops.dwconv_fwd(a2d, None, None, 0, pl.taps, Y, st, pl.cout, N, H, W, pl.cout, pl.k, pl.stride)
     else:
@@ -281,7 +287,7 @@ def convbn_backward(pl, sv, G, need_input_grad):
     act = pl.act
     Y, b, a2d = sv["Y"], sv["b"], sv["a"]
     g = torch.empty_like(Y)
-    st2 = _stats(pl.cout, dev)
+    st2 = _stats(pl.cout, dev, pl.bn["mgr"])
     ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, int(act), g, st2, M, pl.cout)
     c1, c2, c3 = bn_backward_coeffs(pl.bn, b, st2, M, dev)
     if sv["kind"] == "dw":
@@ -339,7 +345,7 @@ def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
     act = lp.act
     bs = bn_uses_batch_stats(lp.bn)
     L = torch.empty(M, lp.cout, dtype=T, device=dev)
-    st = _stats(lp.cout, dev) if bs else None
+    st = _stats(lp.cout, dev, lp.bn["mgr"]) if bs else None
     ops.gemm_nt(a2d, lp.W_pack, L, M, lp.cout, lp.cin, stats=st, stat_mode=STAT_SQ if bs else 0)
     b = bn_forward_coeffs(lp.bn, st, M, dev)
     pooled = torch.empty(N, lp.cout, dtype=T, device=dev)
@@ -375,7 +381,7 @@ def tail_backward(lp, fp, sv, dlogits):
     # dropout + average pool + ReLU backward, with the last BN's backward statistics
     L, b = sv["L"], sv["b"]
     gL = torch.empty(M, lp.cout, dtype=T, device=dev)
-    st2 = _stats(lp.cout, dev)
+    st2 = _stats(lp.cout, dev, lp.bn["mgr"])
     ops.pool_act_bwd(dpooled, sv["keep"], sv["p"], L, b.scale, b.shift, int(act), gL, st2, N, HW, lp.cout)
     c1, c2, c3 = bn_backward_coeffs(lp.bn, b, st2, M, dev)
     ops.gemm_tn(sv["a"], lp.cin, gL, lp.cout, lp.W_grad, 1, lp.cin, M, v_mode=PRO_BNBWD, v2=L, vc1=c1, vc2=c2, vc3=c3)

@@ -80,6 +80,7 @@ class ArenaManager:
         self.optimizers = []
         self.emas = []
         self.P = self.G = self.SQ = self.BUF = self.EMA = self.S = self.SEMA = self.CNT = None
+        self._stats_ws, self._stats_off, self._stats_need = None, 0, 0
         self.version = 0
         self.param_slots = collections.OrderedDict()  # name -> (off, shape, strides) of every nn.Parameter
         self.compute_dtype = getattr(model, "compute_dtype", torch.bfloat16)
@@ -507,11 +508,33 @@ class ArenaManager:
 
     # Outermost module call: refresh packed weights on entry; on exit bump every BN's num_batches_tracked once if any BN
     # ran with batch statistics (all BNs of the model share their mode in the reference's train / calibration phases).
+    # ---- per-step statistics workspace: every BatchNorm use of a step (forward and backward) takes a distinct, zeroed slice;
+    # one memset at the top-level forward replaces one fill launch per use.  A slice is dead as soon as its finalize kernel
+    # has run, so resetting at the next top-level forward is safe even when a backward is still pending.
+    def take_stats(self, n):
+        n = (n + 63) // 64 * 64
+        off = self._stats_off
+        self._stats_off = off + n
+        self._stats_need = max(self._stats_need, self._stats_off)
+        ws = self._stats_ws
+        if ws is None or off + n > ws.numel():
+            return None    # first steps: the caller allocates; the workspace is sized at the next top-level forward
+        return ws[off:off + n]
+
+    def _reset_stats(self):
+        ws = self._stats_ws
+        if self._stats_need > (ws.numel() if ws is not None else 0):
+            self._stats_ws = torch.zeros(int(self._stats_need * 1.25) // 64 * 64 + 64, dtype=torch.float32, device=self.device)
+        elif ws is not None:
+            ws.zero_()
+        self._stats_off = 0
+
     def enter(self):
         self.ensure()
         if self._depth == 0:
             self.pack()
             self.bn_trained = False
+            self._reset_stats()
         self._depth += 1
 
     def leave(self):
