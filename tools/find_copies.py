@@ -13,5 +13,6 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 rows = prof.key_averages()
 rows = sorted(rows, key=lambda r: -r.count)
-for r in rows[:25]:
+for r in rows:
+    if r.count < 20 and not any(w in r.key.lower() for w in ("memcpy", "copy", "memset")): continue
     print("%6d  %-60s cpu %.1f us  cuda %.1f us" % (r.count, r.key[:60], r.cpu_time_total, getattr(r, "device_time_total", getattr(r, "cuda_time_total", 0))))
