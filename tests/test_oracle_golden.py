@@ -36,13 +36,14 @@ def _spec_of(kw):
                 dropout=kw.get("dropout_ratio", 0.2), act=kw["active_fn"], pool=kw["input_size"] // 32, num_classes=kw["num_classes"])
 
 
-def test_blocks_forward_backward_eval():
-    g = load("blocks.pt")
+@pytest.mark.parametrize("fixture,act", [("blocks.pt", "nn.ReLU"), ("blocks_relu6.pt", "nn.ReLU6")])
+def test_blocks_forward_backward_eval(fixture, act):
+    g = load(fixture)
     for name, b in g.items():
         cfg = b["cfg"]
         blk = dict(name="blk", inp=cfg["inp"], oup=cfg["oup"], stride=cfg["stride"], expand=cfg["expand"], channels=cfg["channels"],
                    ks=cfg["ks"], res=cfg["stride"] == 1 and cfg["inp"] == cfg["oup"])
-        spec = dict(eps=1e-3, momentum=0.01, act="nn.ReLU")
+        spec = dict(eps=1e-3, momentum=0.01, act=act)
         work = {"blk." + k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.clone()) for k, v in b["sd"].items()}
         x = b["x"].clone().requires_grad_(True)
         stats = {}

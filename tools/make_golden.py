@@ -96,6 +96,32 @@ def g_blocks():
     torch.save(out, os.path.join(OUT, "blocks.pt"))
 
 
+def g_blocks_relu6():
+    """ReLU6 (the MobileNetV2 baseline of apps/mobilenet): BN scales x4 so that the upper clamp is active in forward and backward."""
+    out = {}
+    cfgs = [dict(inp=8, oup=8, stride=1, channels=[16, 16, 16], ks=[3, 5, 7], expand=True),
+            dict(inp=8, oup=12, stride=2, channels=[12, 20, 7], ks=[3, 5, 7], expand=True)]
+    for ci, cfg in enumerate(cfgs):
+        blk = mb.InvertedResidualChannels(cfg["inp"], cfg["oup"], cfg["stride"], cfg["channels"], cfg["ks"], cfg["expand"],
+                                          active_fn=mb.get_active_fn("nn.ReLU6"), batch_norm_kwargs={"momentum": 0.01, "eps": 1e-3})
+        randomize(blk, 40 + 10 * ci)
+        with torch.no_grad():
+            for n, p in blk.named_parameters():
+                if p.dim() == 1 and "bias" not in n:
+                    p.mul_(4.0)
+        blk = blk.double().train()
+        sd0 = sd_of(blk)
+        x = (counter_fill(torch.empty(3, cfg["inp"], 14, 14), 177 + ci) * 4).requires_grad_(True)
+        y = blk(x)
+        gout = counter_fill(y.detach(), 199 + ci) * 2
+        y.backward(gout)
+        out["block%d" % ci] = dict(cfg=cfg, sd=sd0, x=x.detach(), out=y.detach(), gout=gout, dx=x.grad.clone(),
+                                   grads={n: p.grad.clone() for n, p in blk.named_parameters()}, sd_after=sd_of(blk))
+        blk.eval()
+        out["block%d" % ci]["out_eval"] = blk(x.detach()).detach()
+    torch.save(out, os.path.join(OUT, "blocks_relu6.pt"))
+
+
 def g_train_steps():
     """Two iterations of the reference's loop body (train.py:165-236) on the tiny supernet, single process."""
     model = ms.Model(**TINY)
@@ -259,7 +285,13 @@ def g_full_supernet():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = sys.argv[1:]   # e.g. `python tools/make_golden.py blocks_relu6` regenerates one fixture and leaves the others alone
+    if only:
+        for name in only:
+            globals()["g_" + name]()
+        sys.exit(0)
     g_blocks()
+    g_blocks_relu6()
     g_train_steps()
     g_shrink()
     g_tables()
