@@ -195,3 +195,18 @@ def test_product_never_imports_the_oracle():
                 assert "atomnas_oracle" not in src and "import oracle" not in src, os.path.join(base, f)
     for f in ("train.py", "common.py"):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_e2e_test_config_resolves_on_cpu(tmp_path):
+    """The config of the GPU entry-point test (tests/test_train_entry_gpu.py) must load without a GPU: include chain, dotted
+    overrides and environment expansion."""
+    os.environ["ATOMNAS_E2E_DIR"] = str(tmp_path)
+    os.environ.setdefault("ARNOLD_OUTPUT", str(tmp_path))
+    os.environ.setdefault("DATA_LMDB", "/tmp/none")
+    from atomnas_amd.utils import config
+    flags = config.load_app(["app:" + os.path.join(ROOT, "tests", "data", "tiny_search.yml")])
+    assert flags.num_epochs == 2 and flags.max_steps_per_epoch == 3 and flags.per_gpu_batch_size == 8
+    assert flags.log_dir == str(tmp_path) and flags.use_distributed is False
+    assert flags.prune_params.method == "network_slimming" and flags.prune_params.rho == 1e-4
+    assert flags.model_kwparams.active_fn == "nn.ReLU" and flags.model_kwparams.batch_norm_momentum == 0.01
+    assert flags.resume == "" and flags.optimizer == "rmsprop"
