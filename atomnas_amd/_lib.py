@@ -13,31 +13,29 @@ vp, i32, i64, f32, f64, u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, cty
 
 # name -> argument ctypes (all return int status)
 SIGNATURES = {
-    "atomnas_dwconv_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "atomnas_dwconv_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
-                           i32, i32, i32, i32, vp],
+    "atomnas_dwconv_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "atomnas_dwconv_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32,
+                           i32, i32, i32, i32, i32, vp],
     "atomnas_pw_gemm_nt": [i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp,
-                           vp, i32, i64, i32, i32, i32, vp],
+                           vp, i32, i32, i64, i32, i32, i32, vp],
     "atomnas_pw_gemm_tn": [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i64,
-                           i64, i64, i32, vp],
-    "atomnas_bn_finalize_fwd": [vp, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+                           i64, i64, vp, i64, i32, vp],
+    "atomnas_bn_finalize_fwd": [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
-    "atomnas_bn_finalize_bwd": [vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "atomnas_bn_finalize_bwd": [vp, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "atomnas_bn_apply": [vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
     "atomnas_bn_act_pool": [vp, i32, vp, vp, i32, vp, i32, vp, f32, u64, vp, i32, i32, i32, i32, vp],
-    "atomnas_pool_act_bwd": [vp, i32, vp, f32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
-    "atomnas_act_bwd_stats": [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i64, i32, i32, vp],
+    "atomnas_pool_act_bwd": [vp, i32, vp, f32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "atomnas_act_bwd_stats": [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
     "atomnas_im2col_stem": [vp, vp, i32, i32, i32, i32, i32, vp],
-    "atomnas_ce_smooth": [vp, i32, vp, f32, i32, i32, vp, vp, vp, i32, f32, vp, i32, vp],
+    "atomnas_ce_smooth": [vp, i32, vp, f32, i32, i32, vp, vp, i32, f32, vp, i32, vp],
     "atomnas_colsum": [vp, i32, vp, i64, i32, i32, vp],
     "atomnas_fused_rmsprop_ema": [vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, i32, f64, vp],
     "atomnas_ema_update": [vp, vp, i64, vp, vp],
-    "atomnas_weighted_norm": [vp, vp, i64, i32, vp, vp],
     "atomnas_reg_grad": [vp, vp, vp, i32, i32, vp, vp, vp],
-    "atomnas_reg_value": [vp, vp, i32, i32, vp, f32, vp, vp],
+    "atomnas_reg_value": [vp, vp, i32, i32, vp, f32, vp, vp, vp],
     "atomnas_pack_weights": [vp, vp, vp, i32, i32, vp],
     "atomnas_gamma_mask": [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp],
-    "atomnas_channel_repack": [vp, vp, i32, vp, i32, vp, vp],
     "atomnas_mask_index": [vp, i32, vp, vp, vp],
     "atomnas_gather_dim": [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp],
 }

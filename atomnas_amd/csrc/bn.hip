@@ -10,30 +10,54 @@
 
 namespace atomnas {
 
-__global__ void k_bn_finalize_fwd(const float* __restrict__ stats, float inv_count, float unbias, const float* __restrict__ gamma,
+// Sums the partial rows of one channel in a fixed order: the 256 threads of a block are 32 channels x 8 row groups; row group
+// rg adds rows rg, rg+8, ... with four independent accumulators, the eight group sums are combined in order 0..7.
+// Returns the totals of both planes to the threads with rg == 0 (other threads get garbage they must not use).
+__device__ __forceinline__ void stat_row_sum(const float* __restrict__ stats, int rows, int C, int c, int rg, int cl, float (&s_red)[2][8][32],
+                                             float& t0, float& t1) {
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (c < C) {
+    int r = rg;
+    for (; r + 8 < rows; r += 16) {
+      a0 += stats[(long)r * 2 * C + c];
+      b0 += stats[(long)r * 2 * C + C + c];
+      a1 += stats[(long)(r + 8) * 2 * C + c];
+      b1 += stats[(long)(r + 8) * 2 * C + C + c];
+    }
+    if (r < rows) {
+      a0 += stats[(long)r * 2 * C + c];
+      b0 += stats[(long)r * 2 * C + C + c];
+    }
+  }
+  s_red[0][rg][cl] = a0 + a1;
+  s_red[1][rg][cl] = b0 + b1;
+  __syncthreads();
+  t0 = s_red[0][0][cl];
+  t1 = s_red[1][0][cl];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) {
+    t0 += s_red[0][g][cl];
+    t1 += s_red[1][g][cl];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ stats, int rows, float inv_count, float unbias,
+                                  const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                   float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ scale,
                                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int C,
                                   int Cpad) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cpad) return;
+  __shared__ float s_red[2][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a0, a1;
+  stat_row_sum(stats, rows, C, c, rg, cl, s_red, a0, a1);
+  if (rg != 0 || c >= Cpad) return;
   if (c >= C) {  // padding lanes of the channel vectors stay neutral
     scale[c] = 0.f; shift[c] = 0.f;
     if (save_mean) { save_mean[c] = 0.f; save_invstd[c] = 0.f; }
     return;
   }
-  float p0[8], p1[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) p0[u] = p1[u] = 0.f;
-  for (int r = 0; r < STAT_ROWS; r += 8) {  // partial rows, see common.h; 16 independent loads in flight
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      p0[u] += stats[(long)(r + u) * 2 * C + c];
-      p1[u] += stats[(long)(r + u) * 2 * C + C + c];
-    }
-  }
-  const float a0 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]));
-  const float a1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]));
   const float mean = a0 * inv_count;
   float var = a1 * inv_count - mean * mean;
   var = fmaxf(var, 0.f);
@@ -65,26 +89,19 @@ __global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* _
 
 // stats2 = [sum g, sum g*x];  dgamma = invstd*(sum g*x - mean*sum g), dbeta = sum g,
 // dx = c1*g + c2*x + c3 with c1 = gamma*invstd, c2 = -gamma*invstd^2*dgamma/M, c3 = gamma*invstd*(mean*invstd*dgamma - dbeta)/M
-__global__ void k_bn_finalize_bwd(const float* __restrict__ stats2, float inv_count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ stats2, int rows, float inv_count,
+                                  const float* __restrict__ gamma,
                                   const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                   const float* __restrict__ rho_ptr, const float* __restrict__ penalty, float* __restrict__ dgamma,
                                   float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
                                   int C, int Cpad) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cpad) return;
+  __shared__ float s_red[2][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float sg, sgx;
+  stat_row_sum(stats2, rows, C, c, rg, cl, s_red, sg, sgx);
+  if (rg != 0 || c >= Cpad) return;
   if (c >= C) { c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
-  float p0[8], p1[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) p0[u] = p1[u] = 0.f;
-  for (int r = 0; r < STAT_ROWS; r += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      p0[u] += stats2[(long)(r + u) * 2 * C + c];
-      p1[u] += stats2[(long)(r + u) * 2 * C + C + c];
-    }
-  }
-  const float sg = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]));
-  const float sgx = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]));
   const float mean = save_mean[c], r = save_invstd[c];
   const float g = gamma ? gamma[c] : 1.f;
   const float dg = r * (sgx - mean * sg);
@@ -194,13 +211,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_pool_act_bwd(const T* __restrict__ dpooled, int ldp, const unsigned char* __restrict__ keep,
                                                       float drop_p, const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu, T* __restrict__ g, int ldg,
-                                                      float* __restrict__ stats2, int N, int HW, int C) {
-  __shared__ float s_red[32 * 8 * 2];
+                                                      float* __restrict__ stats2, int stat_rows, int N, int HW, int C) {
+  __shared__ float s_red[8][512];   // [pixel lane][channel of the block][2]: combined in pixel-lane order (no atomics)
   const int tid = threadIdx.x;
   const int cgl = tid & 31, pl = tid >> 5;
   const int c0 = (blockIdx.y * 32 + cgl) * 8;
-  for (int i = tid; i < 512; i += 256) s_red[i] = 0.f;
-  __syncthreads();
   float s0[8], s1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
@@ -230,21 +245,24 @@ __global__ __launch_bounds__(256) void k_pool_act_bwd(const T* __restrict__ dpoo
       }
       VecIO<T, 8>::store(g + p * ldg + c0, o);
     }
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(&s_red[(cgl * 8 + e) * 2], s0[e]);
-      atomicAdd(&s_red[(cgl * 8 + e) * 2 + 1], s1[e]);
-    }
+  for (int e = 0; e < 8; ++e) {
+    s_red[pl][(cgl * 8 + e) * 2] = s0[e];
+    s_red[pl][(cgl * 8 + e) * 2 + 1] = s1[e];
   }
   __syncthreads();
   if (stats2) {
-    for (int i = tid; i < 256; i += 256) {
-      const int c = blockIdx.y * 256 + i;
-      if (c < C) {
-        float* srow = stats2 + (long)(blockIdx.x % STAT_ROWS) * 2 * C;
-        atomicAdd(&srow[c], s_red[i * 2]);
-        atomicAdd(&srow[C + c], s_red[i * 2 + 1]);
-      }
+    const int c = blockIdx.y * 256 + tid;
+    if (c < C) {
+      float a = s_red[0][tid * 2], b = s_red[0][tid * 2 + 1];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) { a += s_red[q][tid * 2]; b += s_red[q][tid * 2 + 1]; }
+      float* srow = stats2 + (long)blockIdx.x * 2 * C;   // one row per workgroup column (gridDim.x <= stat_rows)
+      srow[c] = a;
+      srow[C + c] = b;
+      stat_zero_tail(stats2, 2L * C, blockIdx.x + gridDim.x, gridDim.x, stat_rows, c);
+      stat_zero_tail(stats2, 2L * C, blockIdx.x + gridDim.x, gridDim.x, stat_rows, C + c);
     }
   }
 }
@@ -253,13 +271,12 @@ __global__ __launch_bounds__(256) void k_pool_act_bwd(const T* __restrict__ dpoo
 template <typename T>
 __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                       T* __restrict__ g, int ldg, float* __restrict__ stats2, long M, int C) {
-  __shared__ float s_red[512];
+                                                       T* __restrict__ g, int ldg, float* __restrict__ stats2, int stat_rows, long M,
+                                                       int C) {
+  __shared__ float s_red[8][512];   // see k_pool_act_bwd
   const int tid = threadIdx.x;
   const int cgl = tid & 31, pl = tid >> 5;
   const int c0 = (blockIdx.y * 32 + cgl) * 8;
-  for (int i = tid; i < 512; i += 256) s_red[i] = 0.f;
-  __syncthreads();
   float s0[8], s1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
@@ -284,21 +301,24 @@ __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy,
       }
       if (g) VecIO<T, 8>::store(g + p * ldg + c0, d);
     }
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(&s_red[(cgl * 8 + e) * 2], s0[e]);
-      atomicAdd(&s_red[(cgl * 8 + e) * 2 + 1], s1[e]);
-    }
+  for (int e = 0; e < 8; ++e) {
+    s_red[pl][(cgl * 8 + e) * 2] = s0[e];
+    s_red[pl][(cgl * 8 + e) * 2 + 1] = s1[e];
   }
   __syncthreads();
   if (stats2) {
-    for (int i = tid; i < 256; i += 256) {
-      const int c = blockIdx.y * 256 + i;
-      if (c < C) {
-        float* srow = stats2 + (long)(blockIdx.x % STAT_ROWS) * 2 * C;
-        atomicAdd(&srow[c], s_red[i * 2]);
-        atomicAdd(&srow[C + c], s_red[i * 2 + 1]);
-      }
+    const int c = blockIdx.y * 256 + tid;
+    if (c < C) {
+      float a = s_red[0][tid * 2], b = s_red[0][tid * 2 + 1];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) { a += s_red[q][tid * 2]; b += s_red[q][tid * 2 + 1]; }
+      float* srow = stats2 + (long)blockIdx.x * 2 * C;
+      srow[c] = a;
+      srow[C + c] = b;
+      stat_zero_tail(stats2, 2L * C, blockIdx.x + gridDim.x, gridDim.x, stat_rows, c);
+      stat_zero_tail(stats2, 2L * C, blockIdx.x + gridDim.x, gridDim.x, stat_rows, C + c);
     }
   }
 }
@@ -307,16 +327,16 @@ __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy,
 
 using namespace atomnas;
 
-extern "C" int atomnas_bn_finalize_fwd(const float* stats, double count, const float* gamma, const float* beta, float eps,
+extern "C" int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, double count, const float* gamma, const float* beta, float eps,
                                        float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
                                        float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
-  ATOMNAS_REQUIRE(stats && scale && shift && C > 0 && count > 0, "bn_finalize_fwd: bad arguments");
+  ATOMNAS_REQUIRE(stats && stat_rows > 0 && scale && shift && C > 0 && count > 0, "bn_finalize_fwd: bad arguments");
   ATOMNAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_fwd: running stats must come together");
   ATOMNAS_REQUIRE(!(momentum < 0.f && running_mean) || num_batches_tracked, "bn_finalize_fwd: cumulative mode needs the batch counter");
   const int Cpad = (C + 7) / 8 * 8;
   const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 63) / 64), dim3(64), 0, st, stats, (float)(1.0 / count), unbias, gamma, beta,
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 31) / 32), dim3(256), 0, st, stats, stat_rows, (float)(1.0 / count), unbias, gamma, beta,
                      eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C, Cpad);
   return check_launch("bn_finalize_fwd");
 }
@@ -330,12 +350,12 @@ extern "C" int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, con
   return check_launch("bn_eval_coeffs");
 }
 
-extern "C" int atomnas_bn_finalize_bwd(const float* stats2, double count, const float* gamma, const float* save_mean,
+extern "C" int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, double count, const float* gamma, const float* save_mean,
                                        const float* save_invstd, const float* rho_ptr, const float* penalty, float* dgamma,
                                        float* dbeta, float* c1, float* c2, float* c3, int C, void* stream) {
-  ATOMNAS_REQUIRE(stats2 && save_mean && save_invstd && c1 && c2 && c3 && C > 0 && count > 0, "bn_finalize_bwd: bad arguments");
+  ATOMNAS_REQUIRE(stats2 && stat_rows > 0 && save_mean && save_invstd && c1 && c2 && c3 && C > 0 && count > 0, "bn_finalize_bwd: bad arguments");
   const int Cpad = (C + 7) / 8 * 8;
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats2, (float)(1.0 / count),
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 31) / 32), dim3(256), 0, (hipStream_t)stream, stats2, stat_rows, (float)(1.0 / count),
                      gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, Cpad);
   return check_launch("bn_finalize_bwd");
 }
@@ -375,37 +395,41 @@ extern "C" int atomnas_bn_act_pool(const void* x, int ldx, const float* scale, c
 }
 
 extern "C" int atomnas_pool_act_bwd(const void* dpooled, int ldp, const unsigned char* keep, float drop_p, const void* x, int ldx,
-                                    const float* scale, const float* shift, int relu, void* g, int ldg, float* stats2, int N, int HW,
-                                    int C, int dtype, void* stream) {
+                                    const float* scale, const float* shift, int relu, void* g, int ldg, float* stats2, int stat_rows,
+                                    int N, int HW, int C, int dtype, void* stream) {
   ATOMNAS_REQUIRE(dpooled && x && g && scale && shift && N > 0 && HW > 0 && C > 0, "pool_act_bwd: bad arguments");
   ATOMNAS_REQUIRE(ldx % 8 == 0 && ldp % 8 == 0 && ldg % 8 == 0 && ldx >= C && ldp >= C && ldg >= C, "pool_act_bwd: bad pitch");
+  ATOMNAS_REQUIRE(!stats2 || stat_rows > 0, "pool_act_bwd: statistics need stat_rows > 0");
   long gx = ((long)N * HW + 7) / 8;
   if (gx > 1024) gx = 1024;
+  if (stats2 && gx > stat_rows) gx = stat_rows;
   dim3 grid((unsigned)gx, (C + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32)
     hipLaunchKernelGGL(k_pool_act_bwd<float>, grid, dim3(256), 0, st, (const float*)dpooled, ldp, keep, drop_p, (const float*)x, ldx,
-                       scale, shift, relu, (float*)g, ldg, stats2, N, HW, C);
+                       scale, shift, relu, (float*)g, ldg, stats2, stat_rows, N, HW, C);
   else
     hipLaunchKernelGGL(k_pool_act_bwd<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dpooled, ldp, keep, drop_p, (const bf16_t*)x,
-                       ldx, scale, shift, relu, (bf16_t*)g, ldg, stats2, N, HW, C);
+                       ldx, scale, shift, relu, (bf16_t*)g, ldg, stats2, stat_rows, N, HW, C);
   return check_launch("pool_act_bwd");
 }
 
 extern "C" int atomnas_act_bwd_stats(const void* dy, int lddy, const void* z, int ldz, const float* scale, const float* shift,
-                                     int relu, void* g, int ldg, float* stats2, long M, int C, int dtype, void* stream) {
+                                     int relu, void* g, int ldg, float* stats2, int stat_rows, long M, int C, int dtype, void* stream) {
   ATOMNAS_REQUIRE(dy && z && M > 0 && C > 0, "act_bwd_stats: bad arguments");
   ATOMNAS_REQUIRE(lddy % 8 == 0 && ldz % 8 == 0 && lddy >= C && ldz >= C && (!g || (ldg % 8 == 0 && ldg >= C)), "act_bwd_stats: bad pitch");
   ATOMNAS_REQUIRE((scale == nullptr) == (shift == nullptr), "act_bwd_stats: scale/shift must come together");
+  ATOMNAS_REQUIRE(!stats2 || stat_rows > 0, "act_bwd_stats: statistics need stat_rows > 0");
   long gx = (M + 7) / 8;
   if (gx > 1024) gx = 1024;
+  if (stats2 && gx > stat_rows) gx = stat_rows;
   dim3 grid((unsigned)gx, (C + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32)
     hipLaunchKernelGGL(k_act_bwd_stats<float>, grid, dim3(256), 0, st, (const float*)dy, lddy, (const float*)z, ldz, scale, shift,
-                       relu, (float*)g, ldg, stats2, M, C);
+                       relu, (float*)g, ldg, stats2, stat_rows, M, C);
   else
     hipLaunchKernelGGL(k_act_bwd_stats<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)z, ldz, scale, shift,
-                       relu, (bf16_t*)g, ldg, stats2, M, C);
+                       relu, (bf16_t*)g, ldg, stats2, stat_rows, M, C);
   return check_launch("act_bwd_stats");
 }

@@ -16,10 +16,16 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
 
-// Per-channel statistics are accumulated into STAT_ROWS partial rows ([STAT_ROWS][2][pitch], zero-initialised) that the
-// BatchNorm finalize kernels sum: atomics on ONE address from thousands of workgroups serialise at ~350 ns each on
-// MI355X (device-scope atomics resolve at the memory side), which cost 10x the kernel itself before the rows were split.
-constexpr int STAT_ROWS = 64;
+// Per-channel statistics leave a kernel as PARTIAL ROWS: a buffer [stat_rows][2][pitch] in which every workgroup (or wave)
+// that reduces a channel range owns one row and writes it with plain stores -- no atomics, so the result does not depend on
+// arrival order and a training step is bit-reproducible (and same-address atomics from thousands of workgroups serialise at
+// ~350 ns each on MI355X).  A producer that uses R < stat_rows rows zero-fills rows R..stat_rows-1 of its channel range
+// (stat_zero_tail), so the buffer needs no initialisation and the BatchNorm finalize kernels sum all stat_rows rows in a
+// fixed order.
+__device__ __forceinline__ void stat_zero_tail(float* __restrict__ stats, long row_stride, int first_row, int row_step, int stat_rows,
+                                               long elem) {
+  for (int r = first_row; r < stat_rows; r += row_step) stats[(long)r * row_stride + elem] = 0.f;
+}
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
@@ -138,6 +144,12 @@ template <typename KernelT>
 static inline int resident_per_cu(KernelT kern, int threads, size_t lds) {
   return resident_per_cu_raw((const void*)kern, threads, lds);
 }
+
+// Fixed-order reduction of per-workgroup partial results (weight gradients):
+//   out[(e / inner) * s_outer + (e % inner) * s_inner] += sum_{r < parts} part[r * part_stride + e]   for e < n
+// The order of the additions depends only on (parts, n): bit-reproducible, unlike atomic accumulation.
+int reduce_parts(const float* part, long part_stride, int parts, long n, float* out, int inner, long s_outer, long s_inner,
+                 hipStream_t st);
 
 #define ATOMNAS_REQUIRE(cond, ...)            \
   do {                                        \

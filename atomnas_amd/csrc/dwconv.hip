@@ -130,7 +130,7 @@ template <typename T, int K, int S, int SW, int CB, int TM, bool R6>
 __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int ldx, const float* __restrict__ in_scale,
                                                     const float* __restrict__ in_shift, int in_relu,
                                                     const float* __restrict__ w, int ldw, T* __restrict__ y, int ldy,
-                                                    float* __restrict__ stats, int stat_ld, DwGeom g) {
+                                                    float* __restrict__ stats, int stat_ld, int stat_rows, DwGeom g) {
   constexpr int P = (K - 1) / 2;
   constexpr int IWS = (SW - 1) * S + K;  // input columns one strip needs
   constexpr int LMAX = (TM - 1) * S + K;                           // largest LDS tile extent for this instantiation
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;                         // [LH][RP]
   float* s_w = s_in + g.LH * g.RP;            // [K*K][CB]
-  float* s_st = s_w + K * K * CB;             // [2][CB]
+  float* s_st = s_w + K * K * CB;             // [4 waves][2][CB]: per-wave partial statistics, combined in wave order
 
   const int tid = threadIdx.x;
   constexpr int C2 = CB / 2, CG = CB / 8;
@@ -156,7 +156,6 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
     const int t = i / CB, c = i % CB;
     s_w[i] = (c_base + c < g.C) ? w[(long)t * ldw + c_base + c] : 0.f;
   }
-  for (int i = tid; i < 2 * CB; i += 256) s_st[i] = 0.f;
 
   // staging role: fixed channel group per thread (256 % CG == 0)
   const int cg = tid % CG;
@@ -312,19 +311,24 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
       ssum[0] += __shfl_xor(ssum[0], o, 64); ssum[1] += __shfl_xor(ssum[1], o, 64);
       ssq[0] += __shfl_xor(ssq[0], o, 64); ssq[1] += __shfl_xor(ssq[1], o, 64);
     }
+    // no atomics anywhere: lanes 0..C2-1 of every wave hold that wave's sums, the four waves are added in order, and the
+    // workgroup owns row `worker` of the partial-row buffer (bit-reproducible statistics)
+    __syncthreads();
     if ((tid & 63) < C2) {
-      atomicAdd(&s_st[2 * c2], ssum[0]);
-      atomicAdd(&s_st[2 * c2 + 1], ssum[1]);
-      atomicAdd(&s_st[CB + 2 * c2], ssq[0]);
-      atomicAdd(&s_st[CB + 2 * c2 + 1], ssq[1]);
+      float* sw = s_st + (tid >> 6) * 2 * CB;
+      sw[2 * c2] = ssum[0];
+      sw[2 * c2 + 1] = ssum[1];
+      sw[CB + 2 * c2] = ssq[0];
+      sw[CB + 2 * c2 + 1] = ssq[1];
     }
     __syncthreads();
-    for (int i = tid; i < CB; i += 256) {
-      const int c = c_base + i;
+    for (int i = tid; i < 2 * CB; i += 256) {
+      const int pl = i / CB, c = c_base + i % CB;
       if (c < g.C) {
-        float* srow = stats + (long)(worker % STAT_ROWS) * 2 * stat_ld;
-        atomicAdd(&srow[c], s_st[i]);
-        atomicAdd(&srow[stat_ld + c], s_st[CB + i]);
+        const float v = ((s_st[i] + s_st[2 * CB + i]) + s_st[4 * CB + i]) + s_st[6 * CB + i];
+        const long elem = (long)pl * stat_ld + c;
+        stats[(long)worker * 2 * stat_ld + elem] = v;
+        stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, elem);
       }
     }
   }
@@ -341,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
                                                     const float* __restrict__ c3, const T* __restrict__ x, int ldx,
                                                     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                     int in_relu, const float* __restrict__ w, int ldw, T* __restrict__ h, int ldh,
-                                                    float* __restrict__ dw /*[C][K*K]*/, float* __restrict__ stats, int stat_ld,
-                                                    DwGeom g) {
+                                                    float* __restrict__ dwp /*[nworkers][C][K*K] partial weight gradients*/,
+                                                    float* __restrict__ stats, int stat_ld, int stat_rows, DwGeom g) {
   constexpr int P = (K - 1) / 2;
   constexpr int KK = K * K;
   constexpr int RELMIN = fdiv(-P, S);            // first output column (relative to strip origin / S) a strip touches
@@ -669,19 +673,25 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       s0[0] += __shfl_xor(s0[0], o, 64); s0[1] += __shfl_xor(s0[1], o, 64);
       s1[0] += __shfl_xor(s1[0], o, 64); s1[1] += __shfl_xor(s1[1], o, 64);
     }
-    if (lane < C2) {
-      float* r0 = &s_red[(2 * cc2) * (KK + 2)];
-      float* r1 = &s_red[(2 * cc2 + 1) * (KK + 2)];
+    // the four waves add their values one after the other (plain read-modify-write, distinct addresses within a wave):
+    // a fixed order instead of LDS atomics, so the result is bit-reproducible
+    for (int wv = 0; wv < 4; ++wv) {
+      if ((tid >> 6) == wv && lane < C2) {
+        float* r0 = &s_red[(2 * cc2) * (KK + 2)];
+        float* r1 = &s_red[(2 * cc2 + 1) * (KK + 2)];
 #pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        atomicAdd(&r0[t], dwa[t][0]);
-        atomicAdd(&r1[t], dwa[t][1]);
+        for (int t = 0; t < KK; ++t) {
+          r0[t] += dwa[t][0];
+          r1[t] += dwa[t][1];
+        }
+        r0[KK] += s0[0]; r0[KK + 1] += s1[0];
+        r1[KK] += s0[1]; r1[KK + 1] += s1[1];
       }
-      atomicAdd(&r0[KK], s0[0]); atomicAdd(&r0[KK + 1], s1[0]);
-      atomicAdd(&r1[KK], s0[1]); atomicAdd(&r1[KK + 1], s1[1]);
+      __syncthreads();
     }
   }
-  __syncthreads();
+  // flush: this workgroup owns row `worker` of the weight-gradient partials and of the statistics (plain stores; the
+  // partials are summed by reduce_parts, the statistics by the BatchNorm finalize kernel, both in a fixed order)
   for (int i = tid; i < CB * (KK + 2); i += 256) {
     const int cl = i / (KK + 2), t = i % (KK + 2);
     const int c = c_base + cl;
@@ -689,9 +699,11 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
     const float v = s_red[i];
     if (DW_EXP == 4) continue;
     if (t < KK) {
-      if (dw) atomicAdd(&dw[(long)c * KK + t], v);
+      if (dwp) dwp[((long)worker * g.C + c) * KK + t] = v;
     } else if (stats) {
-      atomicAdd(&stats[(long)(worker % STAT_ROWS) * 2 * stat_ld + (long)(t - KK) * stat_ld + c], v);
+      const long elem = (long)(t - KK) * stat_ld + c;
+      stats[(long)worker * 2 * stat_ld + elem] = v;
+      stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, elem);
     }
   }
 }
@@ -716,13 +728,14 @@ static void pick_tiles(DwGeom& g, int rows, int cols, int sw, int cb, int even) 
 }
 
 // Persistent grid: exactly as many workgroups as are resident at once (a partial second round of workgroups costs up to 2x).
-static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap) {
+static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap, long max_workers) {
   const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > cap) per_cu = cap;
   long want = ((long)num_cus() * per_cu) / nslabs;
   static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: force long tile walks
   if (max_env > 0 && want > max_env) want = max_env;
+  if (max_workers > 0 && want > max_workers) want = max_workers;   // every worker owns one partial row (statistics, weight gradient)
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
   g.nworkers = (int)want;
@@ -733,7 +746,7 @@ static inline unsigned dw_grid(const DwGeom& g) { return (unsigned)((g.nworkers 
 
 template <typename T, int K, int S>
 static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y,
-                      int ldy, float* stats, int stat_ld, int N, int H, int W, int C, hipStream_t st) {
+                      int ldy, float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, hipStream_t st) {
   constexpr int P = (K - 1) / 2;
   DwGeom g;
   g.N = N; g.H = H; g.W = W; g.C = C;
@@ -756,16 +769,16 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
   g.LW = (g.TW - 1) * S + K;
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
-  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 2 * cb) * sizeof(float);
+  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 8 * cb) * sizeof(float);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env = getenv("ATOMNAS_DW_FWD_PERCU") ? atoi(getenv("ATOMNAS_DW_FWD_PERCU")) : 0;
   const int cap = cap_env ? cap_env : 8;
 #define FWD_CASE(CBV, TMV)                                                                                                   \
   {                                                                                                                      \
     auto kern = (relu == ACT_RELU6) ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, true> : k_dwconv_fwd<T, K, S, 7, CBV, TMV, false>;                                                                           \
-    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap);                                                             \
+    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, stats ? stat_rows : 0);                                      \
     dim3 grid(dw_grid(g));                                                                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy, stats, stat_ld, g); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy, stats, stat_ld, stat_rows, g); \
   }
   const bool small = g.TH <= 7 && g.TW <= 7;
   if (cb == 8) { if (small) FWD_CASE(8, 7) else FWD_CASE(8, 14) }
@@ -779,7 +792,8 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
 template <typename T, int K, int S>
 static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
                       const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h,
-                      int ldh, float* dw, float* stats, int stat_ld, int N, int H, int W, int C, hipStream_t st) {
+                      int ldh, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C,
+                      hipStream_t st) {
   constexpr int P = (K - 1) / 2;
   constexpr int SW = (S == 2) ? 14 : 7;
   DwGeom g;
@@ -813,14 +827,17 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
 #define BWD_CASE(CBV)                                                                                                     \
   {                                                                                                                       \
     auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, true> : k_dwconv_bwd<T, K, S, SW, CBV, false>;                                                                           \
-    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap);                                                              \
+    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, (stats || dw) ? part_rows : 0);                               \
     dim3 grid(dw_grid(g));                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2, c3, (const T*)x, ldx, sc, \
-                       sh, relu, w, ldw, (T*)h, ldh, dw, stats, stat_ld, g);                                              \
+                       sh, relu, w, ldw, (T*)h, ldh, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g);                 \
   }
   if (cb == 8) BWD_CASE(8) else if (cb == 16) BWD_CASE(16) else BWD_CASE(32)
 #undef BWD_CASE
-  return check_launch("dwconv_bwd");
+  if (int rc = check_launch("dwconv_bwd")) return rc;
+  // dw[c][t] += sum over workers of the partials, in worker order
+  if (dw) return reduce_parts(dw_ws, (long)C * K * K, g.nworkers, (long)C * K * K, dw, C * K * K, 0, 1, st);
+  return 0;
 }
 
 #if DW_TIMING
@@ -859,8 +876,8 @@ namespace atomnas {
 using namespace atomnas;
 
 extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu,
-                                  const float* w, int ldw, void* y, int ldy, float* stats, int stat_ld, int N, int H, int W, int C,
-                                  int k, int stride, int dtype, void* stream) {
+                                  const float* w, int ldw, void* y, int ldy, float* stats, int stat_ld, int stat_rows, int N, int H, int W,
+                                  int C, int k, int stride, int dtype, void* stream) {
   ATOMNAS_REQUIRE(x && w && y, "dwconv_fwd: null pointer");
   ATOMNAS_REQUIRE((k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2), "dwconv_fwd: unsupported k=%d stride=%d", k, stride);
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_fwd: bad dtype %d", dtype);
@@ -869,16 +886,17 @@ extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale,
   ATOMNAS_REQUIRE(ldx >= cpad && ldy >= cpad && ldw >= C && ldx % 8 == 0 && ldy % 8 == 0,
                   "dwconv_fwd: bad pitch (C=%d ldx=%d ldy=%d ldw=%d)", C, ldx, ldy, ldw);
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_fwd: scale/shift must come together");
-  ATOMNAS_REQUIRE(!stats || stat_ld >= C, "dwconv_fwd: statistics pitch %d < C=%d", stat_ld, C);
+  ATOMNAS_REQUIRE(!stats || (stat_ld >= C && stat_rows > 0), "dwconv_fwd: statistics pitch %d < C=%d or stat_rows=%d", stat_ld, C, stat_rows);
   hipStream_t st = (hipStream_t)stream;
-  DW_DISPATCH(launch_fwd, x, ldx, in_scale, in_shift, in_relu, w, ldw, y, ldy, stats, stat_ld, N, H, W, C, st);
+  DW_DISPATCH(launch_fwd, x, ldx, in_scale, in_shift, in_relu, w, ldw, y, ldy, stats, stat_ld, stat_rows, N, H, W, C, st);
   return 1;
 }
 
 extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2,
                                   const float* c3, const void* x, int ldx, const float* in_scale, const float* in_shift,
-                                  int in_relu, const float* w, int ldw, void* h, int ldh, float* dw, float* stats, int stat_ld, int N,
-                                  int H, int W, int C, int k, int stride, int dtype, void* stream) {
+                                  int in_relu, const float* w, int ldw, void* h, int ldh, float* dw, float* stats, int stat_ld,
+                                  int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride, int dtype,
+                                  void* stream) {
   ATOMNAS_REQUIRE(g && x && w && h, "dwconv_bwd: null pointer");
   ATOMNAS_REQUIRE((k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2), "dwconv_bwd: unsupported k=%d stride=%d", k, stride);
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_bwd: bad dtype %d", dtype);
@@ -889,8 +907,10 @@ extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int 
   ATOMNAS_REQUIRE(!yraw || (c1 && c2 && c3 && ldyr >= cpad && ldyr % 8 == 0), "dwconv_bwd: yraw needs c1,c2,c3 and a valid pitch");
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_bwd: scale/shift must come together");
   ATOMNAS_REQUIRE(!stats || stat_ld >= C, "dwconv_bwd: statistics pitch %d < C=%d", stat_ld, C);
+  ATOMNAS_REQUIRE(!(stats || dw) || part_rows > 0, "dwconv_bwd: part_rows must be positive");
+  ATOMNAS_REQUIRE(!dw || dw_ws, "dwconv_bwd: the weight gradient needs the partial workspace dw_ws [part_rows][C][k*k]");
   hipStream_t st = (hipStream_t)stream;
   DW_DISPATCH(launch_bwd, g, ldg, yraw, ldyr, c1, c2, c3, x, ldx, in_scale, in_shift, in_relu, w, ldw, h, ldh, dw, stats, stat_ld,
-              N, H, W, C, st);
+              part_rows, dw_ws, N, H, W, C, st);
   return 1;
 }

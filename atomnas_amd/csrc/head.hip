@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_im2col_stem(const float* __restrict__ i
 template <typename T>
 __global__ __launch_bounds__(256) void k_ce_smooth(const float* __restrict__ logits, int ldl, const long long* __restrict__ target,
                                                    float eps, int B, int K, float* __restrict__ loss_per_sample,
-                                                   float* __restrict__ loss_sum, T* __restrict__ dlogits, int ldd, float gscale,
+                                                   T* __restrict__ dlogits, int ldd, float gscale,
                                                    int* __restrict__ topk_correct /*[2]: top1, top5*/) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -73,8 +73,7 @@ __global__ __launch_bounds__(256) void k_ce_smooth(const float* __restrict__ log
   const float loss = -(1.f - eps) * (xy - lse) - (eps / (float)K) * (sx - (float)K * lse);
   if (lane == 0) {
     if (loss_per_sample) loss_per_sample[b] = loss;
-    if (loss_sum) atomicAdd(loss_sum, loss);
-    if (topk_correct) {
+    if (topk_correct) {   // integer atomics: exact and order-independent
       if (rank < 1) atomicAdd(&topk_correct[0], 1);
       if (rank < 5) atomicAdd(&topk_correct[1], 1);
     }
@@ -94,14 +93,22 @@ __global__ __launch_bounds__(256) void k_ce_smooth(const float* __restrict__ log
   }
 }
 
-// column sums of a [M, C] tensor of storage type T into fp32 (classifier bias gradient)
+// column sums of a [M, C] tensor of storage type T into fp32 (classifier bias gradient): one thread per column, rows in
+// order (M is the batch size here), so the result is bit-reproducible
 template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ x, int ld, float* __restrict__ out, long M, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f;
-  for (long m = blockIdx.y; m < M; m += gridDim.y) s += to_f32(x[m * ld + c]);
-  atomicAdd(&out[c], s);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long m = 0;
+  for (; m + 3 < M; m += 4) {
+    s0 += to_f32(x[m * ld + c]);
+    s1 += to_f32(x[(m + 1) * ld + c]);
+    s2 += to_f32(x[(m + 2) * ld + c]);
+    s3 += to_f32(x[(m + 3) * ld + c]);
+  }
+  for (; m < M; ++m) s0 += to_f32(x[m * ld + c]);
+  out[c] += (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace atomnas
@@ -123,22 +130,22 @@ extern "C" int atomnas_im2col_stem(const float* img, void* col, int ld, int N, i
 }
 
 extern "C" int atomnas_ce_smooth(const float* logits, int ldl, const long long* target, float eps, int B, int K, float* loss_per_sample,
-                                 float* loss_sum, void* dlogits, int ldd, float gscale, int* topk_correct, int dtype, void* stream) {
+                                 void* dlogits, int ldd, float gscale, int* topk_correct, int dtype, void* stream) {
   ATOMNAS_REQUIRE(logits && target && B > 0 && K > 0 && ldl >= K, "ce_smooth: bad arguments");
   ATOMNAS_REQUIRE(!dlogits || ldd >= K, "ce_smooth: bad gradient pitch");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32)
     hipLaunchKernelGGL(k_ce_smooth<float>, dim3((B + 3) / 4), dim3(256), 0, st, logits, ldl, target, eps, B, K, loss_per_sample,
-                       loss_sum, (float*)dlogits, ldd, gscale, topk_correct);
+                       (float*)dlogits, ldd, gscale, topk_correct);
   else
     hipLaunchKernelGGL(k_ce_smooth<bf16_t>, dim3((B + 3) / 4), dim3(256), 0, st, logits, ldl, target, eps, B, K, loss_per_sample,
-                       loss_sum, (bf16_t*)dlogits, ldd, gscale, topk_correct);
+                       (bf16_t*)dlogits, ldd, gscale, topk_correct);
   return check_launch("ce_smooth");
 }
 
 extern "C" int atomnas_colsum(const void* x, int ld, float* out, long M, int C, int dtype, void* stream) {
   ATOMNAS_REQUIRE(x && out && M > 0 && C > 0 && ld >= C, "colsum: bad arguments");
-  dim3 grid((C + 255) / 256, (unsigned)(M < 64 ? M : 64));
+  dim3 grid((C + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32) hipLaunchKernelGGL(k_colsum<float>, grid, dim3(256), 0, st, (const float*)x, ld, out, M, C);
   else hipLaunchKernelGGL(k_colsum<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, out, M, C);

@@ -52,26 +52,6 @@ __global__ __launch_bounds__(256) void k_ema(float* __restrict__ shadow, const f
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) shadow[i] = shadow[i] * d + (1.0f - d) * x[i];
 }
 
-// sum over the arena of coef[chunk] * f(p): f = p^2 (L2 value) or |p| (L1 value); only needed for logging
-__global__ __launch_bounds__(256) void k_weighted_norm(const float* __restrict__ p, const float* __restrict__ coef_chunk, long n,
-                                                       int use_abs, float* __restrict__ out) {
-  __shared__ float s_part[4];
-  const long nchunks = (n + 255) / 256;
-  float acc = 0.f;
-  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const long i = ch * 256 + threadIdx.x;
-    if (i < n) {
-      const float c = coef_chunk[ch];
-      const float v = p[i];
-      acc += c * (use_abs ? fabsf(v) : v * v);
-    }
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
-}
-
 // Weight packing jobs.  src is fp32 in the parameter arena with logical shape [rows][cols] (row pitch src_ld).
 //   mode 0 (PW):   dst[r*dst_ld + c_off + c] = src[r][c]            (storage T)   -> gemm_nt weight  [N][K]
 //   mode 1 (PW_T): dst[(c_off + c)*dst_ld + r] = src[r][c]          (storage T)   -> gemm_nt weight of the transposed product
@@ -120,14 +100,6 @@ extern "C" int atomnas_ema_update(float* shadow, const float* x, long n, const f
   return check_launch("ema_update");
 }
 
-extern "C" int atomnas_weighted_norm(const float* p, const float* coef_chunk, long n, int use_abs, float* out, void* stream) {
-  ATOMNAS_REQUIRE(p && coef_chunk && out && n > 0, "weighted_norm: bad arguments");
-  long blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_weighted_norm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, coef_chunk, n, use_abs, out);
-  return check_launch("weighted_norm");
-}
-
 extern "C" int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream) {
   ATOMNAS_REQUIRE(arena && packbuf && jobs_dev && njobs > 0, "pack_weights: bad arguments");
   dim3 grid(32, njobs);
@@ -160,8 +132,9 @@ __global__ __launch_bounds__(256) void k_reg_grad(const float* __restrict__ p, f
   }
 }
 
+// stage 1: ws[job * 64 + block] = coef * post_scale * mult * (block's share of the job's sum), fixed order inside the block
 __global__ __launch_bounds__(256) void k_reg_value(const float* __restrict__ p, const RegJob* __restrict__ jobs, int use_abs,
-                                                   const float* __restrict__ mult_ptr, float post_scale, float* __restrict__ out) {
+                                                   const float* __restrict__ mult_ptr, float post_scale, float* __restrict__ ws) {
   __shared__ float s_part[4];
   const RegJob jb = jobs[blockIdx.y];
   float acc = 0.f;
@@ -175,8 +148,22 @@ __global__ __launch_bounds__(256) void k_reg_value(const float* __restrict__ p, 
   if (threadIdx.x == 0) {
     float m = jb.coef * post_scale;
     if (mult_ptr) m *= mult_ptr[0];
-    atomicAdd(out, m * (s_part[0] + s_part[1] + s_part[2] + s_part[3]));
+    ws[blockIdx.y * gridDim.x + blockIdx.x] = m * (((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
   }
+}
+
+// stage 2 (one workgroup): out += sum of the n stage-1 partials in a fixed order (thread t adds t, t+256, ...; then a fixed tree)
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ ws, int n, float* __restrict__ out) {
+  __shared__ float s_t[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += ws[i];
+  s_t[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_t[threadIdx.x] += s_t[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += s_t[0];
 }
 }  // namespace atomnas
 
@@ -189,11 +176,13 @@ extern "C" int atomnas_reg_grad(const float* p, float* g, const void* jobs_dev, 
   return atomnas::check_launch("reg_grad");
 }
 
-// out += post_scale * mult * sum_jobs coef * sum_i (use_abs ? |p_i| : p_i^2)
+// out += post_scale * mult * sum_jobs coef * sum_i (use_abs ? |p_i| : p_i^2);  ws: caller-owned scratch of 64 * njobs floats
+// (per-workgroup partials, summed in a fixed order: the logged regulariser values are bit-reproducible)
 extern "C" int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_abs, const float* mult_ptr,
-                                 float post_scale, float* out, void* stream) {
-  ATOMNAS_REQUIRE(p && out && jobs_dev && njobs > 0, "reg_value: bad arguments");
+                                 float post_scale, float* out, float* ws, void* stream) {
+  ATOMNAS_REQUIRE(p && out && ws && jobs_dev && njobs > 0, "reg_value: bad arguments");
   hipLaunchKernelGGL(atomnas::k_reg_value, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, p, (const atomnas::RegJob*)jobs_dev,
-                     use_abs, mult_ptr, post_scale, out);
+                     use_abs, mult_ptr, post_scale, ws);
+  hipLaunchKernelGGL(atomnas::k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, 64 * njobs, out);
   return atomnas::check_launch("reg_value");
 }

@@ -145,17 +145,19 @@ struct Epilogue {
   const void* z; int ldz;              // optional raw activation stream (storage T) for mask / STAT_Z
   const float* zscale; const float* zshift; int mask;  // mask: c *= [z*zscale+zshift > 0]
   const float* bias;                   // optional per-output-channel bias
-  float* stats; int stat_mode;         // [STAT_ROWS][2][N] fp32 partial rows, accumulated atomically
+  float* stats; int stat_mode;         // [stat_rows][2][N] fp32 partial rows: one row per workgroup row-slot, plain stores (common.h)
+  int stat_rows;
 };
 
-constexpr int NT_MAX_STAT = 8192;  // dynamic LDS [2][N] floats stays within the 64 KiB default limit
+constexpr int NT_MAX_STAT = 8192;  // widest output for which the epilogue statistics are supported
 
 // Epilogue of one 16-pixel x 64-channel accumulator tile: the lane holds channels nb .. nb+15 of pixel `row`, ordered [t][r].
 // bias, residual add, ReLU mask of the producer, rounding to the storage type, store, and the per-channel statistics
-// (reduced over the 16 pixels with cross-lane adds, then one LDS atomic per channel into s_stat[2][N]).
+// (reduced over the 16 pixels with cross-lane adds, then added by lane j == 0 into the WAVE-PRIVATE LDS row sw[2][swd] at local
+// channel nl: plain read-modify-write in program order, no atomics -- the statistics are bit-reproducible).
 template <typename T>
 __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&acc)[4], long row, bool rowvalid, int nb, int N,
-                                            bool do_stats, float* s_stat, int j) {
+                                            bool do_stats, float* sw, int swd, int nl, int j) {
   float c[16], zv[16];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -231,9 +233,24 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
         s2 += __shfl_xor(s2, o, 64);
       }
       if (j == 0 && nb + i < N) {
-        atomicAdd(&s_stat[nb + i], s1);
-        atomicAdd(&s_stat[N + nb + i], s2);
+        sw[nl + i] += s1;
+        sw[swd + nl + i] += s2;
       }
+    }
+  }
+}
+
+// Statistics flush shared by k_gemm_nt and k_gemm_nt_ws: the four wave-private rows s_stat[4][2][swd] are added in wave order and
+// stored as row `rs` of the partial-row buffer for channels nc0 .. nc0+swd-1; rows rs+R, rs+2R, ... are zero-filled.
+__device__ __forceinline__ void nt_flush_stats(const Epilogue& ep, const float* s_stat, int swd, int nc0, int N, int rs, int R, int tid) {
+  __syncthreads();
+  for (int i = tid; i < 2 * swd; i += 256) {
+    const int pl = i / swd, c = nc0 + i % swd;
+    if (c < N) {
+      const float v = ((s_stat[i] + s_stat[2 * swd + i]) + s_stat[4 * swd + i]) + s_stat[6 * swd + i];
+      const long elem = (long)pl * N + c;
+      ep.stats[(long)rs * 2 * N + elem] = v;
+      stat_zero_tail(ep.stats, 2L * N, rs + R, R, ep.stat_rows, elem);
     }
   }
 }
@@ -248,7 +265,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
   using MM = Mma<T>;
   constexpr int E = MM::EPL;
   constexpr int KS = 4 * E;
-  extern __shared__ float s_stat[];  // [2][N] when statistics are taken
+  constexpr int SWD = 64 * NCG;
+  extern __shared__ float s_stat[];  // [4 waves][2][SWD] when statistics are taken
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -256,23 +274,25 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
   const int q = lane >> 4, j = lane & 15;
   const int wrow = 16 * (j >> 2) + (j & 3);  // weight row of this lane inside a 64-channel chunk, before the +4*t
   const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+  float* sw = s_stat + wave * 2 * SWD;
 
   if (do_stats) {
-    for (int i = tid; i < 2 * N; i += 256) s_stat[i] = 0.f;
+    for (int i = tid; i < 8 * SWD; i += 256) s_stat[i] = 0.f;
     __syncthreads();
   }
 
-  // work item = (16-row tile, group of NCG 64-channel chunks): small-M problems (classifier, 7x7 maps) still fill the chip
+  // A workgroup owns ONE group of NCG 64-channel chunks (grp) and the row slot rs of R: its waves walk the 16-row tiles
+  // rs*4 + wave, + 4R, ...  (small-M problems -- classifier, 7x7 maps -- still fill the chip through the groups).  The fixed
+  // channel group is what lets the statistics live in small wave-private LDS rows and leave as one partial row per slot.
   const long mtiles = (M + 15) / 16;
-  const int ngroups = (N + 64 * NCG - 1) / (64 * NCG);
-  const long nitems = mtiles * ngroups;
-  for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
-    const long mt = item / ngroups;
+  const int ngroups = (N + SWD - 1) / SWD;
+  const int grp = blockIdx.x % ngroups, rs = blockIdx.x / ngroups, R = gridDim.x / ngroups;
+  const int nc0 = grp * SWD;
+  for (long mt = (long)rs * 4 + wave; mt < mtiles; mt += (long)R * 4) {
     const long m0 = mt * 16;
     const long row = m0 + j;
     const bool rowvalid = row < M;
     {
-      const int nc0 = (int)(item % ngroups) * 64 * NCG;
       f32x4 acc[NCG][4];
 #pragma unroll
       for (int g = 0; g < NCG; ++g)
@@ -302,19 +322,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
         if (nc0 + 64 * g >= N) continue;
-        nt_epilogue<T>(ep, acc[g], row, rowvalid, nc0 + 64 * g + 16 * q, N, do_stats, s_stat, j);
+        nt_epilogue<T>(ep, acc[g], row, rowvalid, nc0 + 64 * g + 16 * q, N, do_stats, sw, SWD, 64 * g + 16 * q, j);
       }
     }
   }
 
-  if (do_stats) {
-    __syncthreads();
-    float* srow = ep.stats + (long)(blockIdx.x % STAT_ROWS) * 2 * N;
-    for (int i = tid; i < 2 * N; i += 256) {
-      const float v = s_stat[i];
-      if (v != 0.f) atomicAdd(&srow[i], v);
-    }
-  }
+  if (do_stats) nt_flush_stats(ep, s_stat, SWD, nc0, N, rs, R, tid);
 }
 
 
@@ -440,10 +453,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
         a += __shfl_xor(a, o, 64);
         b += __shfl_xor(b, o, 64);
       }
-      if (j == 0 && nb + i < N) {
-        float* srow = ep.stats + (long)(range % STAT_ROWS) * 2 * N;
-        atomicAdd(&srow[nb + i], a);
-        atomicAdd(&srow[N + nb + i], b);
+      if (j == 0 && nb + i < N) {   // this wave is the only writer of (row `range`, channel nb + i): plain stores
+        ep.stats[(long)range * 2 * N + nb + i] = a;
+        ep.stats[(long)range * 2 * N + N + nb + i] = b;
+        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, nb + i);
+        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, (long)N + nb + i);
       }
     }
   }
@@ -475,15 +489,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_ws[];
   T* s_w = reinterpret_cast<T*>(smem_ws);                     // [2][WROWS][WS_WP], rows permuted (see below)
   float* s_c = reinterpret_cast<float*>(s_w + 2 * WBUF);      // [2][3][WS_KC]
-  float* s_stat = s_c + 2 * 3 * WS_KC;                        // [2][N]
+  float* s_stat = s_c + 2 * 3 * WS_KC;                        // [4 waves][2][WROWS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & 15;
   const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
   if (do_stats) {
-    for (int i = tid; i < 2 * N; i += 256) s_stat[i] = 0.f;
+    for (int i = tid; i < 8 * WROWS; i += 256) s_stat[i] = 0.f;
   }
+  float* sw = s_stat + wave * 2 * WROWS;
   const int nchunk = (K + WS_KC - 1) / WS_KC;
   const int K8 = (K + 7) & ~7;
   const long rblocks = (M + 64 * RT - 1) / (64 * RT);
@@ -530,9 +545,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
     }
   };
 
-  for (long item = blockIdx.x; item < rblocks * ngroups; item += gridDim.x) {
-    const long rb = item / ngroups;
-    const int nc0 = (int)(item % ngroups) * WROWS;
+  // fixed channel group per workgroup, row blocks rs, rs+R, ... (see k_gemm_nt)
+  const int grp = blockIdx.x % ngroups, rs = blockIdx.x / ngroups, R = gridDim.x / ngroups;
+  const int nc0 = grp * WROWS;
+  for (long rb = rs; rb < rblocks; rb += R) {
     long row[RT];
     bool rowvalid[RT];
 #pragma unroll
@@ -631,18 +647,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
         if (nc0 + 64 * g >= N) continue;
-        nt_epilogue<T>(ep, acc[s][g], row[s], rowvalid[s], nc0 + 64 * g + 16 * q, N, do_stats, s_stat, j);
+        nt_epilogue<T>(ep, acc[s][g], row[s], rowvalid[s], nc0 + 64 * g + 16 * q, N, do_stats, sw, WROWS, 64 * g + 16 * q, j);
       }
   }
 
-  if (do_stats) {
-    __syncthreads();
-    float* srow = ep.stats + (long)(blockIdx.x % STAT_ROWS) * 2 * N;
-    for (int i = tid; i < 2 * N; i += 256) {
-      const float v = s_stat[i];
-      if (v != 0.f) atomicAdd(&srow[i], v);
-    }
-  }
+  if (do_stats) nt_flush_stats(ep, s_stat, WROWS, nc0, N, rs, R, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ gemm_tn
@@ -654,7 +663,7 @@ constexpr int TN_ROWS = 32;
 
 template <typename T, int UMODE, int VMODE>
 __global__ __launch_bounds__(256) void k_gemm_tn(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj,
-                                                 long M, long rows_per_block) {
+                                                 long M, long rows_per_block, float* __restrict__ ws) {
   using MM = Mma<T>;
   constexpr int E = MM::EPL;
   constexpr int SUB = TN_ROWS / (4 * E);     // MFMA k-steps per 32-row slab (1 for bf16, 8 for fp32)
@@ -729,7 +738,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(Operand U, int NU, Operand V, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int uc = u0 + 16 * t + 4 * q + r;
-          if (uc < NU) atomicAdd(&out[uc * si + vc * sj], acc[t][r]);
+          if (uc < NU) {   // one workgroup per (row chunk, output tile): plain stores, partials summed by reduce_parts
+            if (ws) ws[((long)blockIdx.x * NU + uc) * NV + vc] = acc[t][r];
+            else out[uc * si + vc * sj] += acc[t][r];
+          }
         }
       }
     }
@@ -768,7 +780,7 @@ __device__ unsigned long long g_tn_timing[8];
 
 template <int UMODE, int VMODE, int UTT, int VTT, int ROWS>
 __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj, long M,
-                                                  long rows_per_block, int nchunks, int vt, int uz, int xcd_aware) {
+                                                  long rows_per_block, int nchunks, int vt, int uz, int xcd_aware, float* __restrict__ ws) {
   using T = bf16_t;
   using MM = Mma<T>;
   constexpr int VW = 64 * VTT;      // V columns per workgroup: each wave owns VTT tiles of 16 (the U tile is re-read per V tile:
@@ -905,7 +917,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int uc = u0 + 16 * t + 4 * q + r;
-            if (uc < NU) atomicAdd(&out[uc * si + vc * sj], acc[v][t][r]);
+            if (uc < NU) {   // one workgroup per (row chunk, output tile): plain stores, partials summed by reduce_parts
+              if (ws) ws[(chunk * NU + uc) * NV + vc] = acc[v][t][r];
+              else out[uc * si + vc * sj] += acc[v][t][r];
+            }
           }
         }
       }
@@ -919,6 +934,8 @@ static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, co
   const int nchunks = (N + 63) / 64;
   const long mtiles = (M + 15) / 16;
   const bf16_t* W = (const bf16_t*)Wp;
+  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+  const long min_tpi = do_stats ? (mtiles + ep.stat_rows - 1) / ep.stat_rows : 1;   // every row range owns one partial row
   // one item per resident wave (a single round of workgroups), but at least 8 row tiles per item so that the
   // register-resident weights pay off
 #define CS_CASE(MODE)                                                                                                   \
@@ -927,6 +944,7 @@ static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, co
     const long waves = (long)num_cus() * resident_per_cu(kern, 256, 0) * 4;                                             \
     long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;                                                       \
     if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
+    if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;                                                             \
     const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;                                      \
     dim3 grid((unsigned)((items + 3) / 4)), block(256);                                                                 \
     hipLaunchKernelGGL(kern, grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);                 \
@@ -940,7 +958,8 @@ static int launch_nt_ws(int mode, const Operand& A, const void* Wp, int ldw, con
   const int wrows = (N + 63) / 64 * 64;   // rows of the packed weight matrix
   const int ncg = N > 64 ? 2 : 1;
   const int ngroups = (N + 64 * ncg - 1) / (64 * ncg);
-  const size_t lds_stat = (ep.stats && ep.stat_mode != STAT_NONE) ? (size_t)2 * N * sizeof(float) : 0;
+  const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
+  const size_t lds_stat = do_stats ? (size_t)8 * 64 * ncg * sizeof(float) : 0;
   // two 16-row subtiles per wave (each weight fragment read feeds two MFMAs) when there are enough 128-row blocks
   static const int rt_env = getenv("ATOMNAS_NT_WS_RT") ? atoi(getenv("ATOMNAS_NT_WS_RT")) : 0;
   const int rt = rt_env ? rt_env : (M >= 32768 ? 2 : 1);   // measured in situ: 7x7 maps (M = 12544) prefer 64-row blocks
@@ -948,10 +967,12 @@ static int launch_nt_ws(int mode, const Operand& A, const void* Wp, int ldw, con
   {                                                                                                                      \
     auto kern = k_gemm_nt_ws<MODE, NCGV, RTV>;                                                                           \
     const size_t lds = (size_t)2 * 64 * NCGV * WS_WP * sizeof(bf16_t) + 2 * 3 * WS_KC * sizeof(float) + lds_stat;        \
-    const long need = ((M + 64 * RTV - 1) / (64 * RTV)) * ngroups;                                                       \
-    long blocks = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                     \
-    if (blocks > need) blocks = need;                                                                                    \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, A, W, ldw, wrows, ep, M, N, K);                 \
+    const long rblocks = (M + 64 * RTV - 1) / (64 * RTV);                                                                \
+    long R = (long)num_cus() * resident_per_cu(kern, 256, lds) / ngroups;   /* row slots: one round of resident workgroups */ \
+    if (R > rblocks) R = rblocks;                                                                                        \
+    if (do_stats && R > ep.stat_rows) R = ep.stat_rows;                                                                  \
+    if (R < 1) R = 1;                                                                                                    \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(R * ngroups)), dim3(256), lds, st, A, W, ldw, wrows, ep, M, N, K);          \
   }
 #define WS_MODE(MODE)                                                                  \
   if (ncg == 1) { if (rt == 2) WS_LAUNCH(MODE, 1, 2) else WS_LAUNCH(MODE, 1, 1) }      \
@@ -986,16 +1007,18 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
   const long mtiles = (M + 15) / 16;
   const bool wide = N > 64;  // keep two 64-channel chunks live when there is more than one
   const int ngroups = wide ? (N + 127) / 128 : 1;
-  const long need = (mtiles * ngroups + 3) / 4;
-  const size_t lds = (ep.stats && ep.stat_mode != STAT_NONE) ? (size_t)2 * N * sizeof(float) : 0;
+  const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
+  const size_t lds = do_stats ? (size_t)8 * (wide ? 128 : 64) * sizeof(float) : 0;
   const T* W = (const T*)Wp;
   // persistent grid-stride loop over (row tile, channel group) items: one round of resident workgroups
 #define NT_LAUNCH(MODE, NCGV)                                                                                  \
   {                                                                                                            \
     auto kern = k_gemm_nt<T, MODE, NCGV>;                                                                      \
-    long blocks = (long)num_cus() * resident_per_cu(kern, 256, lds);                                           \
-    if (blocks > need) blocks = need;                                                                          \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, A, W, ldw, ep, M, N, K, Kpad);        \
+    long R = (long)num_cus() * resident_per_cu(kern, 256, lds) / ngroups;   /* row slots of 4 tiles */         \
+    if (R > (mtiles + 3) / 4) R = (mtiles + 3) / 4;                                                            \
+    if (do_stats && R > ep.stat_rows) R = ep.stat_rows;                                                        \
+    if (R < 1) R = 1;                                                                                          \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(R * ngroups)), dim3(256), lds, st, A, W, ldw, ep, M, N, K, Kpad); \
   }
 #define NT_CASE(MODE) \
   if (wide) NT_LAUNCH(MODE, 2) else NT_LAUNCH(MODE, 1)
@@ -1009,7 +1032,7 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
 
 template <int UTT, int VTT, int ROWS>
 static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
-                          hipStream_t st) {
+                          float* ws, long ws_floats, hipStream_t st) {
   const int vt = (NV + 64 * VTT - 1) / (64 * VTT), uz = (NU + 16 * UTT - 1) / (16 * UTT);
   const size_t lds = (size_t)(64 * VTT + 16 * UTT) * (ROWS + 8) * sizeof(bf16_t) + (size_t)3 * (64 * VTT + 16 * UTT) * sizeof(float);
   // row chunks so that the grid is one round of resident workgroups (at least two slabs per workgroup)
@@ -1020,15 +1043,20 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
     const long resident = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                  \
     long chunks = resident / ((long)vt * uz);                                                                                 \
     if (chunks > M / (2 * ROWS)) chunks = M / (2 * ROWS);                                                                     \
+    if (chunks > max_chunks) chunks = max_chunks;   /* every row chunk owns one partial output in the workspace */           \
     int xcd = xcd_env;                                                                                                        \
     if (chunks < 8) xcd = 0; /* fewer chunks than XCDs: plain order */                                                        \
     if (xcd) chunks = chunks / 8 * 8; /* equal work per XCD */                                                                \
     if (chunks < 1) chunks = 1;                                                                                               \
     const long rows = (M + chunks - 1) / chunks;                                                                              \
     chunks = (M + rows - 1) / rows;                                                                                           \
+    nparts = chunks;                                                                                                          \
     dim3 grid((unsigned)((xcd ? (chunks + 7) / 8 * 8 : chunks) * vt * uz)), block(256);                                       \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, U, NU, V, NV, out, si, sj, M, rows, (int)chunks, vt, uz, xcd);             \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, U, NU, V, NV, out, si, sj, M, rows, (int)chunks, vt, uz, xcd,             \
+                       chunks > 1 ? ws : nullptr);                                                                            \
   }
+  const long max_chunks = (ws && (long)NU * NV > 0) ? ws_floats / ((long)NU * NV) : 1;   // < 2: single chunk, direct accumulation
+  long nparts = 1;
   if (umode == PRO_NONE && vmode == PRO_NONE) TN2_CASE(PRO_NONE, PRO_NONE)
   else if (umode == PRO_NONE && vmode == PRO_BNBWD) TN2_CASE(PRO_NONE, PRO_BNBWD)
   else if (umode == PRO_BNBWD && vmode == PRO_BNRELU) TN2_CASE(PRO_BNBWD, PRO_BNRELU)
@@ -1036,7 +1064,9 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
   else if (umode == PRO_BNBWD && vmode == PRO_NONE) TN2_CASE(PRO_BNBWD, PRO_NONE)
   else { set_error("gemm_tn: unsupported prologue pair (%d,%d)", umode, vmode); return 1; }
 #undef TN2_CASE
-  return check_launch("gemm_tn2");
+  if (int rc = check_launch("gemm_tn2")) return rc;
+  if (nparts > 1) return reduce_parts(ws, (long)NU * NV, (int)nparts, (long)NU * NV, out, NV, si, sj, st);
+  return 0;
 }
 
 // V tile width.  Staging U (re-read per V tile) costs 2-3x staging V in the late layers (-DTN_TIMING), but 128-column V tiles on
@@ -1044,39 +1074,43 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
 // what did help the 320-column case is two U tiles of 160 columns instead of one of 320 (fewer accumulator registers).
 template <int UTT>
 static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
-                         hipStream_t st) {
+                         float* ws, long ws_floats, hipStream_t st) {
   static const int wide_env = getenv("ATOMNAS_TN_WIDE") ? atoi(getenv("ATOMNAS_TN_WIDE")) : 0;
   if constexpr (UTT >= 4 && UTT <= 12) {
-    if (wide_env && NV >= 256) return launch_tn2_cfg<UTT, 2, 64>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+    if (wide_env && NV >= 256) return launch_tn2_cfg<UTT, 2, 64>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
   }
-  return launch_tn2_cfg<UTT, 1, 128>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  return launch_tn2_cfg<UTT, 1, 128>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
 }
 
 static int launch_tn2(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
-                      hipStream_t st) {
+                      float* ws, long ws_floats, hipStream_t st) {
   // accumulator tiles per wave (= U tiles of 16 columns): fewer tiles -> fewer AGPRs -> more waves per SIMD
   const int ut = (NU + 15) / 16;
-  if (ut <= 2) return launch_tn2_ut<2>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
-  if (ut <= 4) return launch_tn2_ut<4>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
-  if (ut <= 6) return launch_tn2_ut<6>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
-  if (ut <= 12) return launch_tn2_ut<12>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
-  if (ut <= 20) return launch_tn2_ut<10>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);   // two U tiles of <= 160 columns
-  return launch_tn2_ut<20>(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+  if (ut <= 2) return launch_tn2_ut<2>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  if (ut <= 4) return launch_tn2_ut<4>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  if (ut <= 6) return launch_tn2_ut<6>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  if (ut <= 12) return launch_tn2_ut<12>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  if (ut <= 20) return launch_tn2_ut<10>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);   // two U tiles of <= 160 columns
+  return launch_tn2_ut<20>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
 }
 
 template <typename T>
 static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
-                     hipStream_t st) {
-  if constexpr (sizeof(T) == 2) return launch_tn2(umode, U, NU, vmode, V, NV, out, si, sj, M, st);
+                     float* ws, long ws_floats, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) return launch_tn2(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
   const int vt = (NV + 63) / 64, uz = (NU + 16 * UT_MAX - 1) / (16 * UT_MAX);
   // enough row chunks to fill the chip, but at least 8 slabs of 32 rows per block
   long chunks = (1024 + (long)vt * uz - 1) / ((long)vt * uz);
+  const long max_chunks = ws ? ws_floats / ((long)NU * NV) : 1;   // every row chunk owns one partial output in the workspace
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
   long rows = (M + chunks - 1) / chunks;
   if (rows < 8 * TN_ROWS) rows = 8 * TN_ROWS;
   rows = (rows + TN_ROWS - 1) / TN_ROWS * TN_ROWS;
   chunks = (M + rows - 1) / rows;
   dim3 grid((unsigned)chunks, vt, uz), block(256);
-#define TN_CASE(UM, VM) hipLaunchKernelGGL((k_gemm_tn<T, UM, VM>), grid, block, 0, st, U, NU, V, NV, out, si, sj, M, rows)
+#define TN_CASE(UM, VM) \
+  hipLaunchKernelGGL((k_gemm_tn<T, UM, VM>), grid, block, 0, st, U, NU, V, NV, out, si, sj, M, rows, chunks > 1 ? ws : nullptr)
   if (umode == PRO_NONE && vmode == PRO_NONE) TN_CASE(PRO_NONE, PRO_NONE);
   else if (umode == PRO_NONE && vmode == PRO_BNBWD) TN_CASE(PRO_NONE, PRO_BNBWD);
   else if (umode == PRO_BNBWD && vmode == PRO_BNRELU) TN_CASE(PRO_BNBWD, PRO_BNRELU);
@@ -1084,7 +1118,9 @@ static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Opera
   else if (umode == PRO_BNBWD && vmode == PRO_NONE) TN_CASE(PRO_BNBWD, PRO_NONE);
   else { set_error("gemm_tn: unsupported prologue pair (%d,%d)", umode, vmode); return 1; }
 #undef TN_CASE
-  return check_launch("gemm_tn");
+  if (int rc = check_launch("gemm_tn")) return rc;
+  if (chunks > 1) return reduce_parts(ws, (long)NU * NV, (int)chunks, (long)NU * NV, out, NV, si, sj, st);
+  return 0;
 }
 
 static int check_operand(const char* who, const Operand& o, int mode, int C) {
@@ -1113,8 +1149,8 @@ using namespace atomnas;
 extern "C" int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void* a2, int lda2, const float* ac1, const float* ac2,
                                   const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, int out_f32,
                                   const void* add, int ldadd, const void* z, int ldz, const float* zscale, const float* zshift,
-                                  int mask, const float* bias, float* stats, int stat_mode, long M, int N, int K, int dtype,
-                                  void* stream) {
+                                  int mask, const float* bias, float* stats, int stat_mode, int stat_rows, long M, int N, int K,
+                                  int dtype, void* stream) {
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pw_gemm_nt: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(a_mode >= PRO_NONE && a_mode <= PRO_BNBWD, "pw_gemm_nt: bad prologue %d", a_mode);
   ATOMNAS_REQUIRE(M > 0 && N > 0 && K > 0, "pw_gemm_nt: empty shape");
@@ -1124,23 +1160,26 @@ extern "C" int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void
     ATOMNAS_REQUIRE(ldw >= (K + ks - 1) / ks * ks && ldw % 8 == 0, "pw_gemm_nt: packed weight pitch %d too small for K=%d", ldw, K);
   }
   ATOMNAS_REQUIRE(!stats || N <= NT_MAX_STAT, "pw_gemm_nt: N=%d too wide for fused statistics", N);
+  ATOMNAS_REQUIRE(!stats || stat_mode == STAT_NONE || stat_rows > 0, "pw_gemm_nt: statistics need stat_rows > 0");
   ATOMNAS_REQUIRE(!add || (ldadd >= N && ldadd % 8 == 0), "pw_gemm_nt: bad residual pitch");
   ATOMNAS_REQUIRE(!z || (ldz >= N && ldz % 8 == 0), "pw_gemm_nt: bad z pitch");
   ATOMNAS_REQUIRE(!mask || (z && zscale && zshift), "pw_gemm_nt: mask needs z, zscale, zshift");
   ATOMNAS_REQUIRE(stat_mode != STAT_Z || z, "pw_gemm_nt: STAT_Z needs z");
   Operand A{a, lda, a2, lda2, ac1, ac2, ac3, a_relu};
   if (check_operand("pw_gemm_nt", A, a_mode, K)) return 1;
-  Epilogue ep{c, ldc, out_f32, add, ldadd, z, ldz, zscale, zshift, mask, bias, stats, stat_mode};
+  Epilogue ep{c, ldc, out_f32, add, ldadd, z, ldz, zscale, zshift, mask, bias, stats, stat_mode, stat_rows};
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32) return launch_nt<float>(a_mode, A, wp, ldw, ep, M, N, K, st);
   return launch_nt<bf16_t>(a_mode, A, wp, ldw, ep, M, N, K, st);
 }
 
-// out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]   (fp32 accumulation into `out`, caller zeroes it)
+// out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]   (fp32 accumulation into `out`, caller zeroes it).
+// ws: caller-owned scratch of ws_floats floats for the per-row-chunk partial outputs (summed in chunk order, no atomics:
+// bit-reproducible); with ws == NULL or room for fewer than two partials the reduction over M runs in a single workgroup per tile.
 extern "C" int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void* u2, int ldu2, const float* uc1, const float* uc2,
                                   const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, const void* v2,
                                   int ldv2, const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out,
-                                  long si, long sj, long M, int dtype, void* stream) {
+                                  long si, long sj, long M, float* ws, long ws_floats, int dtype, void* stream) {
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pw_gemm_tn: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(M > 0 && NU > 0 && NV > 0 && out, "pw_gemm_tn: empty shape");
   Operand U{u, ldu, u2, ldu2, uc1, uc2, uc3, u_relu};
@@ -1148,6 +1187,6 @@ extern "C" int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void
   if (check_operand("pw_gemm_tn(U)", U, u_mode, NU)) return 1;
   if (check_operand("pw_gemm_tn(V)", V, v_mode, NV)) return 1;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_F32) return launch_tn<float>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, st);
-  return launch_tn<bf16_t>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, st);
+  if (dtype == DT_F32) return launch_tn<float>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  return launch_tn<bf16_t>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, ws, ws_floats, st);
 }

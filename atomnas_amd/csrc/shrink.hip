@@ -1,5 +1,5 @@
-// Dynamic network shrinkage on device: alive masks of the atomic blocks and the index-packed channel repack that
-// rebuilds weights, optimizer state and EMA shadows after a shrink.
+// Dynamic network shrinkage on device: alive masks of all prunable BatchNorms in one launch (mask bytes, ascending
+// kept-channel indices, kept counts) and the index-packed gather that rebuilds weights, optimizer state and EMA shadows.
 //   masks : train.py:46-63 and utils/prune.py:190-195   mask = |gamma| > thr  (optionally OR / replaced by the EMA gamma)
 //   repack: models/compress_utils.py:31-37 (_mask_along_dim) applied by compress_conv/compress_bn (:73-119) and mirrored
 //           into RMSprop state (utils/rmsprop.py:134-165) and EMA shadows (utils/optim.py:134-153)
@@ -51,29 +51,6 @@ __global__ __launch_bounds__(256) void k_gamma_mask(const float* __restrict__ p,
   if (threadIdx.x == 0) kept[blockIdx.x] = s_base;
 }
 
-// dst[o*dst_os + j*dst_ds + i] = src[o*src_os + idx[j]*src_ds + i],  o < outer, j < n_kept, i < inner (idx == null: identity)
-struct RepackJob {
-  long src_off, dst_off;
-  long src_os, src_ds, dst_os, dst_ds;
-  int outer, n_kept, inner;
-  int idx_off;  // offset into the index buffer, -1 for a plain copy
-};
-
-__global__ __launch_bounds__(256) void k_repack(const float* const* __restrict__ srcs, float* const* __restrict__ dsts, int narenas,
-                                                const RepackJob* __restrict__ jobs, const int* __restrict__ index) {
-  const RepackJob jb = jobs[blockIdx.y];
-  const long total = (long)jb.outer * jb.n_kept * jb.inner;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int i = (int)(e % jb.inner);
-    const int j = (int)((e / jb.inner) % jb.n_kept);
-    const int o = (int)(e / ((long)jb.inner * jb.n_kept));
-    const int sj = (jb.idx_off >= 0) ? index[jb.idx_off + j] : j;
-    const long s = jb.src_off + o * jb.src_os + sj * jb.src_ds + i;
-    const long d = jb.dst_off + o * jb.dst_os + j * jb.dst_ds + i;
-    for (int a = 0; a < narenas; ++a) dsts[a][d] = srcs[a][s];
-  }
-}
-
 }  // namespace atomnas
 
 using namespace atomnas;
@@ -85,15 +62,6 @@ extern "C" int atomnas_gamma_mask(const float* params, const float* ema, const v
   hipLaunchKernelGGL(k_gamma_mask, dim3(njobs), dim3(256), 0, (hipStream_t)stream, params, ema, (const MaskJob*)jobs_dev, threshold, mode,
                      mask, index, kept);
   return check_launch("gamma_mask");
-}
-
-extern "C" int atomnas_channel_repack(const void* src_ptrs_dev, const void* dst_ptrs_dev, int narenas, const void* jobs_dev, int njobs,
-                                      const int* index, void* stream) {
-  ATOMNAS_REQUIRE(src_ptrs_dev && dst_ptrs_dev && narenas > 0 && jobs_dev && njobs > 0, "channel_repack: bad arguments");
-  dim3 grid(16, njobs);
-  hipLaunchKernelGGL(k_repack, grid, dim3(256), 0, (hipStream_t)stream, (const float* const*)src_ptrs_dev, (float* const*)dst_ptrs_dev,
-                     narenas, (const RepackJob*)jobs_dev, index);
-  return check_launch("channel_repack");
 }
 
 // ---- single-tensor forms used by the reference-compatible per-tensor protocol (info['mask_hook'](new, old, mask))

@@ -26,8 +26,6 @@ class TrainStep:
         self.use_graph = use_graph
         self.world_size = world_size
         self.pg = process_group
-        # the collective can be forced on a single rank to exercise RCCL + graph capture on a one-GPU box
-        self._reduce = world_size > 1 or (bool(os.environ.get("ATOMNAS_FORCE_ALLREDUCE")) and dist.is_initialized())
         dev = next(model.parameters()).device
         self.mgr = runtime.manager_of(model)
         self.mgr.attach_optimizer(optimizer)
@@ -108,9 +106,16 @@ class TrainStep:
         self.x.copy_(x, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
 
-    def step(self, lr=None, rho=0.0, ema_decay=None):
-        """One iteration on the current static batch.  lr defaults to the optimizer's group lr."""
+    def _wants_reduce(self):
+        # the collective can be forced on a single rank to exercise RCCL next to graph replay on a one-GPU box
+        return self.world_size > 1 or (bool(os.environ.get("ATOMNAS_FORCE_ALLREDUCE")) and dist.is_initialized())
+
+    def step(self, lr=None, rho=0.0, ema_decay=None, reduce=None):
+        """One iteration on the current static batch.  lr defaults to the optimizer's group lr.  reduce: None = all-reduce the
+        gradient arena when world_size > 1; False = never (bench.py's single-rank profiling pass: the other ranks wait at a
+        barrier, so no collective may be issued)."""
         mgr = self.mgr
+        do_reduce = self._wants_reduce() if reduce is None else bool(reduce)
         if mgr.dirty or self._version != mgr.version:
             mgr.ensure()
             self.g_fwd_bwd = self.g_opt = None
@@ -126,12 +131,14 @@ class TrainStep:
             if self.g_fwd_bwd is None:
                 self._capture()
             self.g_fwd_bwd.replay()
-            if self._reduce:
+            if do_reduce:
                 dist.all_reduce(mgr.G, group=self.pg)
             self.g_opt.replay()
         else:
             self._fwd_bwd()
-            if self._reduce:
+            if do_reduce:
                 dist.all_reduce(mgr.G, group=self.pg)
             self._opt()
         self.global_step += 1
+        if self.ema is not None:   # bookkeeping the reference keeps per variable (utils/optim.py:62-63); checkpointed
+            self.ema.note_updates(1, float(h[ops.HYP_EMA_DECAY]))

@@ -53,15 +53,28 @@ def _f32(n, dev, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
 
 
+class StatBuf:
+    """Partial-row statistics buffer [rows][2][c] (include/atomnas_hip.h): every producer writes all rows of its channel range
+    with plain stores, the BatchNorm finalize sums them in a fixed order -- no initialisation, no atomics."""
+    __slots__ = ("t", "rows", "c")
+
+    def __init__(self, t, rows, c):
+        self.t, self.rows, self.c = t, rows, c
+
+    def at(self, off):
+        """buffer pointer advanced to channel `off` (a branch segment of a fused hidden tensor)"""
+        return self.t[off:] if off else self.t
+
+
 def _stats(c, dev, mgr=None):
-    """Zeroed [STAT_ROWS][2][c] partial-row statistics buffer.  With a manager it is a slice of the per-step workspace that one
-    memset clears at the top-level forward (134 separate fill launches per step otherwise)."""
-    n = ops.STAT_ROWS * 2 * c
+    """Uninitialised StatBuf for c channels.  With a manager it is a slice of the per-step statistics workspace."""
+    rows = ops.stat_rows_for(c)
+    n = rows * 2 * c
     if mgr is not None:
         v = mgr.take_stats(n)
         if v is not None:
-            return v
-    return torch.zeros(n, dtype=torch.float32, device=dev)
+            return StatBuf(v, rows, c)
+    return StatBuf(torch.empty(n, dtype=torch.float32, device=dev), rows, c)
 
 
 # ---------------------------------------------------------------------------------------------- batch norm helpers
@@ -82,9 +95,9 @@ def bn_forward_coeffs(bn, stats, count, dev):
     if mod.training or not mod.track_running_stats:
         st.mean, st.invstd = _f32(Cp, dev), _f32(Cp, dev)
         track = mod.track_running_stats
-        ops.bn_finalize_fwd(stats, count, bn["gamma"], bn["beta"], eps, mod.momentum, bn["rm"] if track else None,
+        ops.bn_finalize_fwd(stats.t, count, bn["gamma"], bn["beta"], eps, mod.momentum, bn["rm"] if track else None,
                             bn["rv"] if track else None, mod.num_batches_tracked if track else None, st.scale, st.shift, st.mean,
-                            st.invstd, C)
+                            st.invstd, C, stat_rows=stats.rows)
         if track:
             bn["mgr"].bn_trained = True
     else:
@@ -105,7 +118,8 @@ def bn_backward_coeffs(bn, st, stats2, count, dev):
     c1, c2, c3 = _f32(Cp, dev), _f32(Cp, dev), _f32(Cp, dev)
     if st.mean is None:
         raise RuntimeError("backward through a BatchNorm in eval mode is not supported")
-    ops.bn_finalize_bwd(stats2, count, bn["gamma"], st.mean, st.invstd, None, None, bn["dgamma"], bn["dbeta"], c1, c2, c3, C)
+    ops.bn_finalize_bwd(stats2.t, count, bn["gamma"], st.mean, st.invstd, None, None, bn["dgamma"], bn["dbeta"], c1, c2, c3, C,
+                        stat_rows=stats2.rows)
     return c1, c2, c3
 
 
@@ -124,7 +138,8 @@ def block_forward(pl, x2d, N, H, W, need_grad):
         bs = bn_uses_batch_stats(pl.bne)
         E = torch.empty(M, HT, dtype=T, device=dev)
         stE = _stats(HT, dev, pl.bne["mgr"]) if bs else None
-        ops.gemm_nt(x2d, pl.We_pack, E, M, HT, pl.inp, stats=stE, stat_mode=STAT_SQ if bs else 0)
+        ops.gemm_nt(x2d, pl.We_pack, E, M, HT, pl.inp, stats=stE.t if bs else None, stat_mode=STAT_SQ if bs else 0,
+                    stat_rows=stE.rows if bs else None)
         bE = bn_forward_coeffs(pl.bne, stE, M, dev)
     else:
         E, bE = x2d, None
@@ -135,13 +150,13 @@ def block_forward(pl, x2d, N, H, W, need_grad):
         o, c = pl.seg[i], pad8(pl.hid[i])
         xin = E[:, o:] if pl.expand else E
         ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], D[:, o:],
-                       stD[o:] if bsd else None, HT, N, H, W, c, pl.ks[i], s)
+                       stD.at(o) if bsd else None, HT, N, H, W, c, pl.ks[i], s, stat_rows=stD.rows if bsd else None)
     bD = bn_forward_coeffs(pl.bnd, stD, M2, dev)
     bsp = bn_uses_batch_stats(pl.bnp)
     Pr = torch.empty(M2, pl.oup, dtype=T, device=dev)
     stP = _stats(pl.oup, dev, pl.bnp["mgr"]) if bsp else None
-    ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=int(act), stats=stP,
-                stat_mode=STAT_SQ if bsp else 0)
+    ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=int(act),
+                stats=stP.t if bsp else None, stat_mode=STAT_SQ if bsp else 0, stat_rows=stP.rows if bsp else None)
     bP = bn_forward_coeffs(pl.bnp, stP, M2, dev)
     out = torch.empty(M2, pl.oup, dtype=T, device=dev)
     ops.bn_apply(Pr, bP.scale, bP.shift, False, x2d if pl.res else None, out, M2, pl.oup)
@@ -160,7 +175,7 @@ def block_backward(pl, sv, G):
     x2d, E, D, Pr, bE, bD, bP = sv["x"], sv["E"], sv["D"], sv["P"], sv["bE"], sv["bD"], sv["bP"]
     # shared pw_bn backward: statistics pass over (G, P), then coefficients
     st2P = _stats(pl.oup, dev, pl.bnp["mgr"])
-    ops.act_bwd_stats(G, Pr, None, None, False, None, st2P, M2, pl.oup)
+    ops.act_bwd_stats(G, Pr, None, None, False, None, st2P.t, M2, pl.oup, stat_rows=st2P.rows)
     p1, p2, p3 = bn_backward_coeffs(pl.bnp, bP, st2P, M2, dev)
     # projection weight gradient: dWp[n][k] = sum_m dP[m][n] * act(bn(D))[m][k]
     ops.gemm_tn(G, pl.oup, D, HT, pl.Wp_grad, HT, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
@@ -169,7 +184,7 @@ def block_backward(pl, sv, G):
     g = torch.empty(M2, HT, dtype=T, device=dev)
     st2D = _stats(HT, dev, pl.bnd["mgr"])
     ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
-                zshift=bD.shift, mask=int(act), stats=st2D, stat_mode=STAT_Z)
+                zshift=bD.shift, mask=int(act), stats=st2D.t, stat_mode=STAT_Z, stat_rows=st2D.rows)
     d1, d2, d3 = bn_backward_coeffs(pl.bnd, bD, st2D, M2, dev)
     # depthwise backward per branch
     if pl.expand:
@@ -182,7 +197,7 @@ def block_backward(pl, sv, G):
         o, c = pl.seg[i], pad8(pl.hid[i])
         if pl.expand:
             ops.dwconv_bwd(g[:, o:], D[:, o:], d1[o:], d2[o:], d3[o:], E[:, o:], bE.scale[o:], bE.shift[o:], act, pl.taps[i],
-                           h[:, o:], pl.Wd_grad[i], st2E[o:], HT, N, H, W, c, pl.ks[i], s)
+                           h[:, o:], pl.Wd_grad[i], st2E.at(o), HT, N, H, W, c, pl.ks[i], s, stat_rows=st2E.rows)
         else:
             if pl.nb > 1:
                 raise NotImplementedError("non-expanding block with more than one branch")
@@ -269,9 +284,11 @@ def convbn_forward(pl, x, need_grad):
     Y = torch.empty(M, Cp, dtype=T, device=dev) if sv["kind"] != "dw" else torch.zeros(M, Cp, dtype=T, device=dev)
     st = _stats(pl.cout, dev, pl.bn["mgr"]) if bs else None
     if sv["kind"] == "dw":
-        ops.dwconv_fwd(a2d, None, None, 0, pl.taps, Y, st, pl.cout, N, H, W, pl.cout, pl.k, pl.stride)
+        ops.dwconv_fwd(a2d, None, None, 0, pl.taps, Y, st.t if bs else None, pl.cout, N, H, W, pl.cout, pl.k, pl.stride,
+                       stat_rows=st.rows if bs else None)
     else:
-        ops.gemm_nt(a2d, pl.W_pack, Y, M, pl.cout, K, stats=st, stat_mode=STAT_SQ if bs else 0)
+        ops.gemm_nt(a2d, pl.W_pack, Y, M, pl.cout, K, stats=st.t if bs else None, stat_mode=STAT_SQ if bs else 0,
+                    stat_rows=st.rows if bs else None)
     b = bn_forward_coeffs(pl.bn, st, M, dev)
     out = torch.empty(M, Cp, dtype=T, device=dev)
     ops.bn_apply(Y, b.scale, b.shift, int(act), None, out, M, pl.cout)
@@ -288,7 +305,7 @@ def convbn_backward(pl, sv, G, need_input_grad):
     Y, b, a2d = sv["Y"], sv["b"], sv["a"]
     g = torch.empty_like(Y)
     st2 = _stats(pl.cout, dev, pl.bn["mgr"])
-    ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, int(act), g, st2, M, pl.cout)
+    ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, int(act), g, st2.t, M, pl.cout, stat_rows=st2.rows)
     c1, c2, c3 = bn_backward_coeffs(pl.bn, b, st2, M, dev)
     if sv["kind"] == "dw":
         h = torch.zeros(N * H * W, pad8(pl.cout), dtype=T, device=dev)
@@ -346,7 +363,8 @@ def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
     bs = bn_uses_batch_stats(lp.bn)
     L = torch.empty(M, lp.cout, dtype=T, device=dev)
     st = _stats(lp.cout, dev, lp.bn["mgr"]) if bs else None
-    ops.gemm_nt(a2d, lp.W_pack, L, M, lp.cout, lp.cin, stats=st, stat_mode=STAT_SQ if bs else 0)
+    ops.gemm_nt(a2d, lp.W_pack, L, M, lp.cout, lp.cin, stats=st.t if bs else None, stat_mode=STAT_SQ if bs else 0,
+                stat_rows=st.rows if bs else None)
     b = bn_forward_coeffs(lp.bn, st, M, dev)
     pooled = torch.empty(N, lp.cout, dtype=T, device=dev)
     p = float(drop_p) if training else 0.0
@@ -382,7 +400,7 @@ def tail_backward(lp, fp, sv, dlogits):
     L, b = sv["L"], sv["b"]
     gL = torch.empty(M, lp.cout, dtype=T, device=dev)
     st2 = _stats(lp.cout, dev, lp.bn["mgr"])
-    ops.pool_act_bwd(dpooled, sv["keep"], sv["p"], L, b.scale, b.shift, int(act), gL, st2, N, HW, lp.cout)
+    ops.pool_act_bwd(dpooled, sv["keep"], sv["p"], L, b.scale, b.shift, int(act), gL, st2.t, N, HW, lp.cout, stat_rows=st2.rows)
     c1, c2, c3 = bn_backward_coeffs(lp.bn, b, st2, M, dev)
     ops.gemm_tn(sv["a"], lp.cin, gL, lp.cout, lp.W_grad, 1, lp.cin, M, v_mode=PRO_BNBWD, v2=L, vc1=c1, vc2=c2, vc3=c3)
     Gx = torch.empty(M, lp.cin, dtype=T, device=dev)
@@ -428,7 +446,7 @@ class CESmoothFunction(torch.autograd.Function):
         loss = torch.empty(B, dtype=torch.float32, device=logits.device)
         dl = torch.empty(B, K, dtype=torch.float32, device=logits.device)
         # gscale = B: dl holds d(loss_i)/d(logits_i) (the 1/B of a mean reduction comes in through grad_output)
-        ops.ce_smooth(lg, target, eps, B, K, loss, None, dl, float(B), topk)
+        ops.ce_smooth(lg, target, eps, B, K, loss, dl, float(B), topk)
         ctx.save_for_backward(dl)
         return loss
 

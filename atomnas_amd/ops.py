@@ -13,7 +13,32 @@ from ._lib import call
 PRO_NONE, PRO_BNRELU, PRO_BNBWD = 0, 1, 2
 STAT_NONE, STAT_SQ, STAT_Z = 0, 1, 2
 HYP_LR, HYP_RHO, HYP_EMA_DECAY, HYP_GRAD_SCALE = 0, 1, 2, 3
-STAT_ROWS = 64  # partial rows of every statistics buffer ([STAT_ROWS][2][C], see include/atomnas_hip.h)
+
+
+def stat_rows_for(c):
+    """Partial rows of a statistics buffer [rows][2][c] (include/atomnas_hip.h): every producing workgroup owns one row, so
+    more rows allow more concurrent workgroups; few-channel tensors (one or two channel slabs) need the most."""
+    if c <= 64:
+        return 1024
+    if c < 1024:
+        return 512
+    return 128
+
+
+def _rows(stats, stat_rows):
+    if stats is None:
+        return 0
+    if stat_rows is not None:
+        return int(stat_rows)
+    if stats.dim() != 3:
+        raise ValueError("pass stat_rows with a flat statistics buffer")
+    return stats.shape[0]
+
+
+def tn_workspace(nu, nv, dev):
+    """scratch for the per-row-chunk partial outputs of atomnas_pw_gemm_tn (at most 32 MiB)"""
+    return torch.empty(max(2 * nu * nv, min(256 * nu * nv, 8 << 20)), dtype=torch.float32, device=dev)
+
 
 
 def _p(t):
@@ -49,48 +74,59 @@ def _chk_cuda(*ts):
             raise _lib.AtomnasHipError("atomnas_amd kernels run on the GPU only (got a %s tensor)" % t.device)
 
 
-def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, stat_ld, N, H, W, C, k, stride):
+def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, stat_ld, N, H, W, C, k, stride, stat_rows=None):
     _chk_cuda(x, y, w_taps)
     if _lib.PROFILE is not None:
         _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
     call("atomnas_dwconv_fwd", _p(x), _ld(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(y), _ld(y),
-         _p(stats), stat_ld, N, H, W, C, k, stride, dt_code(x.dtype), _stream())
+         _p(stats), stat_ld, _rows(stats, stat_rows), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
 
-def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, dw, stats, stat_ld, N, H, W, C, k, stride):
+def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, dw, stats, stat_ld, N, H, W, C, k, stride,
+               stat_rows=None, dw_ws=None):
+    """dw_ws: scratch [part_rows][C][k*k] for the per-workgroup weight-gradient partials (allocated here when omitted)"""
     _chk_cuda(g, x, h, w_taps)
+    rows = _rows(stats, stat_rows) if stats is not None else stat_rows_for(C)
+    if dw is not None and dw_ws is None:
+        dw_ws = torch.empty(rows * C * k * k, dtype=torch.float32, device=x.device)
     if _lib.PROFILE is not None:
         _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
     call("atomnas_dwconv_bwd", _p(g), _ld(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _p(c1), _p(c2), _p(c3), _p(x), _ld(x),
-         _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _p(dw), _p(stats), stat_ld, N, H, W, C,
-         k, stride, dt_code(x.dtype), _stream())
+         _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _p(dw), _p(stats), stat_ld, rows,
+         _p(dw_ws), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
 
 def gemm_nt(a, wp, c, M, N, K, a_mode=PRO_NONE, a2=None, ac1=None, ac2=None, ac3=None, a_relu=False, add=None, z=None,
-            zscale=None, zshift=None, mask=False, bias=None, stats=None, stat_mode=STAT_NONE):
+            zscale=None, zshift=None, mask=False, bias=None, stats=None, stat_mode=STAT_NONE, stat_rows=None):
     _chk_cuda(a, wp, c)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d pro%d st%d%s%s" % (M, N, K, a_mode, stat_mode, "+add" if add is not None else "", "+mask" if mask else ""))
     out_f32 = 1 if (c.dtype == torch.float32 and a.dtype != torch.float32) else 0
     call("atomnas_pw_gemm_nt", a_mode, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, _p(ac1), _p(ac2), _p(ac3),
          int(a_relu), _p(wp), wp.stride(0), _p(c), _ld(c), out_f32, _p(add), _ld(add) if add is not None else 0, _p(z),
-         _ld(z) if z is not None else 0, _p(zscale), _p(zshift), int(mask), _p(bias), _p(stats), stat_mode, M, N, K,
-         dt_code(a.dtype), _stream())
+         _ld(z) if z is not None else 0, _p(zscale), _p(zshift), int(mask), _p(bias), _p(stats), stat_mode, _rows(stats, stat_rows),
+         M, N, K, dt_code(a.dtype), _stream())
 
 
 def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc2=None, uc3=None, u_relu=False, v_mode=PRO_NONE,
-            v2=None, vc1=None, vc2=None, vc3=None, v_relu=False):
+            v2=None, vc1=None, vc2=None, vc3=None, v_relu=False, ws=None):
+    """ws: scratch for the per-row-chunk partial outputs (allocated here when omitted; pass False for a single-chunk reduction)"""
     _chk_cuda(u, v, out)
+    if ws is None:
+        ws = tn_workspace(NU, NV, u.device)
+    elif ws is False:
+        ws = None
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d NU%d NV%d pro%d,%d" % (M, NU, NV, u_mode, v_mode))
     call("atomnas_pw_gemm_tn", u_mode, _p(u), _ld(u), _p(u2), _ld(u2) if u2 is not None else 0, _p(uc1), _p(uc2), _p(uc3),
          int(u_relu), NU, v_mode, _p(v), _ld(v), _p(v2), _ld(v2) if v2 is not None else 0, _p(vc1), _p(vc2), _p(vc3), int(v_relu),
-         NV, _p(out), si, sj, M, dt_code(u.dtype), _stream())
+         NV, _p(out), si, sj, M, _p(ws), ws.numel() if ws is not None else 0, dt_code(u.dtype), _stream())
 
 
 def bn_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, save_mean,
-                    save_invstd, C):
-    call("atomnas_bn_finalize_fwd", _p(stats), float(count), _p(gamma), _p(beta), eps, -1.0 if momentum is None else momentum,
+                    save_invstd, C, stat_rows=None):
+    call("atomnas_bn_finalize_fwd", _p(stats), _rows(stats, stat_rows), float(count), _p(gamma), _p(beta), eps,
+         -1.0 if momentum is None else momentum,
          _p(running_mean), _p(running_var), _p(nbt), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), C, _stream())
 
 
@@ -98,8 +134,9 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, scale, shift, C)
     call("atomnas_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(scale), _p(shift), C, _stream())
 
 
-def bn_finalize_bwd(stats2, count, gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C):
-    call("atomnas_bn_finalize_bwd", _p(stats2), float(count), _p(gamma), _p(save_mean), _p(save_invstd), _p(rho_ptr), _p(penalty),
+def bn_finalize_bwd(stats2, count, gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, stat_rows=None):
+    call("atomnas_bn_finalize_bwd", _p(stats2), _rows(stats2, stat_rows), float(count), _p(gamma), _p(save_mean), _p(save_invstd),
+         _p(rho_ptr), _p(penalty),
          _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), C, _stream())
 
 
@@ -113,14 +150,14 @@ def bn_act_pool(x, scale, shift, relu, pooled, keep, drop_p, seed, step_ptr, N, 
          int(seed) & 0xFFFFFFFFFFFFFFFF, _p(step_ptr), N, HW, C, dt_code(x.dtype), _stream())
 
 
-def pool_act_bwd(dpooled, keep, drop_p, x, scale, shift, relu, g, stats2, N, HW, C):
+def pool_act_bwd(dpooled, keep, drop_p, x, scale, shift, relu, g, stats2, N, HW, C, stat_rows=None):
     call("atomnas_pool_act_bwd", _p(dpooled), _ld(dpooled), _p(keep), float(drop_p), _p(x), _ld(x), _p(scale), _p(shift), int(relu),
-         _p(g), _ld(g), _p(stats2), N, HW, C, dt_code(x.dtype), _stream())
+         _p(g), _ld(g), _p(stats2), _rows(stats2, stat_rows), N, HW, C, dt_code(x.dtype), _stream())
 
 
-def act_bwd_stats(dy, z, scale, shift, relu, g, stats2, M, C):
+def act_bwd_stats(dy, z, scale, shift, relu, g, stats2, M, C, stat_rows=None):
     call("atomnas_act_bwd_stats", _p(dy), _ld(dy), _p(z), _ld(z), _p(scale), _p(shift), int(relu), _p(g),
-         _ld(g) if g is not None else 0, _p(stats2), M, C, dt_code(dy.dtype), _stream())
+         _ld(g) if g is not None else 0, _p(stats2), _rows(stats2, stat_rows), M, C, dt_code(dy.dtype), _stream())
 
 
 def im2col_stem(img, col, N, H, W):
@@ -128,9 +165,9 @@ def im2col_stem(img, col, N, H, W):
     call("atomnas_im2col_stem", _p(img), _p(col), _ld(col), N, H, W, dt_code(col.dtype), _stream())
 
 
-def ce_smooth(logits, target, eps, B, K, loss_per_sample, loss_sum, dlogits, gscale, topk):
+def ce_smooth(logits, target, eps, B, K, loss_per_sample, dlogits, gscale, topk):
     assert logits.dtype == torch.float32 and target.dtype == torch.int64
-    call("atomnas_ce_smooth", _p(logits), _ld(logits), _p(target), float(eps), B, K, _p(loss_per_sample), _p(loss_sum), _p(dlogits),
+    call("atomnas_ce_smooth", _p(logits), _ld(logits), _p(target), float(eps), B, K, _p(loss_per_sample), _p(dlogits),
          _ld(dlogits) if dlogits is not None else 0, float(gscale), _p(topk),
          dt_code(dlogits.dtype) if dlogits is not None else 0, _stream())
 
@@ -148,10 +185,6 @@ def ema_update(shadow, x, n, hyper):
     call("atomnas_ema_update", _p(shadow), _p(x), n, _p(hyper), _stream())
 
 
-def weighted_norm(p, coef_chunk, n, use_abs, out):
-    call("atomnas_weighted_norm", _p(p), _p(coef_chunk), n, int(use_abs), _p(out), _stream())
-
-
 def pack_weights(arena, packbuf, jobs_dev, njobs, dtype):
     call("atomnas_pack_weights", _p(arena), _p(packbuf), _p(jobs_dev), njobs, dt_code(dtype), _stream())
 
@@ -161,16 +194,14 @@ def gamma_mask(params, ema, jobs_dev, njobs, threshold, mode, mask, index, kept)
          _stream())
 
 
-def channel_repack(src_ptrs_dev, dst_ptrs_dev, narenas, jobs_dev, njobs, index):
-    call("atomnas_channel_repack", _p(src_ptrs_dev), _p(dst_ptrs_dev), narenas, _p(jobs_dev), njobs, _p(index), _stream())
-
-
 def reg_grad(p, g, jobs_dev, njobs, use_sign, mult_ptr=None, grad_out=None):
     call("atomnas_reg_grad", _p(p), _p(g), _p(jobs_dev), njobs, int(use_sign), _p(mult_ptr), _p(grad_out), _stream())
 
 
-def reg_value(p, jobs_dev, njobs, use_abs, mult_ptr, post_scale, out):
-    call("atomnas_reg_value", _p(p), _p(jobs_dev), njobs, int(use_abs), _p(mult_ptr), float(post_scale), _p(out), _stream())
+def reg_value(p, jobs_dev, njobs, use_abs, mult_ptr, post_scale, out, ws=None):
+    if ws is None:
+        ws = torch.empty(64 * njobs, dtype=torch.float32, device=p.device)
+    call("atomnas_reg_value", _p(p), _p(jobs_dev), njobs, int(use_abs), _p(mult_ptr), float(post_scale), _p(out), _p(ws), _stream())
 
 
 def gather_by_mask(dst, src, mask, dim):

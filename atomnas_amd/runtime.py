@@ -508,9 +508,10 @@ class ArenaManager:
 
     # Outermost module call: refresh packed weights on entry; on exit bump every BN's num_batches_tracked once if any BN
     # ran with batch statistics (all BNs of the model share their mode in the reference's train / calibration phases).
-    # ---- per-step statistics workspace: every BatchNorm use of a step (forward and backward) takes a distinct, zeroed slice;
-    # one memset at the top-level forward replaces one fill launch per use.  A slice is dead as soon as its finalize kernel
-    # has run, so resetting at the next top-level forward is safe even when a backward is still pending.
+    # ---- per-step statistics workspace: every BatchNorm use of a step (forward and backward) takes a distinct slice of partial
+    # rows.  The producing kernels write every row (include/atomnas_hip.h), so nothing is ever cleared.  A slice is dead as soon
+    # as its finalize kernel has run, so re-using the workspace from the next top-level forward on is safe even when a
+    # backward is still pending.
     def take_stats(self, n):
         n = (n + 63) // 64 * 64
         off = self._stats_off
@@ -524,9 +525,7 @@ class ArenaManager:
     def _reset_stats(self):
         ws = self._stats_ws
         if self._stats_need > (ws.numel() if ws is not None else 0):
-            self._stats_ws = torch.zeros(int(self._stats_need * 1.25) // 64 * 64 + 64, dtype=torch.float32, device=self.device)
-        elif ws is not None:
-            ws.zero_()
+            self._stats_ws = torch.empty(int(self._stats_need * 1.25) // 64 * 64 + 64, dtype=torch.float32, device=self.device)
         self._stats_off = 0
 
     def enter(self):

@@ -149,6 +149,12 @@ class ExponentialMovingAverage(nn.Module):
             info['num_updates'] += 1
             info['last_momemtum'] = m
 
+    def note_updates(self, n, momentum):
+        """host-side counters of the reference's per-variable `_info` for updates that ran inside a replayed graph"""
+        for info in self._info.values():
+            info['num_updates'] += n
+            info['last_momemtum'] = momentum
+
     def launch(self, mgr):
         from .. import ops
         ops.ema_update(mgr.EMA, mgr.P, mgr.nP, mgr.hyper)
@@ -180,6 +186,13 @@ class ExponentialMovingAverage(nn.Module):
                 warnings.warn(msg, RuntimeWarning)
                 logging.warning(msg)
         self._info = copy.deepcopy(state_dict['info'])
+        # the checkpoint REPLACES the shadow set (utils/optim.py:98-117 deep-copies state['shadow']): entries the checkpoint
+        # does not hold (e.g. branches a resumed, already shrunk run no longer has) must not survive next to the new `_info`
+        stale = [k for k in self._shadow if k not in state_dict['shadow']]
+        for k in stale:
+            del self._shadow[k]
+        if stale and self._mgr is not None:
+            self._mgr.mark_dirty()
         for k, v in state_dict['shadow'].items():
             if k in self._shadow and self._shadow[k].shape == v.shape:
                 self._shadow[k].copy_(v)

@@ -135,9 +135,45 @@ def cal_bn_l1_loss(bn_weights, penalties, rho):
     return _L1Function.apply(mgr.anchor, mgr, table, njobs)
 
 
+def alive_masks(weights, threshold, mode=0, with_index=False):
+    """Alive masks of a list of arena-backed BN gammas in ONE launch (atomnas_gamma_mask; train.py:46-63, utils/prune.py:190-195):
+    mode 0: |gamma| > thr, 1: |gamma| > thr OR |gamma_ema| > thr, 2: the EMA shadow only (the shadows live at the same offsets
+    of the EMA arena).  The compare is the plain fp32 one torch does for `tensor > python_float`, so masks, kept counts and
+    the ascending kept-channel indices are bit-exact with the reference.  Returns bool tensors (views of one byte buffer);
+    with_index: also (index int32 per tensor, kept counts int32[n])."""
+    import ctypes
+    if len(weights) == 0:
+        return ([], [], None) if with_index else []
+    mgr = getattr(weights[0], '_atomnas_mgr', None)
+    if mgr is None or any(getattr(w, '_atomnas_mgr', None) is not mgr for w in weights):
+        raise ops._lib.AtomnasHipError('alive_masks needs arena-backed BN weights of one model (run the model on the GPU first)')
+    mgr.ensure()
+    if mode != 0 and mgr.EMA is None:
+        raise RuntimeError('alive_masks(mode={}) needs the EMA attached to the model arenas'.format(mode))
+
+    class J(ctypes.Structure):
+        _fields_ = [("off", ctypes.c_long), ("count", ctypes.c_int), ("out_off", ctypes.c_int)]
+
+    jobs, pos = [], 0
+    for w in weights:
+        jobs.append(J(int(w._atomnas_off), int(w.numel()), pos))
+        pos += int(w.numel())
+    dev = mgr.P.device
+    table = torch.frombuffer(bytearray(bytes((J * len(jobs))(*jobs))), dtype=torch.uint8).clone().to(dev)
+    mask = torch.empty(pos, dtype=torch.uint8, device=dev)
+    index = torch.empty(pos, dtype=torch.int32, device=dev)
+    kept = torch.empty(len(jobs), dtype=torch.int32, device=dev)
+    ops.gamma_mask(mgr.P, mgr.EMA if mode != 0 else None, table, len(jobs), threshold, mode, mask, index, kept)
+    mb_ = mask.view(torch.bool)
+    masks = [mb_[j.out_off:j.out_off + j.count] for j in jobs]
+    if with_index:
+        return masks, [index[j.out_off:j.out_off + j.count] for j in jobs], kept
+    return masks
+
+
 def cal_mask_network_slimming_by_threshold(weights, threshold):
-    """Alive masks |gamma| > threshold (utils/prune.py:190-195); bit-exact fp32 compare."""
-    return [w.detach().abs() > threshold for w in weights]
+    """Alive masks |gamma| > threshold (utils/prune.py:190-195); bit-exact fp32 compare, one launch for all tensors."""
+    return alive_masks(list(weights), threshold, mode=0)
 
 
 def cal_mask_network_slimming_by_flops(weights, prune_info, flops_to_prune, incremental=False):

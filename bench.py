@@ -81,16 +81,17 @@ def algorithmic_bytes(tag_name, tag, itemsize):
 def kernel_profile(ts, itemsize):
     """Eager pass of the same step with HIP events around every C-ABI launch (on the launch stream)."""
     from atomnas_amd import _lib
-    was, world = ts.use_graph, ts.world_size
+    was = ts.use_graph
     ts.use_graph = False
-    ts.world_size = 1   # rank 0 profiles alone: no collective in this pass (the other ranks wait at the barrier)
-    ts.step(rho=1e-4)
+    # rank 0 profiles alone while the other ranks wait at the barrier: reduce=False keeps every collective out of this pass
+    # (the 1/world gradient scale of the optimizer graph is harmless here)
+    ts.step(rho=1e-4, reduce=False)
     torch.cuda.synchronize()
     _lib.PROFILE = []
-    ts.step(rho=1e-4)
+    ts.step(rho=1e-4, reduce=False)
     torch.cuda.synchronize()
     prof, _lib.PROFILE = _lib.PROFILE, None
-    ts.use_graph, ts.world_size = was, world
+    ts.use_graph = was
     agg = collections.OrderedDict()
     for name, tag, e0, e1 in prof:
         a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0))

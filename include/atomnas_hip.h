@@ -13,8 +13,13 @@
  *   - activations are NHWC viewed as [M = N*H*W rows][C channels] with an explicit channel pitch ld (elements);
  *     ld is a multiple of 8 and channels C..ld-1 hold zeros.  dtype: 0 = fp32, 1 = bf16 storage (fp32 accumulation).
  *   - per-channel fp32 vectors (scale, shift, c1..c3, gamma, ...) are readable up to C rounded up to 8.
- *   - "stats" outputs are accumulated atomically into zero-initialised fp32 buffers of shape [ATOMNAS_STAT_ROWS][2][C]
- *     (partial rows; the BatchNorm finalize functions sum them -- same-address atomics serialise on MI355X).
+ *   - "stats" outputs are PARTIAL ROWS: an fp32 buffer [stat_rows][2][pitch] (pitch = stat_ld, or N for the GEMM).  The
+ *     producing function writes EVERY row of its channel range with plain stores (one workgroup or wave owns a row; rows it
+ *     does not need are zero-filled), so the buffer needs no initialisation, nothing is accumulated atomically, and the
+ *     BatchNorm finalize functions, which sum rows 0..stat_rows-1 in a fixed order, give bit-identical results run to run.
+ *     More rows allow more concurrent workgroups (ATOMNAS_STAT_ROWS_DEFAULT is a good value for 64 <= C < 1024).
+ *   - weight gradients (depthwise taps, 1x1 weights) are likewise reduced from per-workgroup partials in a caller-owned
+ *     workspace in a fixed order; no entry point of this library accumulates floating-point values with atomics.
  */
 #ifndef ATOMNAS_HIP_H
 #define ATOMNAS_HIP_H
@@ -23,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ATOMNAS_STAT_ROWS 64
+#define ATOMNAS_STAT_ROWS_DEFAULT 512
 
 #define ATOMNAS_DT_F32 0
 #define ATOMNAS_DT_BF16 1
@@ -55,21 +60,23 @@ int atomnas_runtime_version(void);
 
 /* ---- depthwise k x k convolution: nn.Conv2d(C, C, k, stride, (k-1)/2, groups=C, bias=False)
  *      models/mobilenet_base.py:330-336 (built through ConvBNReLU :120-142); k in {3,5,7}, stride in {1,2}.
- * forward: y = dwconv(act(x*in_scale+in_shift));  stats[c], stats[stat_ld+c] += sum y, sum y^2   (in_scale == NULL: x as is)
+ * forward: y = dwconv(act(x*in_scale+in_shift));  stats rows [sum y, sum y^2] for channels 0..C-1   (in_scale == NULL: x as is)
  *   w: fp32 taps [k*k][ldw] (tap-major, see atomnas_pack_weights mode 2). */
 int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
-                       void* y, int ldy, float* stats, int stat_ld, int N, int H, int W, int C, int k, int stride, int dtype,
-                       void* stream);
+                       void* y, int ldy, float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int stride,
+                       int dtype, void* stream);
 
 /* backward (input gradient and weight gradient in one pass over the data):
  *   dYraw = c1*g + c2*yraw + c3  (yraw == NULL: dYraw = g)      -- BatchNorm backward of the BN after the conv
  *   h     = dwconv^T(dYraw) * [x*in_scale+in_shift > 0]         -- ReLU backward of the producer (if in_relu)
- *   dw[c][k*k] += corr(act(x*in_scale+in_shift), dYraw)         -- torch layout [C,1,k,k], fp32, atomically accumulated
- *   stats += [sum h, sum h*x]                                   -- for the producer's BatchNorm backward */
+ *   dw[c][k*k] += corr(act(x*in_scale+in_shift), dYraw)         -- torch layout [C,1,k,k], fp32; per-workgroup partials go to
+ *                                                                   dw_ws [part_rows][C][k*k] and are summed in a fixed order
+ *   stats rows [sum h, sum h*x]                                 -- for the producer's BatchNorm backward ([part_rows][2][stat_ld])
+ *   part_rows bounds the number of workgroups per channel slab (each owns one row of stats and of dw_ws). */
 int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
                        const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
-                       void* h, int ldh, float* dw, float* stats, int stat_ld, int N, int H, int W, int C, int k, int stride,
-                       int dtype, void* stream);
+                       void* h, int ldh, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W,
+                       int C, int k, int stride, int dtype, void* stream);
 
 /* ---- pointwise (1x1) convolutions as MFMA GEMMs: models/mobilenet_base.py:316-320 (expand), :338 (project),
  *      models/mobilenet_supernet.py:148-153 (last conv), :160-163 (classifier); branches concatenated (:378).
@@ -77,23 +84,26 @@ int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const
  *   prologue: a_mode (ATOMNAS_PRO_*), second stream a2, coefficient vectors ac1..ac3, a_relu for BNRELU
  *   wp: packed weights, storage dtype, [N rounded up to 64][ldw], ldw >= K rounded up to 32 (bf16) / 4 (fp32), padding zero
  *   epilogue: + bias[n]; + add[m][n]; if mask: c = 0 where z*zscale+zshift <= 0; store (fp32 if out_f32);
- *             stats per stat_mode on the stored value. */
+ *             stats per stat_mode on the stored value: partial rows [stat_rows][2][N]. */
 int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void* a2, int lda2, const float* ac1, const float* ac2,
                        const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, int out_f32, const void* add,
                        int ldadd, const void* z, int ldz, const float* zscale, const float* zshift, int mask, const float* bias,
-                       float* stats, int stat_mode, long M, int N, int K, int dtype, void* stream);
+                       float* stats, int stat_mode, int stat_rows, long M, int N, int K, int dtype, void* stream);
 
-/* weight gradient: out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]  (fp32, atomically accumulated) */
+/* weight gradient: out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]  (fp32).  The reduction over M is split into
+ *   row chunks whose partial outputs [chunk][NU][NV] go to the caller-owned workspace ws (ws_floats floats) and are summed in
+ *   chunk order; ws == NULL (or room for < 2 partials): one workgroup per output tile walks all of M. */
 int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void* u2, int ldu2, const float* uc1, const float* uc2,
                        const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, const void* v2, int ldv2,
                        const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out, long si, long sj, long M,
-                       int dtype, void* stream);
+                       float* ws, long ws_floats, int dtype, void* stream);
 
 /* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;
  *      kwargs from models/mobilenet_supernet.py:95-98; calibration mode utils/common.py:214-226.
- * finalize forward: stats=[sum x, sum x^2] over `count` elements -> scale = gamma*invstd, shift = beta - mean*scale,
- *   save_mean / save_invstd for backward, running statistics update (momentum < 0: cumulative average 1/(counter+1); the caller bumps the counter). */
-int atomnas_bn_finalize_fwd(const float* stats, double count, const float* gamma, const float* beta, float eps, float momentum,
+ * finalize forward: stats = stat_rows partial rows of [sum x, sum x^2] over `count` elements -> scale = gamma*invstd,
+ *   shift = beta - mean*scale, save_mean / save_invstd for backward, running statistics update (momentum < 0: cumulative
+ *   average 1/(counter+1); the caller bumps the counter). */
+int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, double count, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
                             float* save_mean, float* save_invstd, int C, void* stream);
 /* eval mode: scale/shift from the running statistics */
@@ -101,7 +111,7 @@ int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, const float* r
                            float* scale, float* shift, int C, void* stream);
 /* finalize backward: stats2=[sum g, sum g*x] -> dgamma (+ rho*penalty*sign(gamma), utils/prune.py:161-167), dbeta and the
  *   coefficients of dx = c1*g + c2*x + c3.  rho is read from device memory (rho_ptr, may be NULL). */
-int atomnas_bn_finalize_bwd(const float* stats2, double count, const float* gamma, const float* save_mean, const float* save_invstd,
+int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, double count, const float* gamma, const float* save_mean, const float* save_invstd,
                             const float* rho_ptr, const float* penalty, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
                             int C, void* stream);
 /* y = act(x*scale+shift) (+ res): the shared pw_bn + residual of a block, models/mobilenet_base.py:379-381 */
@@ -113,11 +123,11 @@ int atomnas_bn_act_pool(const void* x, int ldx, const float* scale, const float*
                         unsigned char* keep, float drop_p, unsigned long long seed, const long long* step_ptr, int N, int HW, int C,
                         int dtype, void* stream);
 int atomnas_pool_act_bwd(const void* dpooled, int ldp, const unsigned char* keep, float drop_p, const void* x, int ldx,
-                         const float* scale, const float* shift, int relu, void* g, int ldg, float* stats2, int N, int HW, int C,
-                         int dtype, void* stream);
-/* g = dy * [z*scale+shift > 0] (scale == NULL: no mask);  stats2 += [sum g, sum g*z];  g may be NULL (statistics only) */
+                         const float* scale, const float* shift, int relu, void* g, int ldg, float* stats2, int stat_rows, int N,
+                         int HW, int C, int dtype, void* stream);
+/* g = dy * [z*scale+shift > 0] (scale == NULL: no mask);  stats2 rows [sum g, sum g*z];  g may be NULL (statistics only) */
 int atomnas_act_bwd_stats(const void* dy, int lddy, const void* z, int ldz, const float* scale, const float* shift, int relu, void* g,
-                          int ldg, float* stats2, long M, int C, int dtype, void* stream);
+                          int ldg, float* stats2, int stat_rows, long M, int C, int dtype, void* stream);
 
 /* ---- stem and loss
  * im2col of the 3x3 stride-2 stem conv (models/mobilenet_supernet.py:126-132): img NCHW fp32 -> col [N*Ho*Wo][ld>=32] */
@@ -125,7 +135,7 @@ int atomnas_im2col_stem(const float* img, void* col, int ld, int N, int H, int W
 /* CrossEntropyLabelSmooth (utils/optim.py:180-207) + top-1/top-5 hit counters (common.py:73-79), no host sync.
  * dlogits = d(mean loss)/dlogits * gscale, storage dtype, columns K..ldd-1 zeroed. */
 int atomnas_ce_smooth(const float* logits, int ldl, const long long* target, float eps, int B, int K, float* loss_per_sample,
-                      float* loss_sum, void* dlogits, int ldd, float gscale, int* topk_correct, int dtype, void* stream);
+                      void* dlogits, int ldd, float gscale, int* topk_correct, int dtype, void* stream);
 int atomnas_colsum(const void* x, int ld, float* out, long M, int C, int dtype, void* stream);
 
 /* ---- optimizer tail on flat fp32 arenas (one launch for all parameters)
@@ -135,15 +145,13 @@ int atomnas_colsum(const void* x, int ld, float* out, long M, int C, int dtype, 
 int atomnas_fused_rmsprop_ema(float* p, const float* g, float* sq, float* buf, float* ema, const float* wd_chunk, long n,
                               const float* hyper, double alpha, double eps, int eps_inside_sqrt, double momentum, void* stream);
 int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper, void* stream);
-/* out += sum_i coef[i/256] * (p_i^2 | |p_i|): values of the L2 / L1 regularisers for logging (train.py:206-208) */
-int atomnas_weighted_norm(const float* p, const float* coef_chunk, long n, int use_abs, float* out, void* stream);
 /* regularisers as gradient contributions / values over a job table {long off; int count; float coef;}:
  *   cal_l2_loss (utils/optim.py:210-249): g += wd*p, value 0.5*wd*sum p^2;  cal_bn_l1_loss (utils/prune.py:161-167):
  *   g += rho*penalty*sign(gamma), value rho*penalty*sum|gamma|.  mult_ptr / grad_out_ptr: optional device scalars. */
 int atomnas_reg_grad(const float* p, float* g, const void* jobs_dev, int njobs, int use_sign, const float* mult_ptr,
                      const float* grad_out_ptr, void* stream);
 int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_abs, const float* mult_ptr, float post_scale,
-                      float* out, void* stream);
+                      float* out, float* ws /* scratch, 64 * njobs floats */, void* stream);
 /* re-pack fp32 master weights into kernel layouts; jobs_dev: device array of
  *   struct { long src_off, dst_off; int rows, cols, src_ld, dst_ld, c_off, mode; }  (mode 0 [N][K], 1 transposed, 2 depthwise taps) */
 int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream);
@@ -153,13 +161,8 @@ int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev
  *   jobs_dev: struct { long off; int count; int out_off; };  outputs: mask bytes, ascending kept-channel indices, kept counts */
 int atomnas_gamma_mask(const float* params, const float* ema, const void* jobs_dev, int njobs, float threshold, int mode,
                        unsigned char* mask, int* index, int* kept, void* stream);
-/* gather kept channels (models/compress_utils.py:31-37) for a list of tensors, applied to `narenas` arenas at once
- *   (parameters, RMSprop square_avg / momentum_buffer -- utils/rmsprop.py:134-165, EMA shadow -- utils/optim.py:134-153):
- *   jobs_dev: struct { long src_off, dst_off, src_os, src_ds, dst_os, dst_ds; int outer, n_kept, inner, idx_off; } */
-int atomnas_channel_repack(const void* src_ptrs_dev, const void* dst_ptrs_dev, int narenas, const void* jobs_dev, int njobs,
-                           const int* index, void* stream);
-
-/* single-tensor forms of the same repack, for the reference's per-tensor protocol info['mask_hook'](new, old, mask)
+/* channel repack in the reference's per-tensor protocol info['mask_hook'](new, old, mask), applied to weights, BN vectors,
+ *   RMSprop square_avg / momentum_buffer (utils/rmsprop.py:134-165) and EMA shadows (utils/optim.py:134-153)
  *   (models/compress_utils.py:31-37): kept-channel index of a byte mask, then a gather along one dimension of an fp32 tensor
  *   viewed as [outer][dim][inner] with explicit element strides. */
 int atomnas_mask_index(const unsigned char* mask, int count, int* index, int* kept, void* stream);

@@ -37,13 +37,23 @@ def shrink_model(model_wrapper, ema, optimizer, prune_info, threshold=1e-3, ema_
     import common as mc
     FLAGS = cfg.FLAGS
     model = mc.unwrap_model(model_wrapper)
-    for block_name, block in model.get_named_block_list().items():
+    # all alive masks in one launch over the parameter / EMA arenas (the reference: 63 x abs, compare, or, sum().item())
+    from atomnas_amd import runtime
+    blocks = list(model.get_named_block_list().items())
+    gammas, per_block = [], []
+    for block_name, block in blocks:
         assert isinstance(block, mb.InvertedResidualChannels)
-        masks = [bn.weight.detach().abs() > threshold for bn in block.get_depthwise_bn()]
-        if ema is not None:
-            masks_ema = [ema.average('{}.{}.weight'.format(block_name, name)).detach().abs() > threshold
-                         for name in block.get_named_depthwise_bn().keys()]
-            masks = masks_ema if ema_only else [a | b for a, b in zip(masks, masks_ema)]
+        bns = block.get_depthwise_bn()
+        per_block.append(len(bns))
+        gammas.extend(bn.weight for bn in bns)
+    if ema is not None:
+        ema.attach(runtime.manager_of(model))
+    all_masks = prune.alive_masks(gammas, threshold, mode=0 if ema is None else (2 if ema_only else 1))
+    all_masks = [m.clone() for m in all_masks]   # the arenas are rebuilt while the blocks are compressed
+    pos = 0
+    for (block_name, block), n in zip(blocks, per_block):
+        masks = all_masks[pos:pos + n]
+        pos += n
         block.compress_by_mask(masks, ema=ema, optimizer=optimizer, prune_info=prune_info, prefix=block_name, verbose=False)
     if optimizer is not None:
         assert set(id(p) for p in optimizer.param_groups[0]['params']) == set(id(p) for p in model.parameters())
