@@ -172,8 +172,14 @@ def alive_masks(weights, threshold, mode=0, with_index=False):
 
 
 def cal_mask_network_slimming_by_threshold(weights, threshold):
-    """Alive masks |gamma| > threshold (utils/prune.py:190-195); bit-exact fp32 compare, one launch for all tensors."""
-    return alive_masks(list(weights), threshold, mode=0)
+    """Alive masks |gamma| > threshold (utils/prune.py:190-195); bit-exact fp32 compare.  Arena-backed gammas (the training
+    path: train.py:383-386 passes the EMA model's BN weights) take one launch for all tensors; free-standing tensors, as in the
+    reference's unit tests (tests/utils/prune_test.py:54-64), are compared where they live."""
+    weights = list(weights)
+    mgr = getattr(weights[0], '_atomnas_mgr', None) if weights else None
+    if mgr is not None and all(getattr(w, '_atomnas_mgr', None) is mgr for w in weights):
+        return alive_masks(weights, threshold, mode=0)
+    return [w.detach().abs() > threshold for w in weights]
 
 
 def cal_mask_network_slimming_by_flops(weights, prune_info, flops_to_prune, incremental=False):
