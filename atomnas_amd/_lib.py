@@ -30,7 +30,8 @@ SIGNATURES = {
     "atomnas_im2col_stem": [vp, vp, i32, i32, i32, i32, i32, vp],
     "atomnas_ce_smooth": [vp, i32, vp, f32, i32, i32, vp, vp, i32, f32, vp, i32, vp],
     "atomnas_colsum": [vp, i32, vp, i64, i32, i32, vp],
-    "atomnas_fused_rmsprop_ema": [vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, i32, f64, vp],
+    "atomnas_fused_rmsprop_ema": [vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, i32, f64, vp, vp, vp],
+    "atomnas_vec_sum": [vp, i32, f32, vp, vp],
     "atomnas_ema_update": [vp, vp, i64, vp, vp],
     "atomnas_reg_grad": [vp, vp, vp, i32, i32, vp, vp, vp],
     "atomnas_reg_value": [vp, vp, i32, i32, vp, f32, vp, vp, vp],

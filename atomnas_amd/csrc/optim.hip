@@ -17,15 +17,18 @@ __global__ __launch_bounds__(256) void k_rmsprop_ema(float* __restrict__ p, cons
                                                      float* __restrict__ buf, float* __restrict__ ema,
                                                      const float* __restrict__ wd_chunk, long n, const float* __restrict__ hyper,
                                                      float alpha, float one_minus_alpha, float eps, int eps_inside_sqrt,
-                                                     float momentum) {
+                                                     float momentum, float* __restrict__ l2_part) {
 #pragma clang fp contract(off)  // keep the reference's separate roundings (no fused multiply-add)
+  __shared__ float s_part[4];
   const float lr = hyper[HYP_LR], d = hyper[HYP_EMA_DECAY], gs = hyper[HYP_GRAD_SCALE];
   const long nchunks = (n + 255) / 256;
+  float l2acc = 0.f;
   for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const long i = ch * 256 + threadIdx.x;
     if (i >= n) continue;
     const float wd = wd_chunk ? wd_chunk[ch] : 0.f;
     float pv = p[i];
+    l2acc += (wd * pv) * pv;   // value of the L2 regulariser at the weights this step's loss saw (before the update)
     float gv = g[i] * gs;
     gv = gv + wd * pv;
     float s = sq[i] * alpha;
@@ -43,6 +46,27 @@ __global__ __launch_bounds__(256) void k_rmsprop_ema(float* __restrict__ p, cons
     p[i] = pv;
     if (ema && d >= 0.f) ema[i] = ema[i] * d + (1.0f - d) * pv;
   }
+  if (l2_part) {   // per-workgroup partial, fixed order inside the workgroup; summed by k_sum_partials
+    l2acc = wave_sum(l2acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = l2acc;
+    __syncthreads();
+    if (threadIdx.x == 0) l2_part[blockIdx.x] = 0.5f * (((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
+  }
+}
+
+// one workgroup: out[0] (+)= scale * sum of n values in a fixed order (thread t adds t, t+256, ...; then a fixed tree)
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ ws, int n, float scale, int accumulate,
+                                                      float* __restrict__ out) {
+  __shared__ float s_t[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += ws[i];
+  s_t[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_t[threadIdx.x] += s_t[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * s_t[0];
 }
 
 __global__ __launch_bounds__(256) void k_ema(float* __restrict__ shadow, const float* __restrict__ x, long n,
@@ -81,15 +105,25 @@ using namespace atomnas;
 
 extern "C" int atomnas_fused_rmsprop_ema(float* p, const float* g, float* sq, float* buf, float* ema, const float* wd_chunk, long n,
                                          const float* hyper, double alpha, double eps, int eps_inside_sqrt, double momentum,
-                                         void* stream) {
+                                         float* l2_value, float* ws, void* stream) {
   ATOMNAS_REQUIRE(p && g && sq && hyper && n > 0, "fused_rmsprop_ema: bad arguments");
+  ATOMNAS_REQUIRE(!l2_value || (ws && wd_chunk), "fused_rmsprop_ema: the L2 value needs wd_chunk and a 4096-float workspace");
   ATOMNAS_REQUIRE(momentum >= 0.0 && alpha >= 0.0 && eps >= 0.0, "fused_rmsprop_ema: bad hyper-parameters");
   ATOMNAS_REQUIRE((momentum > 0.0) == (buf != nullptr), "fused_rmsprop_ema: momentum buffer must be given iff momentum > 0");
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_rmsprop_ema, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, buf, ema, wd_chunk, n, hyper,
-                     (float)alpha, (float)(1.0 - alpha), (float)eps, eps_inside_sqrt, (float)momentum);
+                     (float)alpha, (float)(1.0 - alpha), (float)eps, eps_inside_sqrt, (float)momentum, l2_value ? ws : nullptr);
+  if (l2_value)
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, (int)blocks, 1.f, 0, l2_value);
   return check_launch("fused_rmsprop_ema");
+}
+
+// out[0] = scale * sum_i x[i] in a fixed order (mean of the per-sample losses, train.py:178-180 `loss = torch.mean(loss)`)
+extern "C" int atomnas_vec_sum(const float* x, int n, float scale, float* out, void* stream) {
+  ATOMNAS_REQUIRE(x && out && n > 0, "vec_sum: bad arguments");
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, 0, out);
+  return check_launch("vec_sum");
 }
 
 extern "C" int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper, void* stream) {
@@ -152,19 +186,6 @@ __global__ __launch_bounds__(256) void k_reg_value(const float* __restrict__ p, 
   }
 }
 
-// stage 2 (one workgroup): out += sum of the n stage-1 partials in a fixed order (thread t adds t, t+256, ...; then a fixed tree)
-__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ ws, int n, float* __restrict__ out) {
-  __shared__ float s_t[256];
-  float a = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) a += ws[i];
-  s_t[threadIdx.x] = a;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) s_t[threadIdx.x] += s_t[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] += s_t[0];
-}
 }  // namespace atomnas
 
 // g[off+i] += coef * mult * go * (use_sign ? sign(p) : p) for every job {long off; int count; float coef;}
@@ -183,6 +204,6 @@ extern "C" int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs
   ATOMNAS_REQUIRE(p && out && ws && jobs_dev && njobs > 0, "reg_value: bad arguments");
   hipLaunchKernelGGL(atomnas::k_reg_value, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, p, (const atomnas::RegJob*)jobs_dev,
                      use_abs, mult_ptr, post_scale, ws);
-  hipLaunchKernelGGL(atomnas::k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, 64 * njobs, out);
+  hipLaunchKernelGGL(atomnas::k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, 64 * njobs, 1.f, 1, out);
   return atomnas::check_launch("reg_value");
 }

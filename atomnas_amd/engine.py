@@ -1,6 +1,6 @@
 """The training iteration of the hot path as one replayable hipGraph (train.py:165-236 of the reference, per process).
 
-    zero_grad -> forward -> CE-smooth mean (+ L2 + L1) -> backward -> [gradient all-reduce] -> RMSprop -> EMA
+    zero_grad -> forward -> CE-smooth mean -> backward -> [gradient all-reduce] -> L1 / L2 gradients + RMSprop + EMA
 
 Everything between the barriers is device work issued from Python once, captured with torch.cuda.graph (the HIP kernels
 are launched on the capturing stream through the C ABI, so they become graph nodes) and replayed every iteration.  Values
@@ -33,10 +33,14 @@ class TrainStep:
         if ema is not None:
             ema.attach(self.mgr)
         self.mgr.ensure()
-        self.criterion = aopt.CrossEntropyLabelSmooth(model.num_classes, label_smoothing, reduction='none')
+        self.label_smoothing = float(label_smoothing)
         self.x = torch.zeros(batch_size, 3, image_size, image_size, dtype=torch.float32, device=dev)
         self.y = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.loss = torch.zeros(3, dtype=torch.float32, device=dev)   # CE, L2, L1 of the last step
+        self._scal = torch.zeros(8, dtype=torch.float32, device=dev)   # per-step scalars, cleared by ONE memset per step
+        self.loss = self._scal[0:3]                                    # CE (mean), L2, L1 of the last step
+        self.topk = self._scal[4:6].view(torch.int32)                  # top-1 / top-5 hits of the last step (common.py:73-79)
+        self.loss_vec = torch.zeros(batch_size, dtype=torch.float32, device=dev)   # per-sample CE of the last step
+        self._tables_version = -1
         self.g_fwd_bwd = self.g_opt = None
         self._version = -1
         self.global_step = 0
@@ -48,37 +52,60 @@ class TrainStep:
         table = dict(self.model.named_parameters())
         return [table[n] for n in self.prune_info.weight], self.prune_info.penalty
 
+    def _tables(self):
+        """Per-arena-version device tables: weight-decay coefficient per 256-element chunk (cal_l2_loss, utils/optim.py:226-243:
+        every conv / fc weight and the classifier bias for 'mnas'; dense conv and fc weights for 'slimmable') and the L1 job
+        table (offset, count, penalty) of the prunable gammas (utils/prune.py:161-167)."""
+        mgr = self.mgr
+        if self._tables_version == mgr.version:
+            return
+        kinds = {'mnas': ('dense', 'dw', 'fc', 'fcbias'), 'slimmable': ('dense', 'fc')}.get(self.wd_method)
+        if kinds is None:
+            raise ValueError('Unknown weight_decay method: {}'.format(self.wd_method))
+        wd = torch.zeros(mgr.nP // runtime.ALIGN, dtype=torch.float32)
+        for kind, off, n in mgr.reg_slots:
+            if kind in kinds:
+                assert off % runtime.ALIGN == 0
+                wd[off // runtime.ALIGN:(off + n + runtime.ALIGN - 1) // runtime.ALIGN] = self.weight_decay
+        self._wd_chunk = wd.to(mgr.P.device)
+        w, pen = self._prune_weights()
+        self._l1 = mgr.reg_table([(p._atomnas_off, p.numel(), c) for p, c in zip(w, pen)]) if w else None
+        self._world = torch.full((1,), float(max(self.world_size, 1)), dtype=torch.float32, device=mgr.P.device)
+        self._ws = torch.empty(4096 + 64 * max(len(w), 1), dtype=torch.float32, device=mgr.P.device)
+        self._tables_version = mgr.version
+
     def _fwd_bwd(self):
+        """zero_grad -> forward -> label-smoothed CE (mean) -> backward, HIP launches only.  The regularisers do not go through
+        autograd here: their gradients are added in _opt (L1: one launch on the gamma job table after the all-reduce; L2: inside
+        the optimizer kernel), which is the same arithmetic as the reference's `loss + l2 + l1` backward because both terms are
+        identical on every rank (train.py:171-185)."""
         mgr = self.mgr
         mgr.zero_grad()
-        self.criterion.topk_correct = None if self.criterion.topk_correct is None else self.criterion.topk_correct.zero_()
-        logits = self.model(self.x)
-        loss = self.criterion(logits, self.y).mean()
-        l2 = aopt.cal_l2_loss(self.model, self.weight_decay, self.wd_method)
-        w, pen = self._prune_weights()
-        if w:
-            rho = float(mgr.hyper_host[ops.HYP_RHO])
-            l1 = aprune.cal_bn_l1_loss(w, pen, rho)
-            total = loss + l2 + l1
-            self.loss[2] = l1.detach()
-        else:
-            total = loss + l2
-        total.backward()
-        self.loss[0] = loss.detach()
-        self.loss[1] = l2.detach()
+        self._scal.zero_()
+        loss = self.model(self.x, loss_args=(self.y, self.label_smoothing, self.loss_vec, self.topk, self.loss[0:1]))
+        loss.backward()
 
     def _opt(self):
+        """[gradients summed over ranks] -> + world * rho * penalty * sign(gamma) -> RMSprop on g / world + wd * p (+ EMA of the
+        parameters, L2 value) -> L1 value -> EMA of the BN statistics."""
         mgr = self.mgr
-        if self.world_size > 1:
-            mgr.G.mul_(1.0 / self.world_size)
-        self.optimizer.launch(mgr)
+        rho_ptr = mgr.hyper[ops.HYP_RHO:ops.HYP_RHO + 1]
+        group = self.optimizer.param_groups[0]
+        if self._l1 is not None:
+            table, njobs = self._l1
+            ops.reg_value(mgr.P, table, njobs, 1, rho_ptr, 1.0, self.loss[2:3], ws=self._ws[4096:])
+            ops.reg_grad(mgr.P, mgr.G, table, njobs, 1, rho_ptr, self._world)
+        ops.fused_rmsprop_ema(mgr.P, mgr.G, mgr.SQ, mgr.BUF if group['momentum'] > 0 else None,
+                              mgr.EMA if self.ema is not None else None, self._wd_chunk, mgr.nP, mgr.hyper, group['alpha'],
+                              group['eps'], group['eps_inside_sqrt'], group['momentum'], l2_value=self.loss[1:2], ws=self._ws)
         if self.ema is not None:
-            self.ema.launch(mgr)
+            ops.ema_update(mgr.SEMA, mgr.S, mgr.nS, mgr.hyper)
         mgr.step_counter.add_(1)
 
     def _capture(self):
         mgr = self.mgr
         mgr.ensure()
+        self._tables()
         # warm-up outside capture (allocator pools, lazy initialisation); it must not leave a trace in the training state:
         # BN running statistics / counters are snapshotted and restored, gradients are re-zeroed by the step itself
         keep_s, keep_c = mgr.S.clone(), mgr.CNT.clone()
@@ -120,8 +147,10 @@ class TrainStep:
             mgr.ensure()
             self.g_fwd_bwd = self.g_opt = None
         h = mgr.hyper_host
+        self._tables()
         h[ops.HYP_LR] = float(self.optimizer.param_groups[0]['lr'] if lr is None else lr)
         h[ops.HYP_RHO] = float(rho)
+        h[ops.HYP_GRAD_SCALE] = 1.0 / max(self.world_size, 1)
         if self.ema is not None:
             h[ops.HYP_EMA_DECAY] = float(self.ema.momentum_at(self.global_step + 1) if ema_decay is None else ema_decay)
         else:

@@ -379,17 +379,21 @@ def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
     return logits[:, :Kc], sv
 
 
-def tail_backward(lp, fp, sv, dlogits):
-    """dlogits [N, K] (any float dtype) -> gradient wrt the tail input [M, cin]."""
+def tail_backward(lp, fp, sv, dlogits, dl_padded=None):
+    """dlogits [N, K] (any float dtype) -> gradient wrt the tail input [M, cin].  dl_padded: the same gradient already in the
+    compute dtype with the channel padding zeroed (what atomnas_ce_smooth writes), used as is."""
     mgr = lp.mgr
     T = mgr.compute_dtype
-    dev = dlogits.device
+    dev = sv["L"].device
     N, H, W = sv["dims"]
     M, HW = N * H * W, H * W
     Kc = fp.cout
     act = lp.act
-    dl = torch.zeros(N, pad8(Kc), dtype=T, device=dev)
-    dl[:, :Kc] = dlogits
+    if dl_padded is not None:
+        dl = dl_padded
+    else:
+        dl = torch.zeros(N, pad8(Kc), dtype=T, device=dev)
+        dl[:, :Kc] = dlogits
     # classifier
     ops.gemm_tn(dl, Kc, sv["pooled"], fp.cin, fp.W_grad, fp.cin, 1, N)
     if fp.bias_grad is not None:
@@ -429,6 +433,36 @@ def run_tail(lp, fp, x, anchor, drop_p, training, seed, step_ptr):
         return TailFunction.apply(x, anchor, lp, fp, drop_p, training, seed, step_ptr)
     logits, _ = tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, False)
     return logits
+
+
+class TailLossFunction(torch.autograd.Function):
+    """Tail (last 1x1 ConvBNReLU -> pool -> dropout -> classifier) + label-smoothed cross entropy, mean over the batch, as ONE
+    autograd node for engine.TrainStep: the loss kernel writes d(mean loss)/d(logits) directly in the compute dtype with zeroed
+    padding, so no ATen op (mean, its backward, dtype / padding copies) is left between the HIP launches
+    (train.py:176-180 `loss = forward_loss(...)`, utils/optim.py:199-207, common.py:67-80).
+    Returns the scalar mean loss; loss_vec / topk receive the per-sample losses and the top-1 / top-5 hit counts."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, lp, fp, drop_p, training, seed, step_ptr, target, eps, loss_vec, topk, loss_out):
+        logits, sv = tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, True)
+        B, K = logits.shape
+        T = lp.mgr.compute_dtype
+        dl = torch.empty(B, pad8(K), dtype=T, device=x.device)
+        ops.ce_smooth(logits, target, eps, B, K, loss_vec, dl, 1.0, topk)   # gscale 1: dl = d(mean loss)/d(logits)
+        ops.vec_sum(loss_vec, B, 1.0 / B, loss_out)
+        ctx.lp, ctx.fp, ctx.sv, ctx.dl = lp, fp, sv, dl
+        ctx.logits = logits
+        return loss_out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        # contract: the caller differentiates the loss itself (d total / d loss = 1, as train.py:181 `loss.backward()` does);
+        # gout is therefore not multiplied in (that would be an elementwise launch per step for a factor of one)
+        lp, fp, sv = ctx.lp, ctx.fp, ctx.sv
+        gx = tail_backward(lp, fp, sv, None, dl_padded=ctx.dl)
+        ctx.sv = ctx.dl = None
+        N, H, W = sv["dims"]
+        return (to_4d(gx, N, H, W, lp.cin),) + (None,) * 12
 
 
 # ---------------------------------------------------------------------------------------------- loss

@@ -56,7 +56,9 @@ class _HipModel(nn.Module):
     def get_named_block_list(self):
         return _get_named_block_list(self)
 
-    def forward(self, x):
+    def forward(self, x, loss_args=None):
+        """loss_args (engine.TrainStep only): (target, label_smoothing, loss_vec, topk, loss_out) -- the tail and the
+        label-smoothed cross entropy then run as one autograd node and the scalar mean loss is returned instead of the logits."""
         if not x.is_cuda:
             raise AF.ops._lib.AtomnasHipError('this model runs on the GPU through libatomnas_hip.so only (input is on %s)' % x.device)
         mgr = runtime.manager_of(self)
@@ -71,6 +73,11 @@ class _HipModel(nn.Module):
             k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
             if not (isinstance(last, ConvBNReLU) and isinstance(pool, nn.AvgPool2d) and y.shape[2] == k and y.shape[3] == k):
                 raise NotImplementedError('the tail must be 1x1 ConvBNReLU -> global AvgPool2d -> Dropout -> Linear')
+            if loss_args is not None:
+                target, eps, loss_vec, topk, loss_out = loss_args
+                return AF.TailLossFunction.apply(y, mgr.anchor, runtime.plan_of(last), runtime.plan_of(fc), drop.p,
+                                                 self.training and drop.training, self.dropout_seed, mgr.step_counter, target,
+                                                 float(eps), loss_vec, topk, loss_out)
             return AF.run_tail(runtime.plan_of(last), runtime.plan_of(fc), y, mgr.anchor, drop.p, self.training and drop.training,
                                self.dropout_seed, mgr.step_counter)
         finally:

@@ -176,9 +176,15 @@ def colsum(x, out, M, C):
     call("atomnas_colsum", _p(x), _ld(x), _p(out), M, C, dt_code(x.dtype), _stream())
 
 
-def fused_rmsprop_ema(p, g, sq, buf, ema, wd_chunk, n, hyper, alpha, eps, eps_inside_sqrt, momentum):
+def fused_rmsprop_ema(p, g, sq, buf, ema, wd_chunk, n, hyper, alpha, eps, eps_inside_sqrt, momentum, l2_value=None, ws=None):
+    if l2_value is not None and ws is None:
+        ws = torch.empty(4096, dtype=torch.float32, device=p.device)
     call("atomnas_fused_rmsprop_ema", _p(p), _p(g), _p(sq), _p(buf), _p(ema), _p(wd_chunk), n, _p(hyper), float(alpha), float(eps),
-         int(eps_inside_sqrt), float(momentum), _stream())
+         int(eps_inside_sqrt), float(momentum), _p(l2_value), _p(ws), _stream())
+
+
+def vec_sum(x, n, scale, out):
+    call("atomnas_vec_sum", _p(x), int(n), float(scale), _p(out), _stream())
 
 
 def ema_update(shadow, x, n, hyper):

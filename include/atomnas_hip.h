@@ -141,9 +141,14 @@ int atomnas_colsum(const void* x, int ld, float* out, long M, int C, int dtype, 
 /* ---- optimizer tail on flat fp32 arenas (one launch for all parameters)
  * L2 'mnas' (utils/optim.py:226-243) + RMSprop.step (utils/rmsprop.py:70-132) + EMA (utils/optim.py:54-65):
  *   g' = g*hyper[GRAD_SCALE] + wd_chunk[i/256]*p;  sq = alpha*sq + (1-alpha)*g'^2;  avg = sqrt(sq+eps) | sqrt(sq)+eps;
- *   buf = momentum*buf + g'/avg;  p -= hyper[LR]*buf;  ema = d*ema + (1-d)*p with d = hyper[EMA_DECAY] (d < 0: skip). */
+ *   buf = momentum*buf + g'/avg;  p -= hyper[LR]*buf;  ema = d*ema + (1-d)*p with d = hyper[EMA_DECAY] (d < 0: skip).
+ *   l2_value (optional): l2_value[0] = 0.5 * sum_i wd_chunk[i/256] * p_i^2 at the weights BEFORE the update (the value of
+ *   cal_l2_loss for logging, train.py:206-208), summed in a fixed order through the 4096-float workspace ws. */
 int atomnas_fused_rmsprop_ema(float* p, const float* g, float* sq, float* buf, float* ema, const float* wd_chunk, long n,
-                              const float* hyper, double alpha, double eps, int eps_inside_sqrt, double momentum, void* stream);
+                              const float* hyper, double alpha, double eps, int eps_inside_sqrt, double momentum, float* l2_value,
+                              float* ws, void* stream);
+/* out[0] = scale * sum_i x[i], fixed summation order: mean of the per-sample losses (train.py:178-180) */
+int atomnas_vec_sum(const float* x, int n, float scale, float* out, void* stream);
 int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper, void* stream);
 /* regularisers as gradient contributions / values over a job table {long off; int count; float coef;}:
  *   cal_l2_loss (utils/optim.py:210-249): g += wd*p, value 0.5*wd*sum p^2;  cal_bn_l1_loss (utils/prune.py:161-167):

@@ -426,6 +426,7 @@ def train_step(sd, spec, opt_state, ema_shadow, x, target, hp, prune_names=None,
     total = loss + loss_l2 + loss_l1
     total.backward()
     grads = {k: p.grad.detach().clone() for k, p in params.items()}
+    params_before = {k: p.detach().clone() for k, p in params.items()}
     with torch.no_grad():
         for k, p in params.items():
             st = opt_state.setdefault(k, {})
@@ -443,4 +444,4 @@ def train_step(sd, spec, opt_state, ema_shadow, x, target, hp, prune_names=None,
             for k in ema_shadow:
                 ema_update(ema_shadow[k], sd[k], d)
     return dict(loss=float(loss.detach()), loss_l2=float(torch.as_tensor(loss_l2).detach()), loss_l1=float(torch.as_tensor(loss_l1).detach()), logits=logits.detach(), grads=grads,
-                loss_vec=loss_vec.detach())
+                loss_vec=loss_vec.detach(), params_before=params_before)

@@ -42,61 +42,6 @@ def _setup(dtype):
     return model, sd, spec, pinfo, opt, ema, engine
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_train_steps_match_oracle(gpu_lib, use_graph):
-    model, sd, spec, pinfo, opt, ema, engine = _setup(torch.float32)
-    N = 6
-    ts = engine.TrainStep(model, opt, ema, pinfo, weight_decay=1e-3, label_smoothing=0.1, batch_size=N, image_size=64, use_graph=use_graph)
-    names, pen, _ = orc.prune_penalties(spec, 64)
-    assert names == pinfo.weight
-    assert_close("penalties", torch.tensor(pinfo.penalty), torch.tensor(pen), rtol=1e-12, atol=0)
-    opt_state = {}
-    ema_o = collections.OrderedDict((k, v.clone()) for k, v in sd.items() if v.is_floating_point())
-    g = torch.Generator().manual_seed(5)
-    # Two iterations: the second one exercises non-zero optimizer state, rho > 0 and the EMA decay schedule.  (Longer runs
-    # cannot be compared element-wise: fp32-vs-fp64 differences are amplified by the tiny-batch BatchNorms of this test net --
-    # the losses still agree to 5e-4 at the third iteration and drift at the fourth.)
-    for step in range(2):
-        x = torch.randn(N, 3, 64, 64, generator=g)
-        y = torch.randint(0, 10, (N,), generator=g)
-        lr, rho = 0.002 * (1 + step), 1e-3 * (1 + step)   # varying per step, as the schedulers do
-        d = ema.momentum_at(step + 1)
-        ts.set_batch(x.cuda(), y.cuda())
-        ts.step(lr=lr, rho=rho)
-        torch.cuda.synchronize()
-        ref = orc.train_step(sd, spec, opt_state, ema_o, x.double(), y, dict(lr=lr, rho=rho, weight_decay=1e-3, wd_method='mnas',
-                             label_smoothing=0.1, alpha=0.9, eps=1e-3, momentum=0.9, ema_decay=d), names, pen)
-        got = ts.loss.tolist()
-        assert abs(got[0] - ref['loss']) < 5e-4 * max(1, abs(ref['loss'])), (step, got, ref['loss'])
-        assert abs(got[1] - ref['loss_l2']) < 1e-5 * max(1, abs(ref['loss_l2'])), (step, got, ref['loss_l2'])
-        assert abs(got[2] - ref['loss_l1']) < 1e-4 * max(1e-3, abs(ref['loss_l1'])), (step, got, ref['loss_l1'])
-    # after the iterations: parameters, BN statistics, optimizer state, EMA shadows.
-    # The forward/backward of a ReLU network is discontinuous: fp32 sums differ from run to run in the last bits (order of
-    # the atomics), a pre-activation within that distance of zero flips its mask against the fp64 oracle, and a set of
-    # gradient elements (mostly of the stem, at the end of the backward chain) moves by a whole contribution; RMSprop
-    # then normalises those gradients to O(1).  So the state after two iterations is compared with bounded outliers and in
-    # aggregate; the optimizer / EMA arithmetic itself is pinned exactly in test_optimizer_and_ema_arithmetic below.
-    msd = model.state_dict()
-    for k, v in sd.items():
-        if v.is_floating_point():
-            s = max(1e-3, float(v.abs().max()))
-            assert_close("param " + k, msd[k], v, rtol=5e-3, atol=5e-3 * s, outlier_frac=0.03)
-        else:
-            assert int(msd[k]) == int(v) == 2, k
-    for key, floor in (("square_avg", 1e-6), ("momentum_buffer", 1e-2)):
-        num = den = 0.0
-        for n, p in model.named_parameters():
-            got, ref = opt.state[p][key].double().cpu(), opt_state[n][key]
-            num += float(((got - ref) ** 2).sum())
-            den += float((ref ** 2).sum())
-            s = max(floor, float(ref.abs().max()))
-            assert_close(key + " " + n, got, ref, rtol=2e-2, atol=1e-2 * s, outlier_frac=0.25)
-        assert (num / den) ** 0.5 < 5e-2, (key, (num / den) ** 0.5)
-    for k in ema_o:
-        s = max(1e-3, float(ema_o[k].abs().max()))
-        assert_close("ema " + k, ema.average(k), ema_o[k], rtol=2e-3, atol=2e-3 * s, outlier_frac=0.03)
-
-
 def test_optimizer_and_ema_arithmetic(gpu_lib):
     """RMSprop (TF variant, eps inside the sqrt, momentum), EMA and the L2 / L1 regulariser gradients on GIVEN gradients:
     no chaotic forward/backward in between, so the comparison with the oracle (utils/rmsprop.py:70-132, utils/optim.py:54-65,
@@ -147,6 +92,71 @@ def test_optimizer_and_ema_arithmetic(gpu_lib):
         for k in ref_ema:
             s = max(1e-3, float(ref_ema[k].abs().max()))
             assert_close("ema " + k, ema.average(k), ref_ema[k], rtol=1e-5, atol=1e-5 * s)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_steps_match_oracle(gpu_lib, use_graph):
+    model, sd, spec, pinfo, opt, ema, engine = _setup(torch.float32)
+    N = 6
+    ts = engine.TrainStep(model, opt, ema, pinfo, weight_decay=1e-3, label_smoothing=0.1, batch_size=N, image_size=64, use_graph=use_graph)
+    names, pen, _ = orc.prune_penalties(spec, 64)
+    assert names == pinfo.weight
+    assert_close("penalties", torch.tensor(pinfo.penalty), torch.tensor(pen), rtol=1e-12, atol=0)
+    opt_state = {}
+    ema_o = collections.OrderedDict((k, v.clone()) for k, v in sd.items() if v.is_floating_point())
+    g = torch.Generator().manual_seed(5)
+    # Two iterations: the second one exercises non-zero optimizer state, rho > 0 and the EMA decay schedule.  (Longer runs and
+    # larger inputs cannot be compared element-wise with a float64 implementation: ReLU masks of pre-activations within fp32
+    # rounding of zero flip and the trajectories separate -- at 128x128 / batch 8 the gradients agree to 2e-3 in the first and
+    # 5e-2 in the second iteration, bit-identically in every run; tools/trainstep_diag.py prints the evidence.)
+    for step in range(2):
+        x = torch.randn(N, 3, 64, 64, generator=g)
+        y = torch.randint(0, 10, (N,), generator=g)
+        lr, rho = 0.002 * (1 + step), 1e-3 * (1 + step)   # varying per step, as the schedulers do
+        d = ema.momentum_at(step + 1)
+        ts.set_batch(x.cuda(), y.cuda())
+        ts.step(lr=lr, rho=rho)
+        torch.cuda.synchronize()
+        ref = orc.train_step(sd, spec, opt_state, ema_o, x.double(), y, dict(lr=lr, rho=rho, weight_decay=1e-3, wd_method='mnas',
+                             label_smoothing=0.1, alpha=0.9, eps=1e-3, momentum=0.9, ema_decay=d), names, pen)
+        got = ts.loss.tolist()
+        assert abs(got[0] - ref['loss']) < 2e-5 * max(1, abs(ref['loss'])), (step, got, ref['loss'])
+        assert abs(got[1] - ref['loss_l2']) < 1e-5 * max(1, abs(ref['loss_l2'])), (step, got, ref['loss_l2'])
+        assert abs(got[2] - ref['loss_l1']) < 1e-4 * max(1e-3, abs(ref['loss_l1'])), (step, got, ref['loss_l1'])
+        # gradients of this iteration: the arena holds the data gradient + world * L1 sub-gradient (the L2 term is applied inside
+        # the optimizer kernel); compared in aggregate with the oracle's d(loss + l2 + l1) minus its L2 part
+        num = den = 0.0
+        for n, p in model.named_parameters():
+            r = ref['grads'][n]
+            if r.dim() in (2, 4) or (r.dim() == 1 and 'classifier' in n):
+                r = r - 1e-3 * ref['params_before'][n]
+            dd = p.grad.double().cpu() - r
+            num += float((dd * dd).sum()); den += float((r * r).sum())
+        assert (num / den) ** 0.5 < 1e-4, (step, (num / den) ** 0.5)
+    # after the iterations: parameters, BN statistics, optimizer state, EMA shadows.
+    # The kernels are bit-reproducible (tests/test_determinism_gpu.py), so this is a fixed comparison, not a statistical one:
+    # measured on MI355X (tools/trainstep_diag.py, profiles/r02_trainstep_diag.txt) all gradients of both iterations agree with
+    # the fp64 oracle to a relative L2 of 3e-6 for this network; the tolerances below are ~100x that, with no outlier allowance
+    # except for RMSprop's momentum buffer of tensors whose true gradient is zero (pw_bn.bias feeding a BatchNorm: g ~ 1e-8 noise
+    # divided by sqrt(eps)), which the absolute floor covers.
+    msd = model.state_dict()
+    for k, v in sd.items():
+        if v.is_floating_point():
+            s = max(1e-3, float(v.abs().max()))
+            assert_close("param " + k, msd[k], v, rtol=2e-4, atol=2e-5 * s)
+        else:
+            assert int(msd[k]) == int(v) == 2, k
+    for key, floor, rt in (("square_avg", 1e-9, 2e-3), ("momentum_buffer", 1e-4, 2e-3)):
+        num = den = 0.0
+        for n, p in model.named_parameters():
+            got, ref = opt.state[p][key].double().cpu(), opt_state[n][key]
+            num += float(((got - ref) ** 2).sum())
+            den += float((ref ** 2).sum())
+            assert_close(key + " " + n, got, ref, rtol=rt, atol=floor + 1e-4 * float(ref.abs().max()), outlier_frac=0.0)
+        assert (num / den) ** 0.5 < 1e-3, (key, (num / den) ** 0.5)
+    for k in ema_o:
+        s = max(1e-3, float(ema_o[k].abs().max()))
+        assert_close("ema " + k, ema.average(k), ema_o[k], rtol=2e-4, atol=2e-5 * s)
 
 
 def test_bf16_training_runs_and_learns(gpu_lib):

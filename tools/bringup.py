@@ -57,4 +57,4 @@ torch.cuda.synchronize(); t0 = time.time()
 K = 10
 for _ in range(K): ts.step(rho=1e-5)
 torch.cuda.synchronize(); dt = (time.time() - t0) / K
-print("graph ms/step %.2f  img/s %.0f" % (dt * 1e3, bs / dt), "loss", ts.loss.tolist(), "top", ts.criterion.topk_correct.tolist())
+print("graph ms/step %.2f  img/s %.0f" % (dt * 1e3, bs / dt), "loss", ts.loss.tolist(), "top", ts.topk.tolist())

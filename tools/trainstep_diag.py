@@ -78,6 +78,8 @@ def run(size, N, use_graph, dtype, compare):
         num = den = 0.0
         for n, p in model.named_parameters():
             gg, rr = p.grad.double().cpu(), ref['grads'][n]
+            if rr.dim() in (2, 4) or (rr.dim() == 1 and 'classifier' in n):   # the L2 gradient is applied inside the optimizer kernel
+                rr = rr - 1e-3 * ref['params_before'][n]
             e = (gg - rr)
             s = max(1e-12, float(rr.abs().max()))
             bad = float(((e.abs() > 1e-3 * s + 2e-3 * rr.abs()).double().mean()))
