@@ -13,13 +13,13 @@ vp, i32, i64, f32, f64, u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, cty
 
 # name -> argument ctypes (all return int status)
 SIGNATURES = {
-    "atomnas_dwconv_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "atomnas_dwconv_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32,
-                           i32, i32, i32, i32, i32, vp],
-    "atomnas_pw_gemm_nt": [i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp,
-                           vp, i32, i32, i64, i32, i32, i32, vp],
-    "atomnas_pw_gemm_tn": [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i64,
-                           i64, i64, vp, i64, i32, vp],
+    "atomnas_dwconv_fwd": [vp, i32, i64, vp, vp, i32, vp, i32, vp, i32, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "atomnas_dwconv_bwd": [vp, i32, i64, vp, i32, i64, vp, vp, vp, vp, i32, i64, vp, vp, i32, vp, i32, vp, i32, i64, vp, vp, i32, i32,
+                           vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "atomnas_pw_gemm_nt": [i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, vp, i32, vp, i32, i64, vp, vp,
+                           i32, vp, vp, i32, i32, i64, i32, i32, i32, vp],
+    "atomnas_pw_gemm_tn": [i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32,
+                           vp, i64, i64, i64, vp, i64, i32, vp],
     "atomnas_bn_finalize_fwd": [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     "atomnas_bn_finalize_bwd": [vp, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],

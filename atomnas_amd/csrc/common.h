@@ -125,6 +125,15 @@ __device__ __forceinline__ Act act_of(int mode) { return Act{mode != ACT_NONE, m
 __device__ __forceinline__ float act_apply(float a, Act m) { return fminf(m.relu ? fmaxf(a, 0.f) : a, m.hi); }
 __device__ __forceinline__ bool act_pass(float a, Act m) { return !(m.relu && !(a > 0.f)) && a < m.hi; }
 
+// Activation layouts (include/atomnas_hip.h).  plain: [M][ld], element (row, c) at row*ld + c.  slab-major (ss > 0): the channel
+// dimension is cut into slabs of 16 channels and every slab is a contiguous [M][16] matrix, slab stride ss elements:
+// (c/16)*ss + row*16 + c%16.  A workgroup that owns a channel range then streams CONTIGUOUS memory (32-byte pixels back to back)
+// instead of 32-byte fragments at the pixel pitch -- measured with tools/probe/membw.hip: 2.6-2.8 TB/s (fragments of a 432-channel
+// tensor) vs 5.3 TB/s (contiguous) for a 3-reads-1-write pass.  8-channel groups (16-byte accesses) never straddle a slab.
+__device__ __forceinline__ long lay_off(long row, int c, int ld, long ss) {
+  return ss ? (long)(c >> 4) * ss + row * 16 + (c & 15) : row * ld + c;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -108,6 +108,11 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
 }
 
+// Activation layouts (include/atomnas_hip.h): plain [M][ld] (ss == 0) or slab-major [C/16][M][16] with slab stride ss elements.
+// chan_base: offset of the 8-channel group starting at channel c (a multiple of 8); pix_stride: distance between pixels.
+__device__ __forceinline__ long chan_base(int c, long ss) { return ss ? (long)(c >> 4) * ss + (c & 15) : (long)c; }
+__device__ __forceinline__ long pix_stride(int ld, long ss) { return ss ? 16 : (long)ld; }
+
 struct DwGeom {
   int N, H, W, C, Ho, Wo;
   int CB;                 // channels per slab (8, 16, 32 or 64)
@@ -127,9 +132,9 @@ static inline int lds_pitch(int lw, int cb) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int K, int S, int SW, int CB, int TM, bool R6>
-__global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int ldx, const float* __restrict__ in_scale,
+__global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int ldx, long xss, const float* __restrict__ in_scale,
                                                     const float* __restrict__ in_shift, int in_relu,
-                                                    const float* __restrict__ w, int ldw, T* __restrict__ y, int ldy,
+                                                    const float* __restrict__ w, int ldw, T* __restrict__ y, int ldy, long yss,
                                                     float* __restrict__ stats, int stat_ld, int stat_rows, DwGeom g) {
   constexpr int P = (K - 1) / 2;
   constexpr int IWS = (SW - 1) * S + K;  // input columns one strip needs
@@ -188,13 +193,14 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   // rowmin: first tile row that has to be (re)loaded; rows below it are still in the LDS ring from the tile above
   auto issue = [&](int n, int ty, int tx, int rowmin) {
     const int hi0 = ty * g.TH * S - P, wi0 = tx * g.TW * S - P;
-    const T* xn = x + (long)n * g.H * g.W * ldx + c_base + cg * 8;
+    const long xps = pix_stride(ldx, xss);
+    const T* xn = x + (long)n * g.H * g.W * xps + chan_base(c_base + cg * 8, xss);
     pfmask = 0;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int hi = hi0 + p_iy[i], wi = wi0 + p_ix[i];
       if (cg_ok && p_iy[i] >= rowmin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
-        pf[i].load(xn + ((long)hi * g.W + wi) * ldx);
+        pf[i].load(xn + ((long)hi * g.W + wi) * xps);
         pfmask |= 1u << i;
       }
     }
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
         }
       }
       if (ch < cpad) {
-        T* yr = y + (((long)n * g.Ho + ho) * g.Wo) * ldy + ch;
+        const long yps = pix_stride(ldy, yss);
+        T* yr = y + (((long)n * g.Ho + ho) * g.Wo) * yps + chan_base(ch & ~7, yss) + (ch & 7);
 #pragma unroll
         for (int t = 0; t < SW; ++t) {
           const int wo = wo0 + j * SW + t;
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
             float o[2];
             o[0] = (ch < g.C) ? to_f32(from_f32<T>(acc[t][0])) : 0.f;
             o[1] = (ch + 1 < g.C) ? to_f32(from_f32<T>(acc[t][1])) : 0.f;
-            if (DW_EXP != 1) VecIO<T, 2>::store(yr + (long)wo * ldy, o);
+            if (DW_EXP != 1) VecIO<T, 2>::store(yr + (long)wo * yps, o);
             ssum[0] += o[0]; ssq[0] += o[0] * o[0];
             ssum[1] += o[1]; ssq[1] += o[1] * o[1];
           }
@@ -340,12 +347,12 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 // per (t, kx) that is a compile-time fact (tile and strip origins are even), per ky it is uniform for a row.
 template <typename T, int K, int S, int SW, int CB, bool R6>
 // (launch bounds for 3 resident workgroups, i.e. <= 168 VGPRs, make k = 5 spill 136 bytes and run 2.3x slower: measured, dropped)
-__global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, const T* __restrict__ yraw, int ldyr,
-                                                    const float* __restrict__ c1, const float* __restrict__ c2p,
-                                                    const float* __restrict__ c3, const T* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, long gss, const T* __restrict__ yraw, int ldyr,
+                                                    long yrss, const float* __restrict__ c1, const float* __restrict__ c2p,
+                                                    const float* __restrict__ c3, const T* __restrict__ x, int ldx, long xss,
                                                     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                     int in_relu, const float* __restrict__ w, int ldw, T* __restrict__ h, int ldh,
-                                                    float* __restrict__ dwp /*[nworkers][C][K*K] partial weight gradients*/,
+                                                    long hss, float* __restrict__ dwp /*[nworkers][C][K*K] partial weight gradients*/,
                                                     float* __restrict__ stats, int stat_ld, int stat_rows, DwGeom g) {
   constexpr int P = (K - 1) / 2;
   constexpr int KK = K * K;
@@ -418,8 +425,9 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   const unsigned rawy_base = lds_addr(s_rawy) + (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 64u * 16u;
   auto issue = [&](int n, int ty, int tx, int rowmin) {
     const int hob = cdiv(ty * g.TH + P - (K - 1), S), wob = (tx * g.TW) / S + RELMIN;
-    const T* gn = gup + (long)n * g.Ho * g.Wo * ldg + c_base + cg * 8;
-    const T* yn = yraw ? yraw + (long)n * g.Ho * g.Wo * ldyr + c_base + cg * 8 : nullptr;
+    const long gps = pix_stride(ldg, gss), yps = pix_stride(ldyr, yrss);
+    const T* gn = gup + (long)n * g.Ho * g.Wo * gps + chan_base(c_base + cg * 8, gss);
+    const T* yn = yraw ? yraw + (long)n * g.Ho * g.Wo * yps + chan_base(c_base + cg * 8, yrss) : nullptr;
     pfmask = 0;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
@@ -427,11 +435,11 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       if (DW_EXP != 8 && DW_EXP != 11 && cg_ok && p_iy[i] >= rowmin && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
         const long off = (long)ho * g.Wo + wo;
         if constexpr (DMA) {
-          lds_dma16(gn + off * ldg, rawg_base + (unsigned)i * 256u * 16u);
-          if (yn && DW_EXP != 9) lds_dma16(yn + off * ldyr, rawy_base + (unsigned)i * 256u * 16u);
+          lds_dma16(gn + off * gps, rawg_base + (unsigned)i * 256u * 16u);
+          if (yn && DW_EXP != 9) lds_dma16(yn + off * yps, rawy_base + (unsigned)i * 256u * 16u);
         } else {
-          pfg[i].load(gn + off * ldg);
-          if (yn && DW_EXP != 9) pfy[i].load(yn + off * ldyr);
+          pfg[i].load(gn + off * gps);
+          if (yn && DW_EXP != 9) pfy[i].load(yn + off * yps);
         }
         pfmask |= 1u << i;
       }
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       const int hi = aty * g.TH + xp_r[p], wi = atx * g.TW + xp_c[p];
       xr[p].zero();
       if (DW_EXP != 7 && DW_EXP != 11 && cg_ok && hi >= 0 && hi < g.H && wi < g.W)
-        xr[p].load(x + (((long)an * g.H + hi) * g.W + wi) * ldx + c_base + cg * 8);
+        xr[p].load(x + (((long)an * g.H + hi) * g.W + wi) * pix_stride(ldx, xss) + chan_base(c_base + cg * 8, xss));
     }
   };
   auto commit_x = [&]() {
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       if (DW_EXP != 6 && DW_EXP != 11 && cg_ok && hi >= 0 && hi < g.H && wi < g.W) {
         Raw8<T> v;
         v.load(s_h + (xp_r[p] * g.TW + xp_c[p]) * CB + cg * 8);
-        v.store(h + (((long)an * g.H + hi) * g.W + wi) * ldh + c_base + cg * 8);
+        v.store(h + (((long)an * g.H + hi) * g.W + wi) * pix_stride(ldh, hss) + chan_base(c_base + cg * 8, hss));
       }
     }
   };
@@ -745,8 +753,8 @@ static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap, long max_wor
 static inline unsigned dw_grid(const DwGeom& g) { return (unsigned)((g.nworkers + 7) / 8 * 8 * g.nslabs); }
 
 template <typename T, int K, int S>
-static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y,
-                      int ldy, float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, hipStream_t st) {
+static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y,
+                      int ldy, long yss, float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, hipStream_t st) {
   constexpr int P = (K - 1) / 2;
   DwGeom g;
   g.N = N; g.H = H; g.W = W; g.C = C;
@@ -778,7 +786,7 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
     auto kern = (relu == ACT_RELU6) ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, true> : k_dwconv_fwd<T, K, S, 7, CBV, TMV, false>;                                                                           \
     set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, stats ? stat_rows : 0);                                      \
     dim3 grid(dw_grid(g));                                                                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, sc, sh, relu, w, ldw, (T*)y, ldy, stats, stat_ld, stat_rows, g); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, xss, sc, sh, relu, w, ldw, (T*)y, ldy, yss, stats, stat_ld, stat_rows, g); \
   }
   const bool small = g.TH <= 7 && g.TW <= 7;
   if (cb == 8) { if (small) FWD_CASE(8, 7) else FWD_CASE(8, 14) }
@@ -790,9 +798,9 @@ static int launch_fwd(const void* x, int ldx, const float* sc, const float* sh, 
 }
 
 template <typename T, int K, int S>
-static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
-                      const void* x, int ldx, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h,
-                      int ldh, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C,
+static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int ldyr, long yrss, const float* c1, const float* c2,
+                      const float* c3, const void* x, int ldx, long xss, const float* sc, const float* sh, int relu, const float* w,
+                      int ldw, void* h, int ldh, long hss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C,
                       hipStream_t st) {
   constexpr int P = (K - 1) / 2;
   constexpr int SW = (S == 2) ? 14 : 7;
@@ -829,8 +837,8 @@ static int launch_bwd(const void* gup, int ldg, const void* yraw, int ldyr, cons
     auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, true> : k_dwconv_bwd<T, K, S, SW, CBV, false>;                                                                           \
     set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, (stats || dw) ? part_rows : 0);                               \
     dim3 grid(dw_grid(g));                                                                                       \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, (const T*)yraw, ldyr, c1, c2, c3, (const T*)x, ldx, sc, \
-                       sh, relu, w, ldw, (T*)h, ldh, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g);                 \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, gss, (const T*)yraw, ldyr, yrss, c1, c2, c3, (const T*)x, \
+                       ldx, xss, sc, sh, relu, w, ldw, (T*)h, ldh, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g); \
   }
   if (cb == 8) BWD_CASE(8) else if (cb == 16) BWD_CASE(16) else BWD_CASE(32)
 #undef BWD_CASE
@@ -875,26 +883,34 @@ namespace atomnas {
 
 using namespace atomnas;
 
-extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu,
-                                  const float* w, int ldw, void* y, int ldy, float* stats, int stat_ld, int stat_rows, int N, int H, int W,
+static inline bool lay_ok(int ld, long ss, int cpad, long rows) {
+  return ss ? (ss >= rows * 16) : (ld >= cpad && ld % 8 == 0);
+}
+
+extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, long x_ss, const float* in_scale, const float* in_shift, int in_relu,
+                                  const float* w, int ldw, void* y, int ldy, long y_ss, float* stats, int stat_ld, int stat_rows, int N, int H, int W,
                                   int C, int k, int stride, int dtype, void* stream) {
   ATOMNAS_REQUIRE(x && w && y, "dwconv_fwd: null pointer");
   ATOMNAS_REQUIRE((k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2), "dwconv_fwd: unsupported k=%d stride=%d", k, stride);
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_fwd: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "dwconv_fwd: empty shape");
   const int cpad = (C + 7) / 8 * 8;
-  ATOMNAS_REQUIRE(ldx >= cpad && ldy >= cpad && ldw >= C && ldx % 8 == 0 && ldy % 8 == 0,
-                  "dwconv_fwd: bad pitch (C=%d ldx=%d ldy=%d ldw=%d)", C, ldx, ldy, ldw);
+  {
+    const int P = (k - 1) / 2;
+    const long mi = (long)N * H * W, mo = (long)N * ((H + 2 * P - k) / stride + 1) * ((W + 2 * P - k) / stride + 1);
+    ATOMNAS_REQUIRE(lay_ok(ldx, x_ss, cpad, mi) && lay_ok(ldy, y_ss, cpad, mo) && ldw >= C,
+                    "dwconv_fwd: bad pitch / slab stride (C=%d ldx=%d ldy=%d ldw=%d)", C, ldx, ldy, ldw);
+  }
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_fwd: scale/shift must come together");
   ATOMNAS_REQUIRE(!stats || (stat_ld >= C && stat_rows > 0), "dwconv_fwd: statistics pitch %d < C=%d or stat_rows=%d", stat_ld, C, stat_rows);
   hipStream_t st = (hipStream_t)stream;
-  DW_DISPATCH(launch_fwd, x, ldx, in_scale, in_shift, in_relu, w, ldw, y, ldy, stats, stat_ld, stat_rows, N, H, W, C, st);
+  DW_DISPATCH(launch_fwd, x, ldx, x_ss, in_scale, in_shift, in_relu, w, ldw, y, ldy, y_ss, stats, stat_ld, stat_rows, N, H, W, C, st);
   return 1;
 }
 
-extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2,
-                                  const float* c3, const void* x, int ldx, const float* in_scale, const float* in_shift,
-                                  int in_relu, const float* w, int ldw, void* h, int ldh, float* dw, float* stats, int stat_ld,
+extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, long g_ss, const void* yraw, int ldyr, long yraw_ss, const float* c1,
+                                  const float* c2, const float* c3, const void* x, int ldx, long x_ss, const float* in_scale,
+                                  const float* in_shift, int in_relu, const float* w, int ldw, void* h, int ldh, long h_ss, float* dw, float* stats, int stat_ld,
                                   int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride, int dtype,
                                   void* stream) {
   ATOMNAS_REQUIRE(g && x && w && h, "dwconv_bwd: null pointer");
@@ -902,15 +918,17 @@ extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int 
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv_bwd: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "dwconv_bwd: empty shape");
   const int cpad = (C + 7) / 8 * 8;
-  ATOMNAS_REQUIRE(ldx >= cpad && ldg >= cpad && ldh >= cpad && ldw >= C && ldx % 8 == 0 && ldg % 8 == 0 && ldh % 8 == 0,
-                  "dwconv_bwd: bad pitch");
-  ATOMNAS_REQUIRE(!yraw || (c1 && c2 && c3 && ldyr >= cpad && ldyr % 8 == 0), "dwconv_bwd: yraw needs c1,c2,c3 and a valid pitch");
+  const int Pk = (k - 1) / 2;
+  const long mi = (long)N * H * W, mo = (long)N * ((H + 2 * Pk - k) / stride + 1) * ((W + 2 * Pk - k) / stride + 1);
+  ATOMNAS_REQUIRE(lay_ok(ldx, x_ss, cpad, mi) && lay_ok(ldg, g_ss, cpad, mo) && lay_ok(ldh, h_ss, cpad, mi) && ldw >= C,
+                  "dwconv_bwd: bad pitch / slab stride");
+  ATOMNAS_REQUIRE(!yraw || (c1 && c2 && c3 && lay_ok(ldyr, yraw_ss, cpad, mo)), "dwconv_bwd: yraw needs c1,c2,c3 and a valid pitch");
   ATOMNAS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_bwd: scale/shift must come together");
   ATOMNAS_REQUIRE(!stats || stat_ld >= C, "dwconv_bwd: statistics pitch %d < C=%d", stat_ld, C);
   ATOMNAS_REQUIRE(!(stats || dw) || part_rows > 0, "dwconv_bwd: part_rows must be positive");
   ATOMNAS_REQUIRE(!dw || dw_ws, "dwconv_bwd: the weight gradient needs the partial workspace dw_ws [part_rows][C][k*k]");
   hipStream_t st = (hipStream_t)stream;
-  DW_DISPATCH(launch_bwd, g, ldg, yraw, ldyr, c1, c2, c3, x, ldx, in_scale, in_shift, in_relu, w, ldw, h, ldh, dw, stats, stat_ld,
-              part_rows, dw_ws, N, H, W, C, st);
+  DW_DISPATCH(launch_bwd, g, ldg, g_ss, yraw, ldyr, yraw_ss, c1, c2, c3, x, ldx, x_ss, in_scale, in_shift, in_relu, w, ldw, h, ldh,
+              h_ss, dw, stats, stat_ld, part_rows, dw_ws, N, H, W, C, st);
   return 1;
 }

@@ -54,6 +54,7 @@ template <> struct Mma<float> {
 struct Operand {
   const void* p1; int ld1;   // main stream
   const void* p2; int ld2;   // second stream (PRO_BNBWD: the raw activation x)
+  long ss1, ss2;             // slab strides of the two streams (0: plain [M][ld]; see lay_off in common.h)
   const float* c1;           // BNRELU: scale   | BNBWD: c1
   const float* c2;           // BNRELU: shift   | BNBWD: c2
   const float* c3;           //                 | BNBWD: c3
@@ -69,7 +70,7 @@ __device__ __forceinline__ void load_pro(const Operand& o, long row, bool rowval
     for (int e = 0; e < E; ++e) v[e] = 0.f;
     return;
   }
-  VecIO<T, E>::load(reinterpret_cast<const T*>(o.p1) + row * o.ld1 + k, v);
+  VecIO<T, E>::load(reinterpret_cast<const T*>(o.p1) + lay_off(row, k, o.ld1, o.ss1), v);
   if constexpr (MODE == PRO_BNRELU) {
     float s[E], h[E];
     VecIO<float, E>::load(o.c1 + k, s);
@@ -81,7 +82,7 @@ __device__ __forceinline__ void load_pro(const Operand& o, long row, bool rowval
     }
   } else if constexpr (MODE == PRO_BNBWD) {
     float x[E], a1[E], a2[E], a3[E];
-    VecIO<T, E>::load(reinterpret_cast<const T*>(o.p2) + row * o.ld2 + k, x);
+    VecIO<T, E>::load(reinterpret_cast<const T*>(o.p2) + lay_off(row, k, o.ld2, o.ss2), x);
     VecIO<float, E>::load(o.c1 + k, a1);
     VecIO<float, E>::load(o.c2 + k, a2);
     VecIO<float, E>::load(o.c3 + k, a3);
@@ -106,7 +107,7 @@ __device__ __forceinline__ void load_pro_lds(const Operand& o, long row, bool ro
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
     return;
   }
-  VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(o.p1) + row * o.ld1 + k, v);
+  VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(o.p1) + lay_off(row, k, o.ld1, o.ss1), v);
   if constexpr (MODE == PRO_BNRELU) {
     float s[8], h[8];
     VecIO<float, 8>::load(lc1, s);
@@ -118,7 +119,7 @@ __device__ __forceinline__ void load_pro_lds(const Operand& o, long row, bool ro
     }
   } else if constexpr (MODE == PRO_BNBWD) {
     float x[8], a1[8], a2[8], a3[8];
-    VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(o.p2) + row * o.ld2 + k, x);
+    VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(o.p2) + lay_off(row, k, o.ld2, o.ss2), x);
     VecIO<float, 8>::load(lc1, a1);
     VecIO<float, 8>::load(lc2, a2);
     VecIO<float, 8>::load(lc3, a3);
@@ -141,8 +142,9 @@ __device__ __forceinline__ void stage_coeffs(const Operand& o, int col0, int n, 
 
 struct Epilogue {
   void* c; int ldc; int out_f32;       // output [M, N] (storage T, or fp32 when out_f32)
-  const void* add; int ldadd;          // optional residual stream (storage T)
+  const void* add; int ldadd;          // optional residual stream (storage T, plain layout)
   const void* z; int ldz;              // optional raw activation stream (storage T) for mask / STAT_Z
+  long css, zss;                       // slab strides of c and z (0: plain)
   const float* zscale; const float* zshift; int mask;  // mask: c *= [z*zscale+zshift > 0]
   const float* bias;                   // optional per-output-channel bias
   float* stats; int stat_mode;         // [stat_rows][2][N] fp32 partial rows: one row per workgroup row-slot, plain stores (common.h)
@@ -186,7 +188,7 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
         for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
       }
       if (ep.z) {
-        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + row * ep.ldz + n8, tmp);
+        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss), tmp);
 #pragma unroll
         for (int i = 0; i < 8; ++i) zv[8 * h8 + i] = tmp[i];
         if (ep.mask) {
@@ -202,7 +204,7 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
       for (int i = 0; i < 8; ++i)
         if (n8 + i >= N) c[8 * h8 + i] = 0.f;
       if (ep.out_f32) {
-        float* cp = reinterpret_cast<float*>(ep.c) + row * ep.ldc + n8;
+        float* cp = reinterpret_cast<float*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css);
         float o8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
@@ -214,7 +216,7 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
           o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
           c[8 * h8 + i] = o8[i];  // statistics see the stored value
         }
-        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + row * ep.ldc + n8, o8);
+        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
       }
     }
   } else {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
         for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
       }
       if (ep.z) {
-        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + row * ep.ldz + n8, zv);
+        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss), zv);
         if (ep.mask) {
           float zs[8], zh[8];
           VecIO<float, 8>::load(ep.zscale + n8, zs);
@@ -428,11 +430,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
       if (ep.out_f32) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
-        VecIO<float, 8>::store(reinterpret_cast<float*>(ep.c) + row * ep.ldc + n8, o8);
+        VecIO<float, 8>::store(reinterpret_cast<float*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
-        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + row * ep.ldc + n8, o8);
+        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
       }
       if (do_stats) {
 #pragma unroll
@@ -578,9 +580,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
           anx[s][ks].a = z;
           if constexpr (MODE == PRO_BNBWD) anx[s][ks].x = z;
           if (rowvalid[s] && k < K) {   // beyond K the packed weights are zero: no masking needed, but never read past a row
-            anx[s][ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + row[s] * A.ld1 + k);
+            anx[s][ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row[s], k, A.ld1, A.ss1));
             if constexpr (MODE == PRO_BNBWD)
-              anx[s][ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + row[s] * A.ld2 + k);
+              anx[s][ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row[s], k, A.ld2, A.ss2));
           }
         }
     };
@@ -1124,9 +1126,10 @@ static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Opera
 }
 
 static int check_operand(const char* who, const Operand& o, int mode, int C) {
-  ATOMNAS_REQUIRE(o.p1 != nullptr && o.ld1 >= C && o.ld1 % 8 == 0, "%s: bad main stream (ld=%d, C=%d)", who, o.ld1, C);
+  ATOMNAS_REQUIRE(o.p1 != nullptr && (o.ss1 > 0 || (o.ld1 >= C && o.ld1 % 8 == 0)), "%s: bad main stream (ld=%d, C=%d)", who, o.ld1, C);
   if (mode == PRO_BNRELU) ATOMNAS_REQUIRE(o.c1 && o.c2, "%s: BNRELU prologue needs scale and shift", who);
-  if (mode == PRO_BNBWD) ATOMNAS_REQUIRE(o.p2 && o.ld2 >= C && o.ld2 % 8 == 0 && o.c1 && o.c2 && o.c3, "%s: BNBWD prologue needs x, c1, c2, c3", who);
+  if (mode == PRO_BNBWD)
+    ATOMNAS_REQUIRE(o.p2 && (o.ss2 > 0 || (o.ld2 >= C && o.ld2 % 8 == 0)) && o.c1 && o.c2 && o.c3, "%s: BNBWD prologue needs x, c1, c2, c3", who);
   return 0;
 }
 
@@ -1146,15 +1149,17 @@ using namespace atomnas;
 
 // C[M,N] = epilogue( prologue(A)[M,K] x Wp[N,K]^T ).  Wp is the packed weight (storage dtype, row pitch ldw >= K rounded
 // up to the MFMA k-step, rows padded to a multiple of 64, padding zero) produced by atomnas_pack_weights.
-extern "C" int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void* a2, int lda2, const float* ac1, const float* ac2,
-                                  const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, int out_f32,
-                                  const void* add, int ldadd, const void* z, int ldz, const float* zscale, const float* zshift,
+extern "C" int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, long a_ss, const void* a2, int lda2, long a2_ss, const float* ac1,
+                                  const float* ac2, const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, long c_ss,
+                                  int out_f32, const void* add, int ldadd, const void* z, int ldz, long z_ss, const float* zscale,
+                                  const float* zshift,
                                   int mask, const float* bias, float* stats, int stat_mode, int stat_rows, long M, int N, int K,
                                   int dtype, void* stream) {
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pw_gemm_nt: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(a_mode >= PRO_NONE && a_mode <= PRO_BNBWD, "pw_gemm_nt: bad prologue %d", a_mode);
   ATOMNAS_REQUIRE(M > 0 && N > 0 && K > 0, "pw_gemm_nt: empty shape");
-  ATOMNAS_REQUIRE(wp && c && ldc >= N && ldc % 8 == 0, "pw_gemm_nt: bad output/weights");
+  ATOMNAS_REQUIRE(wp && c && (c_ss >= M * 16 || (c_ss == 0 && ldc >= N && ldc % 8 == 0)), "pw_gemm_nt: bad output/weights");
+  ATOMNAS_REQUIRE(a_ss == 0 || a_ss >= M * 16, "pw_gemm_nt: slab stride of A smaller than M*16");
   {
     const int ks = (dtype == DT_BF16) ? 32 : 4;
     ATOMNAS_REQUIRE(ldw >= (K + ks - 1) / ks * ks && ldw % 8 == 0, "pw_gemm_nt: packed weight pitch %d too small for K=%d", ldw, K);
@@ -1162,12 +1167,12 @@ extern "C" int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void
   ATOMNAS_REQUIRE(!stats || N <= NT_MAX_STAT, "pw_gemm_nt: N=%d too wide for fused statistics", N);
   ATOMNAS_REQUIRE(!stats || stat_mode == STAT_NONE || stat_rows > 0, "pw_gemm_nt: statistics need stat_rows > 0");
   ATOMNAS_REQUIRE(!add || (ldadd >= N && ldadd % 8 == 0), "pw_gemm_nt: bad residual pitch");
-  ATOMNAS_REQUIRE(!z || (ldz >= N && ldz % 8 == 0), "pw_gemm_nt: bad z pitch");
+  ATOMNAS_REQUIRE(!z || z_ss >= M * 16 || (z_ss == 0 && ldz >= N && ldz % 8 == 0), "pw_gemm_nt: bad z pitch");
   ATOMNAS_REQUIRE(!mask || (z && zscale && zshift), "pw_gemm_nt: mask needs z, zscale, zshift");
   ATOMNAS_REQUIRE(stat_mode != STAT_Z || z, "pw_gemm_nt: STAT_Z needs z");
-  Operand A{a, lda, a2, lda2, ac1, ac2, ac3, a_relu};
+  Operand A{a, lda, a2, lda2, a_ss, a2_ss, ac1, ac2, ac3, a_relu};
   if (check_operand("pw_gemm_nt", A, a_mode, K)) return 1;
-  Epilogue ep{c, ldc, out_f32, add, ldadd, z, ldz, zscale, zshift, mask, bias, stats, stat_mode, stat_rows};
+  Epilogue ep{c, ldc, out_f32, add, ldadd, z, ldz, c_ss, z_ss, zscale, zshift, mask, bias, stats, stat_mode, stat_rows};
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32) return launch_nt<float>(a_mode, A, wp, ldw, ep, M, N, K, st);
   return launch_nt<bf16_t>(a_mode, A, wp, ldw, ep, M, N, K, st);
@@ -1176,14 +1181,15 @@ extern "C" int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void
 // out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]   (fp32 accumulation into `out`, caller zeroes it).
 // ws: caller-owned scratch of ws_floats floats for the per-row-chunk partial outputs (summed in chunk order, no atomics:
 // bit-reproducible); with ws == NULL or room for fewer than two partials the reduction over M runs in a single workgroup per tile.
-extern "C" int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void* u2, int ldu2, const float* uc1, const float* uc2,
-                                  const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, const void* v2,
-                                  int ldv2, const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out,
+extern "C" int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, long u_ss, const void* u2, int ldu2, long u2_ss, const float* uc1,
+                                  const float* uc2, const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, long v_ss,
+                                  const void* v2, int ldv2, long v2_ss, const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out,
                                   long si, long sj, long M, float* ws, long ws_floats, int dtype, void* stream) {
   ATOMNAS_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pw_gemm_tn: bad dtype %d", dtype);
   ATOMNAS_REQUIRE(M > 0 && NU > 0 && NV > 0 && out, "pw_gemm_tn: empty shape");
-  Operand U{u, ldu, u2, ldu2, uc1, uc2, uc3, u_relu};
-  Operand V{v, ldv, v2, ldv2, vc1, vc2, vc3, v_relu};
+  Operand U{u, ldu, u2, ldu2, u_ss, u2_ss, uc1, uc2, uc3, u_relu};
+  Operand V{v, ldv, v2, ldv2, v_ss, v2_ss, vc1, vc2, vc3, v_relu};
+  ATOMNAS_REQUIRE((u_ss == 0 || u_ss >= M * 16) && (v_ss == 0 || v_ss >= M * 16), "pw_gemm_tn: slab stride smaller than M*16");
   if (check_operand("pw_gemm_tn(U)", U, u_mode, NU)) return 1;
   if (check_operand("pw_gemm_tn(V)", V, v_mode, NV)) return 1;
   hipStream_t st = (hipStream_t)stream;

@@ -8,12 +8,15 @@ Parameter gradients are written straight into the gradient arena (p.grad views) 
 Reference call sites: InvertedResidualChannels.forward (models/mobilenet_base.py:371-382), ConvBNReLU (:120-142),
 MobileNetV2.forward (models/mobilenet_supernet.py:169-173), CrossEntropyLabelSmooth.forward (utils/optim.py:199-207).
 """
+import os
+
 import torch
 from torch import nn
 
 from . import ops
 from .ops import PRO_BNBWD, PRO_BNRELU, PRO_NONE, STAT_SQ, STAT_Z
-from .runtime import pad8
+from .ops import Slab
+from .runtime import pad8, pads
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2   # the integer `relu` / `mask` arguments of the C ABI
 
@@ -124,6 +127,18 @@ def bn_backward_coeffs(bn, st, stats2, count, dev):
 
 
 # ---------------------------------------------------------------------------------------------- atomic block
+_PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))   # experiment switch (same-box A/B of the two layouts)
+
+
+def _hidden(pl, M, C, T, dev):
+    """hidden tensor of a block: slab-major (ops.Slab) for expanding blocks, plain [M, C] for the narrow non-expanding one"""
+    return Slab(M, C, T, dev) if (pl.expand and not _PLAIN_HIDDEN) else torch.empty(M, C, dtype=T, device=dev)
+
+
+def _seg(t, o):
+    return t.seg(o) if isinstance(t, Slab) else (t[:, o:] if o else t)
+
+
 def block_forward(pl, x2d, N, H, W, need_grad):
     """InvertedResidualChannels.forward on arena views.  Returns (out2d, saved) -- saved is None when need_grad is False."""
     dev, T = x2d.device, x2d.dtype
@@ -136,7 +151,7 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     sv = {}
     if pl.expand:
         bs = bn_uses_batch_stats(pl.bne)
-        E = torch.empty(M, HT, dtype=T, device=dev)
+        E = _hidden(pl, M, HT, T, dev)
         stE = _stats(HT, dev, pl.bne["mgr"]) if bs else None
         ops.gemm_nt(x2d, pl.We_pack, E, M, HT, pl.inp, stats=stE.t if bs else None, stat_mode=STAT_SQ if bs else 0,
                     stat_rows=stE.rows if bs else None)
@@ -144,12 +159,12 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     else:
         E, bE = x2d, None
     bsd = bn_uses_batch_stats(pl.bnd)
-    D = torch.empty(M2, HT, dtype=T, device=dev)
+    D = _hidden(pl, M2, HT, T, dev)
     stD = _stats(HT, dev, pl.bnd["mgr"]) if bsd else None
     for i in range(pl.nb):
-        o, c = pl.seg[i], pad8(pl.hid[i])
-        xin = E[:, o:] if pl.expand else E
-        ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], D[:, o:],
+        o, c = pl.seg[i], pl.segpad(pl.hid[i])
+        xin = _seg(E, o) if pl.expand else E
+        ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], _seg(D, o),
                        stD.at(o) if bsd else None, HT, N, H, W, c, pl.ks[i], s, stat_rows=stD.rows if bsd else None)
     bD = bn_forward_coeffs(pl.bnd, stD, M2, dev)
     bsp = bn_uses_batch_stats(pl.bnp)
@@ -181,27 +196,27 @@ def block_backward(pl, sv, G):
     ops.gemm_tn(G, pl.oup, D, HT, pl.Wp_grad, HT, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
                 vc1=bD.scale, vc2=bD.shift, v_relu=int(act))
     # projection input gradient, masked by the depthwise ReLU, with the depthwise-BN backward statistics
-    g = torch.empty(M2, HT, dtype=T, device=dev)
+    g = _hidden(pl, M2, HT, T, dev)
     st2D = _stats(HT, dev, pl.bnd["mgr"])
     ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
                 zshift=bD.shift, mask=int(act), stats=st2D.t, stat_mode=STAT_Z, stat_rows=st2D.rows)
     d1, d2, d3 = bn_backward_coeffs(pl.bnd, bD, st2D, M2, dev)
     # depthwise backward per branch
     if pl.expand:
-        h = torch.empty(M, HT, dtype=T, device=dev)
+        h = _hidden(pl, M, HT, T, dev)
         st2E = _stats(HT, dev, pl.bne["mgr"])
     else:
         h = torch.zeros(M, pl.inp, dtype=T, device=dev) if pl.nb > 1 else torch.empty(M, pl.inp, dtype=T, device=dev)
         st2E = None
     for i in range(pl.nb):
-        o, c = pl.seg[i], pad8(pl.hid[i])
+        o, c = pl.seg[i], pl.segpad(pl.hid[i])
         if pl.expand:
-            ops.dwconv_bwd(g[:, o:], D[:, o:], d1[o:], d2[o:], d3[o:], E[:, o:], bE.scale[o:], bE.shift[o:], act, pl.taps[i],
-                           h[:, o:], pl.Wd_grad[i], st2E.at(o), HT, N, H, W, c, pl.ks[i], s, stat_rows=st2E.rows)
+            ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], _seg(E, o), bE.scale[o:], bE.shift[o:], act, pl.taps[i],
+                           _seg(h, o), pl.Wd_grad[i], st2E.at(o), HT, N, H, W, c, pl.ks[i], s, stat_rows=st2E.rows)
         else:
             if pl.nb > 1:
                 raise NotImplementedError("non-expanding block with more than one branch")
-            ops.dwconv_bwd(g[:, o:], D[:, o:], d1[o:], d2[o:], d3[o:], E, None, None, 0, pl.taps[i], h, pl.Wd_grad[i], None, 0, N, H,
+            ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], E, None, None, 0, pl.taps[i], h, pl.Wd_grad[i], None, 0, N, H,
                            W, c, pl.ks[i], s)
     if not pl.expand:
         if pl.res:

@@ -41,10 +41,67 @@ def tn_workspace(nu, nv, dev):
 
 
 
+class Slab:
+    """Slab-major activation (include/atomnas_hip.h): C channels in slabs of 16, every slab a contiguous [M][16] matrix.
+    The 6x-expanded hidden tensors of a block live in this layout: a kernel workgroup that owns a channel range then streams
+    contiguous memory.  `seg(o)` is the same tensor seen from channel o on (o a multiple of 16: a branch segment)."""
+    __slots__ = ("t", "M", "C", "ss", "off")
+
+    def __init__(self, M, C, dtype, device, zero=False, _t=None, _off=0):
+        self.M, self.C = int(M), int(C)
+        self.ss = self.M * 16
+        n = (self.C + 15) // 16 * self.ss
+        self.t = _t if _t is not None else (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
+        self.off = _off
+
+    def seg(self, o):
+        if o == 0:
+            return self
+        if o % 16:
+            raise ValueError("slab segments start at multiples of 16 channels")
+        return Slab(self.M, self.C - o, self.t.dtype, self.t.device, _t=self.t, _off=self.off + (o // 16) * self.ss)
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @property
+    def is_cuda(self):
+        return self.t.is_cuda
+
+    def data_ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+    def to_plain(self):
+        """[M, C16] torch tensor with the same contents (tests / debugging)"""
+        ns = (self.C + 15) // 16
+        v = self.t[self.off:self.off + ns * self.ss].view(ns, self.M, 16)
+        return v.permute(1, 0, 2).reshape(self.M, ns * 16)
+
+    @staticmethod
+    def from_plain(x2d, C=None):
+        M, ld = x2d.shape
+        C = ld if C is None else C
+        s = Slab(M, C, x2d.dtype, x2d.device, zero=True)
+        ns = (C + 15) // 16
+        buf = torch.zeros(M, ns * 16, dtype=x2d.dtype, device=x2d.device)
+        buf[:, :min(ld, ns * 16)] = x2d[:, :min(ld, ns * 16)]
+        s.t.view(ns, M, 16).copy_(buf.view(M, ns, 16).permute(1, 0, 2))
+        return s
+
+
 def _p(t):
     if t is None:
         return ctypes.c_void_p(0)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _ss(t):
+    return t.ss if isinstance(t, Slab) else 0
 
 
 def _stream():
@@ -60,6 +117,8 @@ def dt_code(dtype):
 
 
 def _ld(t):
+    if isinstance(t, Slab):
+        return 16
     assert t.dim() == 2 and t.stride(1) == 1, "activation must be [M, ld] with unit channel stride"
     return t.stride(0)
 
@@ -78,8 +137,8 @@ def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, stat_ld, N, H, 
     _chk_cuda(x, y, w_taps)
     if _lib.PROFILE is not None:
         _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
-    call("atomnas_dwconv_fwd", _p(x), _ld(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(y), _ld(y),
-         _p(stats), stat_ld, _rows(stats, stat_rows), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
+    call("atomnas_dwconv_fwd", _p(x), _ld(x), _ss(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(y),
+         _ld(y), _ss(y), _p(stats), stat_ld, _rows(stats, stat_rows), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
 
 def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, dw, stats, stat_ld, N, H, W, C, k, stride,
@@ -91,8 +150,9 @@ def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, d
         dw_ws = torch.empty(rows * C * k * k, dtype=torch.float32, device=x.device)
     if _lib.PROFILE is not None:
         _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
-    call("atomnas_dwconv_bwd", _p(g), _ld(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _p(c1), _p(c2), _p(c3), _p(x), _ld(x),
-         _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _p(dw), _p(stats), stat_ld, rows,
+    call("atomnas_dwconv_bwd", _p(g), _ld(g), _ss(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _ss(yraw), _p(c1), _p(c2), _p(c3),
+         _p(x), _ld(x), _ss(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _ss(h), _p(dw),
+         _p(stats), stat_ld, rows,
          _p(dw_ws), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
 
@@ -102,9 +162,9 @@ def gemm_nt(a, wp, c, M, N, K, a_mode=PRO_NONE, a2=None, ac1=None, ac2=None, ac3
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d pro%d st%d%s%s" % (M, N, K, a_mode, stat_mode, "+add" if add is not None else "", "+mask" if mask else ""))
     out_f32 = 1 if (c.dtype == torch.float32 and a.dtype != torch.float32) else 0
-    call("atomnas_pw_gemm_nt", a_mode, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, _p(ac1), _p(ac2), _p(ac3),
-         int(a_relu), _p(wp), wp.stride(0), _p(c), _ld(c), out_f32, _p(add), _ld(add) if add is not None else 0, _p(z),
-         _ld(z) if z is not None else 0, _p(zscale), _p(zshift), int(mask), _p(bias), _p(stats), stat_mode, _rows(stats, stat_rows),
+    call("atomnas_pw_gemm_nt", a_mode, _p(a), _ld(a), _ss(a), _p(a2), _ld(a2) if a2 is not None else 0, _ss(a2), _p(ac1), _p(ac2), _p(ac3),
+         int(a_relu), _p(wp), wp.stride(0), _p(c), _ld(c), _ss(c), out_f32, _p(add), _ld(add) if add is not None else 0, _p(z),
+         _ld(z) if z is not None else 0, _ss(z), _p(zscale), _p(zshift), int(mask), _p(bias), _p(stats), stat_mode, _rows(stats, stat_rows),
          M, N, K, dt_code(a.dtype), _stream())
 
 
@@ -118,8 +178,8 @@ def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc
         ws = None
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d NU%d NV%d pro%d,%d" % (M, NU, NV, u_mode, v_mode))
-    call("atomnas_pw_gemm_tn", u_mode, _p(u), _ld(u), _p(u2), _ld(u2) if u2 is not None else 0, _p(uc1), _p(uc2), _p(uc3),
-         int(u_relu), NU, v_mode, _p(v), _ld(v), _p(v2), _ld(v2) if v2 is not None else 0, _p(vc1), _p(vc2), _p(vc3), int(v_relu),
+    call("atomnas_pw_gemm_tn", u_mode, _p(u), _ld(u), _ss(u), _p(u2), _ld(u2) if u2 is not None else 0, _ss(u2), _p(uc1), _p(uc2), _p(uc3),
+         int(u_relu), NU, v_mode, _p(v), _ld(v), _ss(v), _p(v2), _ld(v2) if v2 is not None else 0, _ss(v2), _p(vc1), _p(vc2), _p(vc3), int(v_relu),
          NV, _p(out), si, sj, M, _p(ws), ws.numel() if ws is not None else 0, dt_code(u.dtype), _stream())
 
 

@@ -12,7 +12,7 @@ so that the optimizer tail, gradient all-reduce, broadcast and regularisers are 
 
 Inside an atomic block the three branches are laid out *fused*: expand weights of all branches form one [HT, inp] matrix,
 projection weights one [oup, HT] matrix, BN vectors one [HT] vector, where each branch owns a segment whose length is
-rounded up to 8 channels (HT = sum of padded segments).  Padding entries are zeros that belong to no Parameter; they
+rounded up to 16 channels, one slab of the slab-major hidden tensors (HT = sum of padded segments).  Padding entries are zeros that belong to no Parameter; they
 stay zero under training (their gradients are identically zero) and let every kernel use aligned 16-byte accesses after a
 shrink has produced ragged channel counts (13, 139, ...).
 """
@@ -29,6 +29,11 @@ ALIGN = 256  # arena slots start on 256-element (1 KiB) boundaries
 
 def pad8(c):
     return (c + 7) // 8 * 8
+
+
+def pads(c):
+    """width of a branch segment inside a block's hidden tensor: whole 16-channel slabs (slab-major layout, ops.Slab)"""
+    return (c + 15) // 16 * 16
 
 
 def pad32(c):
@@ -166,20 +171,23 @@ class ArenaManager:
                     self._bind_bn(bind_param, bind_buf, lc, m.pw_bn, sl, 0, pl.oup)
                     plans.append((m, pl, {}))
                     continue
+                # expanding blocks keep their hidden tensors slab-major (segments = whole 16-channel slabs); the first block of
+                # the network (no expansion: hidden = input, narrow) stays plain with 8-channel padding
+                sp = pl.segpad = pads if m.expand else pad8
                 pl.seg = []
                 o = 0
                 for h in pl.hid:
                     pl.seg.append(o)
-                    o += pad8(h)
+                    o += sp(h)
                 HT = pl.HT = o
                 so = {}
                 if m.expand:
                     so["We"] = lp.take(HT * pl.inp)
                     reg_slots.append(("dense", so["We"], HT * pl.inp))
                     so["bne"] = bn_slots(HT)
-                so["Wd"] = [lp.take(pad8(h) * k * k) for h, k in zip(pl.hid, pl.ks)]
+                so["Wd"] = [lp.take(sp(h) * k * k) for h, k in zip(pl.hid, pl.ks)]
                 for o_, h_, k_ in zip(so["Wd"], pl.hid, pl.ks):
-                    reg_slots.append(("dw", o_, pad8(h_) * k_ * k_))
+                    reg_slots.append(("dw", o_, sp(h_) * k_ * k_))
                 so["bnd"] = bn_slots(HT)
                 so["Wp"] = lp.take(pl.oup * HT)
                 reg_slots.append(("dense", so["Wp"], pl.oup * HT))
@@ -205,9 +213,9 @@ class ArenaManager:
                 pk["Wp"], pk["WpT"] = pw_pack(so["Wp"], pl.oup, HT, HT)
                 pk["taps"] = []
                 for i, (h, k) in enumerate(zip(pl.hid, pl.ks)):
-                    o_f = lpf.take(k * k * pad8(h))
-                    pack_jobs_f.append((so["Wd"][i], o_f, pad8(h), k * k, k * k, pad8(h), 0, 2))
-                    pk["taps"].append((o_f, k * k, pad8(h)))
+                    o_f = lpf.take(k * k * sp(h))
+                    pack_jobs_f.append((so["Wd"][i], o_f, sp(h), k * k, k * k, sp(h), 0, 2))
+                    pk["taps"].append((o_f, k * k, sp(h)))
                 plans.append((m, pl, dict(so=so, pk=pk)))
             elif isinstance(m, mb.ConvBNReLU) and id(m) not in handled:
                 conv, bn, _ = list(m.children())
@@ -429,7 +437,7 @@ class ArenaManager:
                 pl.bne = bnv(so["bne"], HT, [list(c[0].children())[1] for c in chs])
                 pl.We_pack = self._packview(pk["We"])
                 pl.WeT_pack = self._packview(pk["WeT"])
-            pl.Wd_grad = [G[o:o + pad8(h) * k * k] for o, h, k in zip(so["Wd"], pl.hid, pl.ks)]
+            pl.Wd_grad = [G[o:o + pl.segpad(h) * k * k] for o, h, k in zip(so["Wd"], pl.hid, pl.ks)]
             pl.bnd = bnv(so["bnd"], HT, [list(c[idx_depth].children())[1] for c in chs])
             pl.Wp_grad = G[so["Wp"]:so["Wp"] + pl.oup * HT]
             pl.bnp = bnv(so["bnp"], pl.oup, [m.pw_bn])
@@ -443,7 +451,7 @@ class ArenaManager:
                         continue
                     rv = S[sl["rv"]:sl["rv"] + C]
                     for s, h in zip(pl.seg, pl.hid):
-                        rv[s + h:s + pad8(h)] = 1.0
+                        rv[s + h:s + pl.segpad(h)] = 1.0
         else:
             so, pk = info["so"], info["pk"]
             if isinstance(m, nn.Linear):

@@ -10,8 +10,12 @@
  *   - every function returns 0 on success, non-zero on failure; atomnas_last_error() returns the message.
  *   - nothing is allocated or freed by the library; workspaces are caller-owned.  Functions are asynchronous on `stream`,
  *     re-entrant per stream, and contain no host synchronisation (they can be captured into a hipGraph).
- *   - activations are NHWC viewed as [M = N*H*W rows][C channels] with an explicit channel pitch ld (elements);
- *     ld is a multiple of 8 and channels C..ld-1 hold zeros.  dtype: 0 = fp32, 1 = bf16 storage (fp32 accumulation).
+ *   - activations are NHWC viewed as [M = N*H*W rows][C channels].  Every activation argument comes as (pointer, ld, ss):
+ *       ss == 0  plain layout: element (row, c) at row*ld + c; ld is a multiple of 8 and channels C..ld-1 hold zeros;
+ *       ss  > 0  slab-major layout: the channels are cut into slabs of 16 and each slab is a contiguous [M][16] matrix,
+ *                element (row, c) at (c/16)*ss + row*16 + c%16, ss >= M*16 (ld is ignored).  This is the layout of the
+ *                6x-expanded hidden tensors of a block: a workgroup that owns a channel range streams contiguous memory.
+ *     dtype: 0 = fp32, 1 = bf16 storage (fp32 accumulation).
  *   - per-channel fp32 vectors (scale, shift, c1..c3, gamma, ...) are readable up to C rounded up to 8.
  *   - "stats" outputs are PARTIAL ROWS: an fp32 buffer [stat_rows][2][pitch] (pitch = stat_ld, or N for the GEMM).  The
  *     producing function writes EVERY row of its channel range with plain stores (one workgroup or wave owns a row; rows it
@@ -62,8 +66,8 @@ int atomnas_runtime_version(void);
  *      models/mobilenet_base.py:330-336 (built through ConvBNReLU :120-142); k in {3,5,7}, stride in {1,2}.
  * forward: y = dwconv(act(x*in_scale+in_shift));  stats rows [sum y, sum y^2] for channels 0..C-1   (in_scale == NULL: x as is)
  *   w: fp32 taps [k*k][ldw] (tap-major, see atomnas_pack_weights mode 2). */
-int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
-                       void* y, int ldy, float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int stride,
+int atomnas_dwconv_fwd(const void* x, int ldx, long x_ss, const float* in_scale, const float* in_shift, int in_relu, const float* w,
+                       int ldw, void* y, int ldy, long y_ss, float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int stride,
                        int dtype, void* stream);
 
 /* backward (input gradient and weight gradient in one pass over the data):
@@ -73,9 +77,9 @@ int atomnas_dwconv_fwd(const void* x, int ldx, const float* in_scale, const floa
  *                                                                   dw_ws [part_rows][C][k*k] and are summed in a fixed order
  *   stats rows [sum h, sum h*x]                                 -- for the producer's BatchNorm backward ([part_rows][2][stat_ld])
  *   part_rows bounds the number of workgroups per channel slab (each owns one row of stats and of dw_ws). */
-int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const float* c1, const float* c2, const float* c3,
-                       const void* x, int ldx, const float* in_scale, const float* in_shift, int in_relu, const float* w, int ldw,
-                       void* h, int ldh, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W,
+int atomnas_dwconv_bwd(const void* g, int ldg, long g_ss, const void* yraw, int ldyr, long yraw_ss, const float* c1, const float* c2,
+                       const float* c3, const void* x, int ldx, long x_ss, const float* in_scale, const float* in_shift, int in_relu,
+                       const float* w, int ldw, void* h, int ldh, long h_ss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W,
                        int C, int k, int stride, int dtype, void* stream);
 
 /* ---- pointwise (1x1) convolutions as MFMA GEMMs: models/mobilenet_base.py:316-320 (expand), :338 (project),
@@ -85,17 +89,17 @@ int atomnas_dwconv_bwd(const void* g, int ldg, const void* yraw, int ldyr, const
  *   wp: packed weights, storage dtype, [N rounded up to 64][ldw], ldw >= K rounded up to 32 (bf16) / 4 (fp32), padding zero
  *   epilogue: + bias[n]; + add[m][n]; if mask: c = 0 where z*zscale+zshift <= 0; store (fp32 if out_f32);
  *             stats per stat_mode on the stored value: partial rows [stat_rows][2][N]. */
-int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, const void* a2, int lda2, const float* ac1, const float* ac2,
-                       const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, int out_f32, const void* add,
-                       int ldadd, const void* z, int ldz, const float* zscale, const float* zshift, int mask, const float* bias,
+int atomnas_pw_gemm_nt(int a_mode, const void* a, int lda, long a_ss, const void* a2, int lda2, long a2_ss, const float* ac1,
+                       const float* ac2, const float* ac3, int a_relu, const void* wp, int ldw, void* c, int ldc, long c_ss, int out_f32,
+                       const void* add, int ldadd, const void* z, int ldz, long z_ss, const float* zscale, const float* zshift, int mask, const float* bias,
                        float* stats, int stat_mode, int stat_rows, long M, int N, int K, int dtype, void* stream);
 
 /* weight gradient: out[i*si + j*sj] += sum_m prologue(U)[m,i] * prologue(V)[m,j]  (fp32).  The reduction over M is split into
  *   row chunks whose partial outputs [chunk][NU][NV] go to the caller-owned workspace ws (ws_floats floats) and are summed in
  *   chunk order; ws == NULL (or room for < 2 partials): one workgroup per output tile walks all of M. */
-int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, const void* u2, int ldu2, const float* uc1, const float* uc2,
-                       const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, const void* v2, int ldv2,
-                       const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out, long si, long sj, long M,
+int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, long u_ss, const void* u2, int ldu2, long u2_ss, const float* uc1,
+                       const float* uc2, const float* uc3, int u_relu, int NU, int v_mode, const void* v, int ldv, long v_ss,
+                       const void* v2, int ldv2, long v2_ss, const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out, long si, long sj, long M,
                        float* ws, long ws_floats, int dtype, void* stream);
 
 /* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;

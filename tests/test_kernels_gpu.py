@@ -235,3 +235,72 @@ def test_dwconv_long_tile_walks():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "test_dwconv_fwd or test_dwconv_bwd"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------- slab-major layout
+def _slab(t2d, C):
+    from atomnas_amd.ops import Slab
+    return Slab.from_plain(t2d, C)
+
+
+@pytest.mark.parametrize("k,stride", [(3, 1), (5, 2), (7, 1), (7, 2)])
+@pytest.mark.parametrize("N,C,H,W", [(3, 48, 15, 15), (2, 144, 28, 28), (2, 16, 44, 37)])
+def test_dwconv_slab_layout_is_bit_identical_to_plain(gpu_lib, k, stride, N, C, H, W):
+    """The hidden tensors of a block are slab-major ([C/16][M][16], include/atomnas_hip.h).  The layout changes addresses only:
+    same work decomposition, same arithmetic order -> every output bit equals the plain-layout result."""
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(k * 100 + C)
+    P = (k - 1) // 2
+    Ho, Wo = (H + 2 * P - k) // stride + 1, (W + 2 * P - k) // stride + 1
+    x, gup, yraw = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, Ho, Wo, generator=g), torch.randn(N, C, Ho, Wo, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    c1, c2, c3 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    xb, gb, yb_ = to_act(x, dtype), to_act(gup, dtype), to_act(yraw, dtype)
+    res = []
+    for slab in (False, True):
+        wrap = (lambda t: _slab(t, C)) if slab else (lambda t: t)
+        y = Slab(N * Ho * Wo, C, dtype, "cuda", zero=True) if slab else fresh(N * Ho * Wo, C, dtype)
+        st = poisoned_stats(64, C)
+        ops.dwconv_fwd(wrap(xb), cvec(sc), cvec(sh), True, taps(w), y, st, C, N, H, W, C, k, stride)
+        h = Slab(N * H * W, C, dtype, "cuda", zero=True) if slab else fresh(N * H * W, C, dtype)
+        dw = torch.zeros(C, k * k, dtype=torch.float32, device="cuda")
+        st2 = poisoned_stats(64, C)
+        ops.dwconv_bwd(wrap(gb), wrap(yb_), cvec(c1), cvec(c2), cvec(c3), wrap(xb), cvec(sc), cvec(sh), True, taps(w), h, dw, st2, C,
+                       N, H, W, C, k, stride)
+        torch.cuda.synchronize()
+        res.append((y.to_plain()[:, :C] if slab else y[:, :C], st, h.to_plain()[:, :C] if slab else h[:, :C], dw, st2))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(2000, 432, 24), (5000, 80, 1440), (333, 40, 139), (4100, 96, 576)])
+def test_gemm_slab_layout_is_bit_identical_to_plain(gpu_lib, M, N, K):
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    r = lambda *s: torch.randn(*s, generator=g)
+    act2d = lambda t, c: torch.cat([t.to(dtype), torch.zeros(t.shape[0], pad8(c) - c, dtype=dtype)], 1).cuda()
+    A, A2, Z, W = act2d(r(M, K), K), act2d(r(M, K), K), act2d(r(M, N), N), r(N, K) / K ** 0.5
+    c1, c2, c3 = cvec(torch.rand(K, generator=g) + 0.5), cvec(r(K) * 0.2), cvec(r(K) * 0.2)
+    zs, zh = cvec(torch.rand(N, generator=g) + 0.5), cvec(r(N) * 0.3)
+    res = []
+    for slab in (False, True):
+        wa = (lambda t: _slab(t, K)) if slab else (lambda t: t)
+        wz = (lambda t: _slab(t, N)) if slab else (lambda t: t)
+        C = Slab(M, N, dtype, "cuda", zero=True) if slab else fresh(M, N, dtype)
+        st = poisoned_stats(64, N)
+        ops.gemm_nt(wa(A), pack_w(W, dtype), C, M, N, K, a_mode=ops.PRO_BNBWD, a2=wa(A2), ac1=c1, ac2=c2, ac3=c3, z=wz(Z), zscale=zs,
+                    zshift=zh, mask=True, stats=st, stat_mode=ops.STAT_Z)
+        out = torch.zeros(N, K, dtype=torch.float32, device="cuda")
+        ops.gemm_tn(wz(Z), N, wa(A), K, out, K, 1, M, v_mode=ops.PRO_BNBWD, v2=wa(A2), vc1=c1, vc2=c2, vc3=c3)
+        out2 = torch.zeros(K, N, dtype=torch.float32, device="cuda")
+        ops.gemm_tn(wa(A), K, wz(Z), N, out2, N, 1, M, u_mode=ops.PRO_BNBWD, u2=wa(A2), uc1=c1, uc2=c2, uc3=c3, v_mode=ops.PRO_BNRELU,
+                    vc1=zs, vc2=zh, v_relu=True)
+        torch.cuda.synchronize()
+        res.append((C.to_plain()[:, :N] if slab else C[:, :N], st, out, out2))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
