@@ -20,9 +20,9 @@ SIGNATURES = {
                            i32, vp, vp, i32, i32, i64, i32, i32, i32, vp],
     "atomnas_pw_gemm_tn": [i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32,
                            vp, i64, i64, i64, vp, i64, i32, vp],
-    "atomnas_bn_finalize_fwd": [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "atomnas_bn_finalize_fwd": [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
-    "atomnas_bn_finalize_bwd": [vp, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "atomnas_bn_finalize_bwd": [vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "atomnas_bn_apply": [vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
     "atomnas_bn_act_pool": [vp, i32, vp, vp, i32, vp, i32, vp, f32, u64, vp, i32, i32, i32, i32, vp],
     "atomnas_pool_act_bwd": [vp, i32, vp, f32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],

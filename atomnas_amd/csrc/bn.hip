@@ -10,49 +10,52 @@
 
 namespace atomnas {
 
-// Sums the partial rows of one channel in a fixed order: the 256 threads of a block are 32 channels x 8 row groups; row group
-// rg adds rows rg, rg+8, ... with four independent accumulators, the eight group sums are combined in order 0..7.
-// Returns the totals of both planes to the threads with rg == 0 (other threads get garbage they must not use).
-__device__ __forceinline__ void stat_row_sum(const float* __restrict__ stats, int rows, int C, int c, int rg, int cl, float (&s_red)[2][8][32],
-                                             float& t0, float& t1) {
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-  if (c < C) {
-    int r = rg;
-    for (; r + 8 < rows; r += 16) {
-      a0 += stats[(long)r * 2 * C + c];
-      b0 += stats[(long)r * 2 * C + C + c];
-      a1 += stats[(long)(r + 8) * 2 * C + c];
-      b1 += stats[(long)(r + 8) * 2 * C + C + c];
-    }
-    if (r < rows) {
-      a0 += stats[(long)r * 2 * C + c];
-      b0 += stats[(long)r * 2 * C + C + c];
+// Sums the partial rows of 16 channels in a fixed order.  The 256 threads of a block are 64 row groups x 4 channel quads:
+// thread (rg, cq) adds rows rg, rg+64, ... of channels 4cq..4cq+3 (both planes) with 16-byte loads, all of them independent
+// (one round of memory latency for up to 512 rows); the 64 group sums of a channel are then added in order 0..63 by one
+// thread per (channel, plane).  Results: t0/t1 of channel c = blockIdx.x*16 + (tid & 15), valid in threads tid < 16.
+__device__ __forceinline__ void stat_row_sum(const float* __restrict__ stats, int rows, int ld, int C, float (&s_red)[2][64][17], float& t0,
+                                             float& t1) {
+  const int tid = threadIdx.x;
+  const int rg = tid >> 2, cq = tid & 3;
+  const int c4 = blockIdx.x * 16 + cq * 4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < C) {   // C is a multiple of 4 here (channel vectors are padded to 8)
+#pragma unroll 4
+    for (int r = rg; r < rows; r += 64) {
+      a += *reinterpret_cast<const f32x4*>(stats + (long)r * 2 * ld + c4);
+      b += *reinterpret_cast<const f32x4*>(stats + (long)r * 2 * ld + ld + c4);
     }
   }
-  s_red[0][rg][cl] = a0 + a1;
-  s_red[1][rg][cl] = b0 + b1;
-  __syncthreads();
-  t0 = s_red[0][0][cl];
-  t1 = s_red[1][0][cl];
 #pragma unroll
-  for (int g = 1; g < 8; ++g) {
-    t0 += s_red[0][g][cl];
-    t1 += s_red[1][g][cl];
+  for (int e = 0; e < 4; ++e) {
+    s_red[0][rg][cq * 4 + e] = a[e];
+    s_red[1][rg][cq * 4 + e] = b[e];
   }
+  __syncthreads();
+  t0 = t1 = 0.f;
+  if (tid < 32) {
+    const int pl = tid >> 4, cl = tid & 15;
+    float t = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < 64; ++g) t += s_red[pl][g][cl];
+    s_red[pl][0][cl] = t;
+  }
+  __syncthreads();
+  if (tid < 16) { t0 = s_red[0][0][tid]; t1 = s_red[1][0][tid]; }
 }
 
-__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ stats, int rows, float inv_count, float unbias,
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ stats, int rows, int stat_ld, float inv_count, float unbias,
                                   const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                   float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ scale,
                                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int C,
                                   int Cpad) {
-  __shared__ float s_red[2][8][32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float s_red[2][64][17];
+  const int c = blockIdx.x * 16 + threadIdx.x;
   float a0, a1;
-  stat_row_sum(stats, rows, C, c, rg, cl, s_red, a0, a1);
-  if (rg != 0 || c >= Cpad) return;
+  stat_row_sum(stats, rows, stat_ld, Cpad, s_red, a0, a1);
+  if (threadIdx.x >= 16 || c >= Cpad) return;
   if (c >= C) {  // padding lanes of the channel vectors stay neutral
     scale[c] = 0.f; shift[c] = 0.f;
     if (save_mean) { save_mean[c] = 0.f; save_invstd[c] = 0.f; }
@@ -89,18 +92,17 @@ __global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* _
 
 // stats2 = [sum g, sum g*x];  dgamma = invstd*(sum g*x - mean*sum g), dbeta = sum g,
 // dx = c1*g + c2*x + c3 with c1 = gamma*invstd, c2 = -gamma*invstd^2*dgamma/M, c3 = gamma*invstd*(mean*invstd*dgamma - dbeta)/M
-__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ stats2, int rows, float inv_count,
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ stats2, int rows, int stat_ld, float inv_count,
                                   const float* __restrict__ gamma,
                                   const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                   const float* __restrict__ rho_ptr, const float* __restrict__ penalty, float* __restrict__ dgamma,
                                   float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
                                   int C, int Cpad) {
-  __shared__ float s_red[2][8][32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float s_red[2][64][17];
+  const int c = blockIdx.x * 16 + threadIdx.x;
   float sg, sgx;
-  stat_row_sum(stats2, rows, C, c, rg, cl, s_red, sg, sgx);
-  if (rg != 0 || c >= Cpad) return;
+  stat_row_sum(stats2, rows, stat_ld, Cpad, s_red, sg, sgx);
+  if (threadIdx.x >= 16 || c >= Cpad) return;
   if (c >= C) { c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
   const float mean = save_mean[c], r = save_invstd[c];
   const float g = gamma ? gamma[c] : 1.f;
@@ -267,16 +269,19 @@ __global__ __launch_bounds__(256) void k_pool_act_bwd(const T* __restrict__ dpoo
   }
 }
 
-// generic "masked gradient + statistics" pass:  g = dy * [z*scale+shift > 0];  stats2 += [sum g, sum g*z]
+// generic "masked gradient + statistics" pass:  g = dy * [z*scale+shift > 0];  stats2 rows = [sum g, sum g*z]
+// block = CGL channel groups (8 channels each) x 256/CGL pixel lanes, CGL = 2^lcg chosen on the host so that narrow tensors
+// (the 16..320-channel block outputs this runs on) keep all 256 threads busy; the pixel lanes are combined in lane order.
 template <typename T>
 __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                        T* __restrict__ g, int ldg, float* __restrict__ stats2, int stat_rows, long M,
-                                                       int C) {
-  __shared__ float s_red[8][512];   // see k_pool_act_bwd
+                                                       int C, int lcg) {
+  __shared__ float s_red[256 * 16];   // [pixel lane][channel of the block column][2]
   const int tid = threadIdx.x;
-  const int cgl = tid & 31, pl = tid >> 5;
-  const int c0 = (blockIdx.y * 32 + cgl) * 8;
+  const int CGL = 1 << lcg, PL = 256 >> lcg;
+  const int cgl = tid & (CGL - 1), pl = tid >> lcg;
+  const int c0 = (blockIdx.y * CGL + cgl) * 8;
   float s0[8], s1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy,
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 1.f; h[e] = 0.f; }
     if (scale) { VecIO<float, 8>::load(scale + c0, s); VecIO<float, 8>::load(shift + c0, h); }
-    for (long p = (long)blockIdx.x * 8 + pl; p < M; p += (long)gridDim.x * 8) {
+    for (long p = (long)blockIdx.x * PL + pl; p < M; p += (long)gridDim.x * PL) {
       float d[8], v[8];
       VecIO<T, 8>::load(dy + p * lddy + c0, d);
       VecIO<T, 8>::load(z + p * ldz + c0, v);
@@ -304,17 +309,16 @@ __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy,
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    s_red[pl][(cgl * 8 + e) * 2] = s0[e];
-    s_red[pl][(cgl * 8 + e) * 2 + 1] = s1[e];
+    s_red[(pl * CGL * 8 + cgl * 8 + e) * 2] = s0[e];
+    s_red[(pl * CGL * 8 + cgl * 8 + e) * 2 + 1] = s1[e];
   }
   __syncthreads();
-  if (stats2) {
-    const int c = blockIdx.y * 256 + tid;
+  if (stats2 && tid < CGL * 8) {
+    const int c = blockIdx.y * CGL * 8 + tid;
     if (c < C) {
-      float a = s_red[0][tid * 2], b = s_red[0][tid * 2 + 1];
-#pragma unroll
-      for (int q = 1; q < 8; ++q) { a += s_red[q][tid * 2]; b += s_red[q][tid * 2 + 1]; }
-      float* srow = stats2 + (long)blockIdx.x * 2 * C;
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < PL; ++q) { a += s_red[(q * CGL * 8 + tid) * 2]; b += s_red[(q * CGL * 8 + tid) * 2 + 1]; }
+      float* srow = stats2 + (long)blockIdx.x * 2 * C;   // one row per workgroup column (gridDim.x <= stat_rows)
       srow[c] = a;
       srow[C + c] = b;
       stat_zero_tail(stats2, 2L * C, blockIdx.x + gridDim.x, gridDim.x, stat_rows, c);
@@ -327,16 +331,17 @@ __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy,
 
 using namespace atomnas;
 
-extern "C" int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, double count, const float* gamma, const float* beta, float eps,
+extern "C" int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, int stat_ld, double count, const float* gamma, const float* beta, float eps,
                                        float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
                                        float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
   ATOMNAS_REQUIRE(stats && stat_rows > 0 && scale && shift && C > 0 && count > 0, "bn_finalize_fwd: bad arguments");
+  ATOMNAS_REQUIRE(stat_ld >= (C + 7) / 8 * 8 && stat_ld % 4 == 0 && ((size_t)stats & 15) == 0, "bn_finalize_fwd: the statistics rows must be 16-byte aligned with a pitch of at least C rounded up to 8 (stat_ld=%d)", stat_ld);
   ATOMNAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_fwd: running stats must come together");
   ATOMNAS_REQUIRE(!(momentum < 0.f && running_mean) || num_batches_tracked, "bn_finalize_fwd: cumulative mode needs the batch counter");
   const int Cpad = (C + 7) / 8 * 8;
   const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 31) / 32), dim3(256), 0, st, stats, stat_rows, (float)(1.0 / count), unbias, gamma, beta,
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 15) / 16), dim3(256), 0, st, stats, stat_rows, stat_ld, (float)(1.0 / count), unbias, gamma, beta,
                      eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C, Cpad);
   return check_launch("bn_finalize_fwd");
 }
@@ -350,12 +355,13 @@ extern "C" int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, con
   return check_launch("bn_eval_coeffs");
 }
 
-extern "C" int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, double count, const float* gamma, const float* save_mean,
+extern "C" int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, int stat_ld, double count, const float* gamma, const float* save_mean,
                                        const float* save_invstd, const float* rho_ptr, const float* penalty, float* dgamma,
                                        float* dbeta, float* c1, float* c2, float* c3, int C, void* stream) {
   ATOMNAS_REQUIRE(stats2 && stat_rows > 0 && save_mean && save_invstd && c1 && c2 && c3 && C > 0 && count > 0, "bn_finalize_bwd: bad arguments");
+  ATOMNAS_REQUIRE(stat_ld >= (C + 7) / 8 * 8 && stat_ld % 4 == 0 && ((size_t)stats2 & 15) == 0, "bn_finalize_bwd: the statistics rows must be 16-byte aligned with a pitch of at least C rounded up to 8 (stat_ld=%d)", stat_ld);
   const int Cpad = (C + 7) / 8 * 8;
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 31) / 32), dim3(256), 0, (hipStream_t)stream, stats2, stat_rows, (float)(1.0 / count),
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats2, stat_rows, stat_ld, (float)(1.0 / count),
                      gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, Cpad);
   return check_launch("bn_finalize_bwd");
 }
@@ -420,16 +426,20 @@ extern "C" int atomnas_act_bwd_stats(const void* dy, int lddy, const void* z, in
   ATOMNAS_REQUIRE(lddy % 8 == 0 && ldz % 8 == 0 && lddy >= C && ldz >= C && (!g || (ldg % 8 == 0 && ldg >= C)), "act_bwd_stats: bad pitch");
   ATOMNAS_REQUIRE((scale == nullptr) == (shift == nullptr), "act_bwd_stats: scale/shift must come together");
   ATOMNAS_REQUIRE(!stats2 || stat_rows > 0, "act_bwd_stats: statistics need stat_rows > 0");
-  long gx = (M + 7) / 8;
-  if (gx > 1024) gx = 1024;
+  const int ncg = (C + 7) / 8;
+  int lcg = 0;
+  while ((1 << lcg) < ncg && lcg < 5) ++lcg;   // channel groups per block column: 1, 2, 4, ..., 32
+  const int cgl = 1 << lcg, pl = 256 >> lcg;
+  long gx = (M + pl - 1) / pl;
+  if (gx > 2048) gx = 2048;
   if (stats2 && gx > stat_rows) gx = stat_rows;
-  dim3 grid((unsigned)gx, (C + 255) / 256);
+  dim3 grid((unsigned)gx, (ncg + cgl - 1) / cgl);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32)
     hipLaunchKernelGGL(k_act_bwd_stats<float>, grid, dim3(256), 0, st, (const float*)dy, lddy, (const float*)z, ldz, scale, shift,
-                       relu, (float*)g, ldg, stats2, stat_rows, M, C);
+                       relu, (float*)g, ldg, stats2, stat_rows, M, C, lcg);
   else
     hipLaunchKernelGGL(k_act_bwd_stats<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)z, ldz, scale, shift,
-                       relu, (bf16_t*)g, ldg, stats2, stat_rows, M, C);
+                       relu, (bf16_t*)g, ldg, stats2, stat_rows, M, C, lcg);
   return check_launch("act_bwd_stats");
 }

@@ -29,6 +29,9 @@
                    // the spills of k = 7, but the extra raw LDS buffers cost residency: +2..4 % on 16-channel slabs, +50..90 % on
                    // 32-channel ones, -5 % only for k = 7 stride 2 (tools/dwbench.py, same box) -> off
 #endif
+#ifndef DW_SMALL_CB7
+#define DW_SMALL_CB7 32   // slab width of the k = 7 backward on 7x7 maps (64 needs more than 256 registers: 98 accumulators + prefetch)
+#endif
 #ifndef DW_RING
 #define DW_RING 1  // 1 = tiles are walked column-major and the LDS operand tile is a ring over rows: a tile below the previous one
                    // loads only its new rows (the (K-1)/S halo rows stay); 0 = every tile loads its whole haloed window
@@ -145,6 +148,12 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   float* s_in = smem;                         // [LH][RP]
   float* s_w = s_in + g.LH * g.RP;            // [K*K][CB]
   float* s_st = s_w + K * K * CB;             // [4 waves][2][CB]: per-wave partial statistics, combined in wave order
+#ifndef DW_FWD_STAGE
+#define DW_FWD_STAGE 1   // 1 = the output tile leaves through LDS in 16-byte pieces (a tile row is one contiguous run in the slab-major
+                         // layout); 0 = every work item stores its 4-byte channel pairs directly (store-issue bound: 7 partial-line
+                         // store instructions per item)
+#endif
+  T* s_y = reinterpret_cast<T*>(s_st + 8 * CB);   // [TH*TW][CB] the tile's output, stored with the next tile's commit
 
   const int tid = threadIdx.x;
   constexpr int C2 = CB / 2, CG = CB / 8;
@@ -237,6 +246,29 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
     it_j[q] = rs % nstrips;
   }
 
+  // output pieces of 16 bytes (pixel, 8 channels) for the staged store
+  constexpr int YP = (TM * TM * CG + 255) / 256;
+  int yp_r[YP], yp_c[YP];
+#pragma unroll
+  for (int p = 0; p < YP; ++p) {
+    const int pix = (tid + 256 * p) / CG;
+    yp_r[p] = pix < g.TH * g.TW ? pix / g.TW : -100000;
+    yp_c[p] = pix % g.TW;
+  }
+  const long yps = pix_stride(ldy, yss);
+  auto store_y = [&](int an, int aty, int atx) {
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      const int ho = aty * g.TH + yp_r[p], wo = atx * g.TW + yp_c[p];
+      if (DW_EXP != 1 && cg_ok && yp_r[p] >= 0 && ho < g.Ho && wo < g.Wo) {
+        Raw8<T> v;
+        v.load(s_y + (yp_r[p] * g.TW + yp_c[p]) * CB + cg * 8);
+        v.store(y + (((long)an * g.Ho + ho) * g.Wo + wo) * yps + chan_base(c_base + cg * 8, yss));
+      }
+    }
+  };
+  int sn = -1, sty = 0, stx = 0;   // tile whose output is waiting in s_y
+
   // tile walk: every worker owns a CONTIGUOUS range of tiles, column-major inside an image (ty fastest); (n, ty, tx) are
   // carried, not re-derived.  The LDS tile is a ring over rows: when the next tile is the one BELOW the current one, its
   // first LH - TH*S rows are the current tile's last rows and stay where they are (slot of tile row r = (r + base) mod LH);
@@ -255,7 +287,8 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   if (tile < t_end) issue(n, ty, tx, 0);
   for (; tile < t_end; ++tile) {
     const int ho0 = ty * g.TH, wo0 = tx * g.TW;
-    __syncthreads();  // previous tile fully consumed (also orders the s_w / s_st initialisation)
+    __syncthreads();  // previous tile fully consumed, its output complete in s_y (also orders the s_w initialisation)
+    if (DW_FWD_STAGE && sn >= 0) store_y(sn, sty, stx);
     if (DW_EXP != 3) commit(rowmin, base);
     __syncthreads();
     ntx = tx; nty = ty; nn = n;
@@ -292,8 +325,8 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
         }
       }
       if (ch < cpad) {
-        const long yps = pix_stride(ldy, yss);
         T* yr = y + (((long)n * g.Ho + ho) * g.Wo) * yps + chan_base(ch & ~7, yss) + (ch & 7);
+        T* sy = s_y + (r * g.TW + j * SW) * CB + 2 * c2;
 #pragma unroll
         for (int t = 0; t < SW; ++t) {
           const int wo = wo0 + j * SW + t;
@@ -301,15 +334,21 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
             float o[2];
             o[0] = (ch < g.C) ? to_f32(from_f32<T>(acc[t][0])) : 0.f;
             o[1] = (ch + 1 < g.C) ? to_f32(from_f32<T>(acc[t][1])) : 0.f;
-            if (DW_EXP != 1) VecIO<T, 2>::store(yr + (long)wo * yps, o);
+            if (DW_FWD_STAGE) VecIO<T, 2>::store(sy + t * CB, o);
+            else if (DW_EXP != 1) VecIO<T, 2>::store(yr + (long)wo * yps, o);
             ssum[0] += o[0]; ssq[0] += o[0] * o[0];
             ssum[1] += o[1]; ssq[1] += o[1] * o[1];
           }
         }
       }
     }
+    sn = n; sty = ty; stx = tx;
     tx = ntx; ty = nty; n = nn;
     rowmin = nrowmin; base = nbase;
+  }
+  if (DW_FWD_STAGE) {
+    __syncthreads();
+    if (sn >= 0) store_y(sn, sty, stx);
   }
 
   if (stats) {
@@ -345,7 +384,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 // Tiles are in INPUT space (TH x TW input pixels); the LDS tile holds dYraw over the output window those pixels touch.
 // Work item = (channel pair, input row, strip of SW input pixels).  For stride 2 only taps of matching parity contribute:
 // per (t, kx) that is a compile-time fact (tile and strip origins are even), per ky it is uniform for a row.
-template <typename T, int K, int S, int SW, int CB, bool R6>
+template <typename T, int K, int S, int SW, int CB, int TM, bool R6>   // TM: largest tile edge (14, or 7 for the 7x7 maps)
 // (launch bounds for 3 resident workgroups, i.e. <= 168 VGPRs, make k = 5 spill 136 bytes and run 2.3x slower: measured, dropped)
 __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, long gss, const T* __restrict__ yraw, int ldyr,
                                                     long yrss, const float* __restrict__ c1, const float* __restrict__ c2p,
@@ -360,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   constexpr int RELMAX = fdiv(SW - 1 + P, S);
   constexpr int DWN = RELMAX - RELMIN + 1;       // dY columns per strip
   static_assert(SW % S == 0, "strip origins must stay multiples of the stride");
-  constexpr int LMAXB = fdiv(14 - 1 + P, S) - cdiv(P - (K - 1), S) + 1;  // dY window of a 14-pixel input tile
-  constexpr int PF = (LMAXB * (fdiv(14 - 1 + P, S) - fdiv(-P, S) + 1) * (CB / 8) + 255) / 256;
+  constexpr int LMAXB = fdiv(TM - 1 + P, S) - cdiv(P - (K - 1), S) + 1;  // dY window of a TM-pixel input tile
+  constexpr int PF = (LMAXB * (fdiv(TM - 1 + P, S) - fdiv(-P, S) + 1) * (CB / 8) + 255) / 256;
   static_assert(PF <= 32, "prefetch mask is 32 bits");
   constexpr bool DMA = DW_DMA && sizeof(T) == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -373,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   float* s_red = s_w + KK * CB;              // [CB][KK + 2]
   float* s_cf = s_red + CB * (KK + 2);       // [3][CB] BN-backward coefficients of the slab (c1 = 1, c2 = c3 = 0 without them)
   T* s_x = reinterpret_cast<T*>(s_cf + 3 * CB);   // [TH*TW][CB] raw input pixels of the tile (staged with 16-byte loads)
-  T* s_h = s_x + 14 * 14 * CB;                    // [TH*TW][CB] the tile's input gradient, written out with 16-byte stores
+  T* s_h = s_x + TM * TM * CB;                    // [TH*TW][CB] the tile's input gradient, written out with 16-byte stores
 
   const int tid = threadIdx.x;
   constexpr int C2 = CB / 2, CG = CB / 8;
@@ -480,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
       }
     }
   };
-  constexpr int NIT = (C2 * 14 * (14 / SW) + 255) / 256;
+  constexpr int NIT = (C2 * TM * (TM / SW) + 255) / 256;
   int it_r[NIT], it_j[NIT];
 #pragma unroll
   for (int q = 0; q < NIT; ++q) {
@@ -493,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
   // items read / write their channel pairs in LDS.  Measured (cold caches, 56x56x144, k = 3): with 4-byte-per-lane global
   // accesses the x loads alone cost 31 % of the kernel (65 % for stride 2) and the h stores 14 %.  The strip's raw pixels
   // stay in registers from the weight-gradient operand to the ReLU mask / statistics of the epilogue.
-  constexpr int XP = (14 * 14 * CG + 255) / 256;
+  constexpr int XP = (TM * TM * CG + 255) / 256;
   int xp_r[XP], xp_c[XP];
 #pragma unroll
   for (int p = 0; p < XP; ++p) {
@@ -777,7 +816,7 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   g.LW = (g.TW - 1) * S + K;
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
-  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 8 * cb) * sizeof(float);
+  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 8 * cb) * sizeof(float) + (size_t)g.TH * g.TW * cb * sizeof(T);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env = getenv("ATOMNAS_DW_FWD_PERCU") ? atoi(getenv("ATOMNAS_DW_FWD_PERCU")) : 0;
   const int cap = cap_env ? cap_env : 8;
@@ -817,6 +856,10 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
   if (S == 2 && H == 56) cb_rule = 16;
   else if (S == 1 && H == 28 && K <= 5) cb_rule = 32;
   else if (S == 1 && H == 14 && K == 5) cb_rule = 32;
+  // 7x7 maps: the whole image is one tile of 7 rows x 1 strip, so only wide slabs fill the 256 threads (64 channels: 224 work
+  // items; 16 channels: 56).  The prefetch registers are sized for the 7-pixel tile there (template parameter TM).
+  const bool small = (S == 1 && H <= 7 && W <= 7);
+  if (small) cb_rule = (K == 7) ? DW_SMALL_CB7 : 64;
   const int cb = slab_width(cb_env ? cb_env : cb_rule, cpad);
   pick_tiles(g, H, W, SW, cb, S == 2);
   // output window of an input tile: rows ceil((hi0+P-K+1)/S) .. floor((hi0+TH-1+P)/S)
@@ -825,22 +868,31 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
   // + raw LDS-DMA staging of the dY / yraw prefetch (bf16): 2 streams x PF pieces x 256 threads x 16 bytes
-  const int lmaxb = fdiv(14 - 1 + P, S) - cdiv(P - (K - 1), S) + 1, lmaxw = fdiv(14 - 1 + P, S) - fdiv(-P, S) + 1;
+  const int tm = small ? 7 : 14;
+  const int lmaxb = fdiv(tm - 1 + P, S) - cdiv(P - (K - 1), S) + 1, lmaxw = fdiv(tm - 1 + P, S) - fdiv(-P, S) + 1;
   const int pf = (lmaxb * lmaxw * (cb / 8) + 255) / 256;
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2) + 3 * (size_t)cb) * sizeof(float) +
-                     (size_t)2 * 14 * 14 * cb * sizeof(T) + ((DW_DMA && sizeof(T) == 2) ? (size_t)2 * pf * 256 * 16 : 0);
+                     (size_t)2 * tm * tm * cb * sizeof(T) + ((DW_DMA && sizeof(T) == 2) ? (size_t)2 * pf * 256 * 16 : 0);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env2 = getenv("ATOMNAS_DW_BWD_PERCU") ? atoi(getenv("ATOMNAS_DW_BWD_PERCU")) : 0;
   const int cap = cap_env2 ? cap_env2 : 8;
-#define BWD_CASE(CBV)                                                                                                     \
+#define BWD_CASE(CBV, TMV)                                                                                                \
   {                                                                                                                       \
-    auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, true> : k_dwconv_bwd<T, K, S, SW, CBV, false>;                                                                           \
+    auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, TMV, true> : k_dwconv_bwd<T, K, S, SW, CBV, TMV, false>;                                                                           \
     set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, (stats || dw) ? part_rows : 0);                               \
     dim3 grid(dw_grid(g));                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, gss, (const T*)yraw, ldyr, yrss, c1, c2, c3, (const T*)x, \
                        ldx, xss, sc, sh, relu, w, ldw, (T*)h, ldh, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g); \
   }
-  if (cb == 8) BWD_CASE(8) else if (cb == 16) BWD_CASE(16) else BWD_CASE(32)
+  if constexpr (S == 1) {
+    if (small) {
+      if (cb == 8) BWD_CASE(8, 7) else if (cb == 16) BWD_CASE(16, 7) else if (cb == 32) BWD_CASE(32, 7) else BWD_CASE(64, 7)
+    } else {
+      if (cb == 8) BWD_CASE(8, 14) else if (cb == 16) BWD_CASE(16, 14) else BWD_CASE(32, 14)
+    }
+  } else {
+    if (cb == 8) BWD_CASE(8, 14) else if (cb == 16) BWD_CASE(16, 14) else BWD_CASE(32, 14)
+  }
 #undef BWD_CASE
   if (int rc = check_launch("dwconv_bwd")) return rc;
   // dw[c][t] += sum over workers of the partials, in worker order

@@ -184,8 +184,8 @@ def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc
 
 
 def bn_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, save_mean,
-                    save_invstd, C, stat_rows=None):
-    call("atomnas_bn_finalize_fwd", _p(stats), _rows(stats, stat_rows), float(count), _p(gamma), _p(beta), eps,
+                    save_invstd, C, stat_rows=None, stat_ld=None):
+    call("atomnas_bn_finalize_fwd", _p(stats), _rows(stats, stat_rows), pad8(C) if stat_ld is None else stat_ld, float(count), _p(gamma), _p(beta), eps,
          -1.0 if momentum is None else momentum,
          _p(running_mean), _p(running_var), _p(nbt), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), C, _stream())
 
@@ -194,8 +194,9 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, scale, shift, C)
     call("atomnas_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(scale), _p(shift), C, _stream())
 
 
-def bn_finalize_bwd(stats2, count, gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, stat_rows=None):
-    call("atomnas_bn_finalize_bwd", _p(stats2), _rows(stats2, stat_rows), float(count), _p(gamma), _p(save_mean), _p(save_invstd),
+def bn_finalize_bwd(stats2, count, gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, stat_rows=None,
+                    stat_ld=None):
+    call("atomnas_bn_finalize_bwd", _p(stats2), _rows(stats2, stat_rows), pad8(C) if stat_ld is None else stat_ld, float(count), _p(gamma), _p(save_mean), _p(save_invstd),
          _p(rho_ptr), _p(penalty),
          _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), C, _stream())
 

@@ -60,8 +60,25 @@ def _stamp(m, h, w, batch):
         if len(m.ops) == 0:
             ho, wo = h, w
         return ho, wo
-    if isinstance(m, mb.InvertedResidualChannelsFused):
-        raise NotImplementedError('profiling of the fused block')
+    if isinstance(m, mb.SqueezeAndExcitation):   # :121-129: the gate's input numel + the two 1x1 convs on the pooled vector
+        _stamp_conv(m.se_reduce, 1, 1, batch)
+        _stamp_conv(m.se_expand, 1, 1, batch)
+        m.n_macs = m.n_feature * h * w * batch + m.se_reduce.n_macs + m.se_expand.n_macs
+        m.n_params = m.se_reduce.n_params + m.se_expand.n_params
+        m.n_seconds = 0
+        return h, w
+    if isinstance(m, mb.InvertedResidualChannelsFused):   # :138-147: depth_ops + expand_conv + project_conv + se_op
+        m.n_macs = m.n_params = m.n_seconds = 0
+        _stamp(m.expand_conv, h, w, batch)
+        ho, wo = h, w
+        for op in m.depth_ops:
+            ho, wo = _stamp_seq(op, h, w, batch)
+        _stamp(m.se_op, ho, wo, batch)
+        _stamp_seq(m.project_conv, ho, wo, batch)
+        for sub in list(m.depth_ops) + [m.expand_conv, m.project_conv, m.se_op]:
+            m.n_macs += getattr(sub, 'n_macs', 0)
+            m.n_params += getattr(sub, 'n_params', 0)
+        return ho, wo
     if len(list(m.children())) > 0:
         return _stamp_seq(m, h, w, batch)
     m.n_macs = m.n_params = m.n_seconds = 0   # BN, activations, dropout: zero-cost leaves in the reference's table

@@ -104,10 +104,11 @@ int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, long u_ss, const void
 
 /* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;
  *      kwargs from models/mobilenet_supernet.py:95-98; calibration mode utils/common.py:214-226.
- * finalize forward: stats = stat_rows partial rows of [sum x, sum x^2] over `count` elements -> scale = gamma*invstd,
+ * finalize forward: stats = stat_rows partial rows [2][stat_ld] of [sum x, sum x^2] over `count` elements (stat_ld >= C rounded
+ *   up to 8: a branch segment of a wider statistics buffer can be finalized on its own) -> scale = gamma*invstd,
  *   shift = beta - mean*scale, save_mean / save_invstd for backward, running statistics update (momentum < 0: cumulative
  *   average 1/(counter+1); the caller bumps the counter). */
-int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, double count, const float* gamma, const float* beta, float eps, float momentum,
+int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, int stat_ld, double count, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
                             float* save_mean, float* save_invstd, int C, void* stream);
 /* eval mode: scale/shift from the running statistics */
@@ -115,7 +116,7 @@ int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, const float* r
                            float* scale, float* shift, int C, void* stream);
 /* finalize backward: stats2=[sum g, sum g*x] -> dgamma (+ rho*penalty*sign(gamma), utils/prune.py:161-167), dbeta and the
  *   coefficients of dx = c1*g + c2*x + c3.  rho is read from device memory (rho_ptr, may be NULL). */
-int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, double count, const float* gamma, const float* save_mean, const float* save_invstd,
+int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, int stat_ld, double count, const float* gamma, const float* save_mean, const float* save_invstd,
                             const float* rho_ptr, const float* penalty, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
                             int C, void* stream);
 /* y = act(x*scale+shift) (+ res): the shared pw_bn + residual of a block, models/mobilenet_base.py:379-381 */

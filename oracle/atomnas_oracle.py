@@ -72,8 +72,10 @@ def spec_from_model(model):
     last_name, last = feats[-2]
     blocks = []
     for name, b in feats[1:-2]:
+        fused = hasattr(b, 'depth_ops')   # InvertedResidualChannelsFused (models/mobilenet_base.py:145-274)
         blocks.append(dict(name='features.' + name, inp=b.input_dim, oup=b.output_dim, stride=b.stride, expand=b.expand,
-                           channels=list(b.channels), ks=list(b.kernel_sizes), res=b.use_res_connect))
+                           channels=list(b.channels), ks=list(b.kernel_sizes), res=b.use_res_connect, fused=fused,
+                           se=bool(fused and getattr(b, 'se_ratio', None) is not None)))
     bn = list(stem.children())[1]
     drop = list(model.classifier.children())[0]
     return dict(stem='features.' + stem_name, last='features.' + last_name, blocks=blocks, eps=bn.eps, momentum=bn.momentum,
@@ -121,8 +123,46 @@ def conv_bn_act(x, sd, prefix, stride, groups, k, training, spec, stats_out, q=N
     return q.f(y) if store_out else y
 
 
+def se_forward(x, sd, prefix, act):
+    """SqueezeAndExcitation.forward (models/mobilenet_base.py:109-112): mean over H, W -> 1x1 conv + bias -> activation -> 1x1 conv +
+    bias -> sigmoid -> scale."""
+    s = x.mean([2, 3], keepdim=True)
+    s = F.conv2d(s, sd[prefix + '.se_reduce.weight'], sd[prefix + '.se_reduce.bias'])
+    s = _act(s, act)
+    s = F.conv2d(s, sd[prefix + '.se_expand.weight'], sd[prefix + '.se_expand.bias'])
+    return torch.sigmoid(s) * x
+
+
+def fused_block_forward(x, sd, blk, training, spec, stats_out=None, q=NoQuant):
+    """InvertedResidualChannelsFused.forward (models/mobilenet_base.py:256-267) with _build's layout (:181-231): one expand
+    ConvBNReLU over all hidden channels, Narrow + depthwise ConvBNReLU per kernel size, concatenation, optional SE, projection
+    conv + BN, residual."""
+    name = blk['name']
+    t = x
+    if blk['expand']:
+        t = conv_bn_act(x, sd, name + '.expand_conv', 1, 1, 1, training, spec, stats_out, q, dense=True, store_out=False)
+    outs, start = [], 0
+    j = 1 if blk['expand'] else 0
+    for i, (h, k) in enumerate(zip(blk['channels'], blk['ks'])):
+        ti = t.narrow(1, start, h) if blk['expand'] else t
+        start += h
+        # without SE the activated depthwise output is the (rounded) MFMA operand of the projection; with SE the gated tensor is
+        outs.append(conv_bn_act(ti, sd, '{}.depth_ops.{}.{}'.format(name, i, j), blk['stride'], h, k, training, spec, stats_out, q,
+                                dense=False, store_out=not blk.get('se')))
+    res = torch.cat(outs, 1) if len(outs) != 1 else outs[0]
+    if blk.get('se'):
+        res = q.b(q.f(se_forward(res, sd, name + '.se_op', spec['act'])))
+    res = F.conv2d(res, q.f(sd[name + '.project_conv.0.weight']))
+    res = q.b(q.f(res))
+    res = bn(res, sd, name + '.project_conv.1', training, spec['eps'], spec['momentum'], stats_out)
+    out = x + res if blk['res'] else res
+    return q.b(q.f(out))
+
+
 def block_forward(x, sd, blk, training, spec, stats_out=None, q=NoQuant):
     """InvertedResidualChannels.forward (models/mobilenet_base.py:371-382) with _build's layout (:305-346)."""
+    if blk.get('fused'):
+        return fused_block_forward(x, sd, blk, training, spec, stats_out, q)
     if len(blk['channels']) == 0:
         return x
     name = blk['name']

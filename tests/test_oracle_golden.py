@@ -169,3 +169,48 @@ def test_full_supernet_eval_logits():
     assert_close("logits", logits, g["logits"], rtol=1e-3, atol=1e-4)
     for (m, a), f in zip(g["feats"][:len(feats)], feats):
         assert abs(float(f.mean()) - m) < 1e-4 * max(1, abs(m)) and abs(float(f.abs().max()) - a) < 1e-3 * max(1, a)
+
+
+def test_fused_se_blocks_and_searched_network():
+    """InvertedResidualChannelsFused + SqueezeAndExcitation + Swish (models/mobilenet_base.py:72-117,145-274) and a small
+    MobileNetSearched (models/searched_network.py) built from them: the oracle's restatement against the reference's own outputs."""
+    g = load("fused_se.pt")
+    for key in ("block0", "block1", "block2"):
+        d = g[key]
+        cfg = d["cfg"]
+        blk = dict(name="blk", inp=cfg["inp"], oup=cfg["oup"], stride=cfg["stride"], expand=cfg["expand"], channels=cfg["channels"],
+                   ks=cfg["ks"], res=cfg["stride"] == 1 and cfg["inp"] == cfg["oup"], fused=True, se=cfg["se_ratio"] is not None)
+        spec = dict(eps=1e-3, momentum=0.01, act=cfg["act"])
+        work = {"blk." + k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.clone()) for k, v in d["sd"].items()}
+        x = d["x"].clone().requires_grad_(True)
+        stats = {}
+        out = orc.block_forward(x, work, blk, True, spec, stats)
+        assert_close(key + " out", out, d["out"], rtol=1e-9, atol=1e-10)
+        out.backward(d["gout"])
+        assert_close(key + " dx", x.grad, d["dx"], rtol=1e-8, atol=1e-10)
+        for n, gr in d["grads"].items():
+            assert_close(key + " grad " + n, work["blk." + n].grad, gr, rtol=1e-8, atol=1e-10 * max(1.0, float(gr.abs().max())))
+        for prefix, (rm, rv) in stats.items():
+            assert_close(prefix, rm, d["sd_after"][prefix[4:] + ".running_mean"], rtol=1e-9, atol=1e-12)
+            assert_close(prefix, rv, d["sd_after"][prefix[4:] + ".running_var"], rtol=1e-9, atol=1e-12)
+        ev = orc.block_forward(d["x"], {"blk." + k: v for k, v in d["sd_after"].items()}, blk, False, spec)
+        assert_close(key + " eval", ev, d["out_eval"], rtol=1e-9, atol=1e-10)
+    # searched network with fused SE blocks
+    n = g["net"]
+    from atomnas_amd.models import searched_network as sn
+    model = sn.Model(**n["kw"])
+    assert list(model.state_dict().keys()) == list(n["sd"].keys())
+    spec = orc.spec_from_model(model)
+    assert [b["fused"] for b in spec["blocks"]] == [True] * 6 and [b["se"] for b in spec["blocks"]] == [True] * 6
+    work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.clone()) for k, v in n["sd"].items()}
+    stats = {}
+    logits = orc.model_forward(n["x"], work, spec, True, stats)
+    assert_close("net logits", logits, n["logits"], rtol=1e-8, atol=1e-9)
+    loss = orc.ce_label_smooth(logits, n["target"], 0.1).mean()
+    assert abs(float(loss) - n["loss"]) < 1e-9
+    loss.backward()
+    for k, dg in n["grad_digests"].items():
+        check_digest("net grad " + k, work[k].grad, dg, rtol=1e-6)
+    from atomnas_amd.utils import model_profiling as mp
+    mp.model_profiling(model, 64, 64, verbose=False)
+    assert model.n_macs == n["n_macs"]

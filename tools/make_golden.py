@@ -282,6 +282,54 @@ def g_full_supernet():
                os.path.join(OUT, "full_supernet_eval.pt"))
 
 
+def g_fused_se():
+    """InvertedResidualChannelsFused (models/mobilenet_base.py:145-274) with Swish and SqueezeAndExcitation (:93-117), as
+    AtomNAS+ uses it (apps/eval/eval_se.yml: se_ratio 0.5): forward / backward / eval of three blocks (aligned, ragged, no SE)
+    and the logits of a small MobileNetSearched (models/searched_network.py) built from the same blocks."""
+    import models.searched_network as sn
+    out = {}
+    cfgs = [dict(inp=8, oup=8, stride=1, channels=[16, 16, 16], ks=[3, 5, 7], expand=True, act="nn.Swish", se_ratio=0.5),
+            dict(inp=8, oup=12, stride=2, channels=[12, 20, 7], ks=[3, 5, 7], expand=True, act="nn.Swish", se_ratio=0.5),
+            dict(inp=16, oup=16, stride=1, channels=[15, 23, 13], ks=[3, 5, 7], expand=True, act="nn.ReLU", se_ratio=None)]
+    for ci, cfg in enumerate(cfgs):
+        blk = mb.InvertedResidualChannelsFused(cfg["inp"], cfg["oup"], cfg["stride"], cfg["channels"], cfg["ks"], cfg["expand"],
+                                               active_fn=mb.get_active_fn(cfg["act"]), batch_norm_kwargs={"momentum": 0.01, "eps": 1e-3},
+                                               se_ratio=cfg["se_ratio"])
+        randomize(blk, 300 + 10 * ci)
+        blk = blk.double().train()
+        sd0 = sd_of(blk)
+        x = (counter_fill(torch.empty(3, cfg["inp"], 14, 14), 377 + ci) * 4).requires_grad_(True)
+        y = blk(x)
+        gout = counter_fill(y.detach(), 399 + ci) * 2
+        y.backward(gout)
+        out["block%d" % ci] = dict(cfg=cfg, sd=sd0, x=x.detach(), out=y.detach(), gout=gout, dx=x.grad.clone(),
+                                   grads={n: p.grad.clone() for n, p in blk.named_parameters()}, sd_after=sd_of(blk))
+        blk.eval()
+        out["block%d" % ci]["out_eval"] = blk(x.detach()).detach()
+    kw = dict(num_classes=10, input_size=64, input_channel=16, last_channel=64, dropout_ratio=0.0, se_ratio=0.5,
+              batch_norm_momentum=0.01, batch_norm_epsilon=1e-3, active_fn="nn.Swish", block="InvertedResidualChannelsFused",
+              inverted_residual_setting=[[8, 1, 1, [3], [16], False], [16, 2, 2, [3, 5, 7], [15, 23, 13], True],
+                                         [24, 1, 2, [3, 5], [40, 9], True], [32, 1, 2, [3, 5, 7], [32, 48, 16], True],
+                                         [40, 1, 2, [7], [100], True]])
+    model = sn.Model(**kw)
+    randomize(model, 500)
+    model = model.double().train()
+    sd0 = sd_of(model)
+    x = (counter_fill(torch.empty(4, 3, 64, 64), 501) * 4)
+    logits = model(x)
+    tgt = torch.tensor([1, 3, 5, 7])
+    crit = roptim.CrossEntropyLabelSmooth(10, 0.1)
+    loss = crit(logits, tgt).mean()
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.eval()
+    out["net"] = dict(kw=kw, sd=sd0, x=x, target=tgt, logits=logits.detach(), loss=float(loss), grad_digests=digests(grads),
+                      logits_eval=model(x).detach(), n_macs=None)
+    rprof.model_profiling(model.float(), 64, 64, use_cuda=False, num_forwards=0, verbose=False)
+    out["net"]["n_macs"] = int(model.n_macs)
+    torch.save(out, os.path.join(OUT, "fused_se.pt"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -296,5 +344,6 @@ if __name__ == "__main__":
     g_shrink()
     g_tables()
     g_full_supernet()
+    g_fused_se()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
