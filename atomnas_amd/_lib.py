@@ -27,6 +27,12 @@ SIGNATURES = {
     "atomnas_bn_act_pool": [vp, i32, vp, vp, i32, vp, i32, vp, f32, u64, vp, i32, i32, i32, i32, vp],
     "atomnas_pool_act_bwd": [vp, i32, vp, f32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "atomnas_act_bwd_stats": [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
+    "atomnas_se_squeeze": [vp, i32, i64, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "atomnas_se_mlp_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "atomnas_se_scale": [vp, i32, i64, vp, vp, i32, vp, i32, vp, i32, i64, i64, i32, i32, i32, vp],
+    "atomnas_se_bwd_gate": [vp, i32, i64, vp, i32, i64, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32,
+                            i32, i32, i32, i32, vp],
+    "atomnas_se_bwd_apply": [vp, i32, i64, vp, i32, i64, vp, vp, i32, vp, vp, i32, vp, i32, i64, vp, i32, i64, i32, i32, i32, vp],
     "atomnas_im2col_stem": [vp, vp, i32, i32, i32, i32, i32, vp],
     "atomnas_ce_smooth": [vp, i32, vp, f32, i32, i32, vp, vp, i32, f32, vp, i32, vp],
     "atomnas_colsum": [vp, i32, vp, i64, i32, i32, vp],

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_pool_act_bwd(const T* __restrict__ dpoo
         float gg = d[e] * inv;
         if (drop_p > 0.f && keep) gg = (c0 + e < C && keep[(long)n * C + c0 + e]) ? gg * keep_scale : 0.f;
         const float a = v[e] * s[e] + h[e];
-        if (!act_pass(a, act_of(relu))) gg = 0.f;
+        gg = act_bwd(gg, a, act_of(relu));
         if (c0 + e >= C) gg = 0.f;
         gg = to_f32(from_f32<T>(gg));
         o[e] = gg;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_stats(const T* __restrict__ dy,
       for (int e = 0; e < 8; ++e) {
         const float a = v[e] * s[e] + h[e];
         float gg = d[e];
-        if (!act_pass(a, act_of(relu))) gg = 0.f;
+        gg = act_bwd(gg, a, act_of(relu));
         if (c0 + e >= C) gg = 0.f;
         d[e] = gg;
         s0[e] += gg;

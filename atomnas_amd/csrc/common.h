@@ -114,16 +114,34 @@ template <int V> struct VecIO<bf16_t, V> {
   }
 };
 
-// Activation modes carried by the integer `relu` / `mask` arguments of the C ABI: 0 none, 1 ReLU, 2 ReLU6
-// (models/mobilenet_base.py:407-415 `get_active_fn`).  act_pass = the derivative is non-zero at pre-activation a.
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
+// Activation modes carried by the integer `relu` / `mask` arguments of the C ABI: 0 none, 1 ReLU, 2 ReLU6, 3 Swish
+// (models/mobilenet_base.py:407-415 `get_active_fn`, :72-80 `Swish`).
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_SWISH = 3 };
 // Resolved once per kernel into the original ReLU flag plus one uniform upper bound (6 or +inf): the ReLU select keeps the
 // code generation the kernels were tuned with, ReLU6 costs one v_min / one compare with a scalar operand.  (Measured on the
 // depthwise backward: a three-way select on the mode per element +35 %, a (lo, hi) clamp +14 % through register pressure.)
-struct Act { int relu; float hi; };
-__device__ __forceinline__ Act act_of(int mode) { return Act{mode != ACT_NONE, mode == ACT_RELU6 ? 6.f : __builtin_inff()}; }
-__device__ __forceinline__ float act_apply(float a, Act m) { return fminf(m.relu ? fmaxf(a, 0.f) : a, m.hi); }
+// Swish (x * sigmoid(x)) sits behind a wave-uniform branch: the ReLU paths do not execute the exponential.
+struct Act { int relu; float hi; int swish; };
+__device__ __forceinline__ Act act_of(int mode) {
+  return Act{mode == ACT_RELU || mode == ACT_RELU6, mode == ACT_RELU6 ? 6.f : __builtin_inff(), mode == ACT_SWISH};
+}
+__device__ __forceinline__ float swish_f(float a) { return a / (1.f + __expf(-a)); }
+// d/da [a * sigmoid(a)] = s * (1 + a * (1 - s))
+__device__ __forceinline__ float swish_grad(float a) {
+  const float s = 1.f / (1.f + __expf(-a));
+  return s * (1.f + a * (1.f - s));
+}
+__device__ __forceinline__ float act_apply(float a, Act m) {
+  if (__builtin_expect(m.swish, 0)) return swish_f(a);
+  return fminf(m.relu ? fmaxf(a, 0.f) : a, m.hi);
+}
+// act_pass = the derivative is non-zero at pre-activation a (ReLU / ReLU6 / none)
 __device__ __forceinline__ bool act_pass(float a, Act m) { return !(m.relu && !(a > 0.f)) && a < m.hi; }
+// gradient c of the activated value back through the activation at pre-activation a
+__device__ __forceinline__ float act_bwd(float c, float a, Act m) {
+  if (__builtin_expect(m.swish, 0)) return c * swish_grad(a);
+  return act_pass(a, m) ? c : 0.f;
+}
 
 // Activation layouts (include/atomnas_hip.h).  plain: [M][ld], element (row, c) at row*ld + c.  slab-major (ss > 0): the channel
 // dimension is cut into slabs of 16 channels and every slab is a contiguous [M][16] matrix, slab stride ss elements:

@@ -29,6 +29,12 @@
                    // the spills of k = 7, but the extra raw LDS buffers cost residency: +2..4 % on 16-channel slabs, +50..90 % on
                    // 32-channel ones, -5 % only for k = 7 stride 2 (tools/dwbench.py, same box) -> off
 #endif
+#ifndef DW_FWD_STAGE
+#define DW_FWD_STAGE 0   // experiment (forward): 1 = the output tile leaves through LDS in 16-byte pieces, 0 = every work item stores its
+                         // 4-byte channel pairs directly.  Measured in situ (bs 256 step, same kernels otherwise, profiles/r02_*): staging
+                         // is 3-5 % SLOWER on most layers and up to +77 % where the extra LDS costs a resident workgroup (only the
+                         // 112x112 k = 7 stride-2 layer gains, -18 %) -> off
+#endif
 #ifndef DW_SMALL_CB7
 #define DW_SMALL_CB7 32   // slab width of the k = 7 backward on 7x7 maps (64 needs more than 256 registers: 98 accumulators + prefetch)
 #endif
@@ -134,7 +140,8 @@ static inline int lds_pitch(int lw, int cb) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int K, int S, int SW, int CB, int TM, bool R6>
+// AM: activation specialisation of the prologue -- 0: none / ReLU by the runtime flag (the tuned code), 2: ReLU6, 3: Swish
+template <typename T, int K, int S, int SW, int CB, int TM, int AM>
 __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int ldx, long xss, const float* __restrict__ in_scale,
                                                     const float* __restrict__ in_shift, int in_relu,
                                                     const float* __restrict__ w, int ldw, T* __restrict__ y, int ldy, long yss,
@@ -148,11 +155,6 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   float* s_in = smem;                         // [LH][RP]
   float* s_w = s_in + g.LH * g.RP;            // [K*K][CB]
   float* s_st = s_w + K * K * CB;             // [4 waves][2][CB]: per-wave partial statistics, combined in wave order
-#ifndef DW_FWD_STAGE
-#define DW_FWD_STAGE 1   // 1 = the output tile leaves through LDS in 16-byte pieces (a tile row is one contiguous run in the slab-major
-                         // layout); 0 = every work item stores its 4-byte channel pairs directly (store-issue bound: 7 partial-line
-                         // store instructions per item)
-#endif
   T* s_y = reinterpret_cast<T*>(s_st + 8 * CB);   // [TH*TW][CB] the tile's output, stored with the next tile's commit
 
   const int tid = threadIdx.x;
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float a = pf[i].get(e) * sc[e] + sh[e];
-          if constexpr (R6) a = fminf(fmaxf(a, 0.f), 6.f);   // ReLU6 instances are separate so that the ReLU code stays as tuned
+          if constexpr (AM == ACT_RELU6) a = fminf(fmaxf(a, 0.f), 6.f);   // separate instances: the ReLU code stays as tuned
+          else if constexpr (AM == ACT_SWISH) a = swish_f(a);
           else a = in_relu ? fmaxf(a, 0.f) : a;
           v[e] = ok ? a : 0.f;
         }
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 // Tiles are in INPUT space (TH x TW input pixels); the LDS tile holds dYraw over the output window those pixels touch.
 // Work item = (channel pair, input row, strip of SW input pixels).  For stride 2 only taps of matching parity contribute:
 // per (t, kx) that is a compile-time fact (tile and strip origins are even), per ky it is uniform for a row.
-template <typename T, int K, int S, int SW, int CB, int TM, bool R6>   // TM: largest tile edge (14, or 7 for the 7x7 maps)
+template <typename T, int K, int S, int SW, int CB, int TM, int AM>   // TM: largest tile edge (14, or 7 for the 7x7 maps); AM as forward
 // (launch bounds for 3 resident workgroups, i.e. <= 168 VGPRs, make k = 5 spill 136 bytes and run 2.3x slower: measured, dropped)
 __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, long gss, const T* __restrict__ yraw, int ldyr,
                                                     long yrss, const float* __restrict__ c1, const float* __restrict__ c2p,
@@ -630,7 +633,8 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
         if (wi < g.W) {
           const float v[2] = {xq[q][t].get(0), xq[q][t].get(1)};
           const float a0 = v[0] * sc[0] + sh[0], a1 = v[1] * sc[1] + sh[1];
-          if constexpr (R6) xa[t] = f32x2{fminf(fmaxf(a0, 0.f), 6.f), fminf(fmaxf(a1, 0.f), 6.f)};
+          if constexpr (AM == ACT_RELU6) xa[t] = f32x2{fminf(fmaxf(a0, 0.f), 6.f), fminf(fmaxf(a1, 0.f), 6.f)};
+          else if constexpr (AM == ACT_SWISH) xa[t] = f32x2{swish_f(a0), swish_f(a1)};
           else xa[t] = in_relu ? f32x2{fmaxf(a0, 0.f), fmaxf(a1, 0.f)} : f32x2{a0, a1};
         }
       }
@@ -677,7 +681,8 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
           for (int c = 0; c < 2; ++c) {
             const float a = xv[c] * sc[c] + sh[c];
             float v;
-            if constexpr (R6) v = (a > 0.f && a < 6.f) ? dx[t][c] : 0.f;
+            if constexpr (AM == ACT_RELU6) v = (a > 0.f && a < 6.f) ? dx[t][c] : 0.f;
+            else if constexpr (AM == ACT_SWISH) v = dx[t][c] * swish_grad(a);
             else v = (in_relu && !(a > 0.f)) ? 0.f : dx[t][c];
             v = (ch + c < g.C) ? to_f32(from_f32<T>(v)) : 0.f;
             o[c] = v;
@@ -816,13 +821,14 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   g.LW = (g.TW - 1) * S + K;
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
-  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 8 * cb) * sizeof(float) + (size_t)g.TH * g.TW * cb * sizeof(T);
+  const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 8 * cb) * sizeof(float) + (DW_FWD_STAGE ? (size_t)g.TH * g.TW * cb * sizeof(T) : 0);
   ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env = getenv("ATOMNAS_DW_FWD_PERCU") ? atoi(getenv("ATOMNAS_DW_FWD_PERCU")) : 0;
   const int cap = cap_env ? cap_env : 8;
 #define FWD_CASE(CBV, TMV)                                                                                                   \
   {                                                                                                                      \
-    auto kern = (relu == ACT_RELU6) ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, true> : k_dwconv_fwd<T, K, S, 7, CBV, TMV, false>;                                                                           \
+    auto kern = (relu == ACT_RELU6) ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, ACT_RELU6>                                    \
+                                    : (relu == ACT_SWISH ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, ACT_SWISH> : k_dwconv_fwd<T, K, S, 7, CBV, TMV, 0>);                                                                           \
     set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, stats ? stat_rows : 0);                                      \
     dim3 grid(dw_grid(g));                                                                                      \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, xss, sc, sh, relu, w, ldw, (T*)y, ldy, yss, stats, stat_ld, stat_rows, g); \
@@ -878,7 +884,8 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
   const int cap = cap_env2 ? cap_env2 : 8;
 #define BWD_CASE(CBV, TMV)                                                                                                \
   {                                                                                                                       \
-    auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, TMV, true> : k_dwconv_bwd<T, K, S, SW, CBV, TMV, false>;                                                                           \
+    auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, TMV, ACT_RELU6>                                   \
+                                    : (relu == ACT_SWISH ? k_dwconv_bwd<T, K, S, SW, CBV, TMV, ACT_SWISH> : k_dwconv_bwd<T, K, S, SW, CBV, TMV, 0>);                                                                           \
     set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, (stats || dw) ? part_rows : 0);                               \
     dim3 grid(dw_grid(g));                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, gss, (const T*)yraw, ldyr, yrss, c1, c2, c3, (const T*)x, \

@@ -196,7 +196,7 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
           for (int i = 0; i < 8; ++i) {
             const int n = n8 + i;
             const float a = (n < N) ? tmp[i] * ep.zscale[n] + ep.zshift[n] : 0.f;
-            if (!act_pass(a, act_of(ep.mask))) c[8 * h8 + i] = 0.f;
+            c[8 * h8 + i] = act_bwd(c[8 * h8 + i], a, act_of(ep.mask));
           }
         }
       }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const float a = zv[i] * zs[i] + zh[i];
-            if (!act_pass(a, act_of(ep.mask))) c[8 * h8 + i] = 0.f;
+            c[8 * h8 + i] = act_bwd(c[8 * h8 + i], a, act_of(ep.mask));
           }
         }
       }

@@ -18,7 +18,7 @@ from .ops import PRO_BNBWD, PRO_BNRELU, PRO_NONE, STAT_SQ, STAT_Z
 from .ops import Slab
 from .runtime import pad8, pads
 
-ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2   # the integer `relu` / `mask` arguments of the C ABI
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH = 0, 1, 2, 3   # the integer `relu` / `mask` arguments of the C ABI
 
 
 def act_code(module):
@@ -29,7 +29,9 @@ def act_code(module):
         return ACT_RELU6
     if isinstance(module, nn.ReLU):
         return ACT_RELU
-    raise NotImplementedError("activation %s is not supported by the HIP path yet (ReLU / ReLU6 only)" % type(module).__name__)
+    if type(module).__name__ == "Swish":   # models/mobilenet_base.py:72-80
+        return ACT_SWISH
+    raise NotImplementedError("activation %s is not supported by the HIP path (ReLU / ReLU6 / Swish)" % type(module).__name__)
 
 
 # ---------------------------------------------------------------------------------------------- layout plumbing
@@ -90,22 +92,28 @@ def bn_forward_coeffs(bn, stats, count, dev):
     """bn: dict of arena views (gamma, beta, rm, rv, C, mods).  Uses batch statistics when the BN modules are in training
     mode (updating running statistics with their momentum; momentum None = cumulative average), running statistics otherwise."""
     C = bn["C"]
-    Cp = pad8(C)
+    segs = bn.get("segs")   # fused block: contiguous [total] parameter vectors, padded-segment kernel layout (runtime.py)
+    Cp = pad8(bn["Cpad"] if segs else C)
     st = BNState()
-    st.scale, st.shift = _f32(Cp, dev), _f32(Cp, dev)
+    zero = segs is not None   # the finalize launches of the segments leave the padding between segments untouched
+    st.scale, st.shift = _f32(Cp, dev, zero), _f32(Cp, dev, zero)
     mod = bn["mods"][0]
     eps = mod.eps
+    pieces = segs if segs else [(0, 0, C)]
     if mod.training or not mod.track_running_stats:
-        st.mean, st.invstd = _f32(Cp, dev), _f32(Cp, dev)
+        st.mean, st.invstd = _f32(Cp, dev, zero), _f32(Cp, dev, zero)
         track = mod.track_running_stats
-        ops.bn_finalize_fwd(stats.t, count, bn["gamma"], bn["beta"], eps, mod.momentum, bn["rm"] if track else None,
-                            bn["rv"] if track else None, mod.num_batches_tracked if track else None, st.scale, st.shift, st.mean,
-                            st.invstd, C, stat_rows=stats.rows)
+        for po, co, c in pieces:
+            ops.bn_finalize_fwd(stats.t[po:], count, bn["gamma"][co:], bn["beta"][co:], eps, mod.momentum,
+                                bn["rm"][co:] if track else None, bn["rv"][co:] if track else None,
+                                mod.num_batches_tracked if track else None, st.scale[po:], st.shift[po:], st.mean[po:], st.invstd[po:],
+                                c, stat_rows=stats.rows, stat_ld=stats.c)
         if track:
             bn["mgr"].bn_trained = True
     else:
         st.mean = st.invstd = None
-        ops.bn_eval_coeffs(bn["gamma"], bn["beta"], bn["rm"], bn["rv"], eps, st.scale, st.shift, C)
+        for po, co, c in pieces:
+            ops.bn_eval_coeffs(bn["gamma"][co:], bn["beta"][co:], bn["rm"][co:], bn["rv"][co:], eps, st.scale[po:], st.shift[po:], c)
     return st
 
 
@@ -117,12 +125,15 @@ def bn_uses_batch_stats(bn):
 def bn_backward_coeffs(bn, st, stats2, count, dev):
     """-> (c1, c2, c3) with dx = c1*g + c2*x + c3; writes dgamma / dbeta into the gradient arena."""
     C = bn["C"]
-    Cp = pad8(C)
-    c1, c2, c3 = _f32(Cp, dev), _f32(Cp, dev), _f32(Cp, dev)
+    segs = bn.get("segs")
+    Cp = pad8(bn["Cpad"] if segs else C)
+    zero = segs is not None
+    c1, c2, c3 = _f32(Cp, dev, zero), _f32(Cp, dev, zero), _f32(Cp, dev, zero)
     if st.mean is None:
         raise RuntimeError("backward through a BatchNorm in eval mode is not supported")
-    ops.bn_finalize_bwd(stats2.t, count, bn["gamma"], st.mean, st.invstd, None, None, bn["dgamma"], bn["dbeta"], c1, c2, c3, C,
-                        stat_rows=stats2.rows)
+    for po, co, c in (segs if segs else [(0, 0, C)]):
+        ops.bn_finalize_bwd(stats2.t[po:], count, bn["gamma"][co:], st.mean[po:], st.invstd[po:], None, None, bn["dgamma"][co:],
+                            bn["dbeta"][co:], c1[po:], c2[po:], c3[po:], c, stat_rows=stats2.rows, stat_ld=stats2.c)
     return c1, c2, c3
 
 
@@ -170,13 +181,28 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     bsp = bn_uses_batch_stats(pl.bnp)
     Pr = torch.empty(M2, pl.oup, dtype=T, device=dev)
     stP = _stats(pl.oup, dev, pl.bnp["mgr"]) if bsp else None
-    ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=int(act),
-                stats=stP.t if bsp else None, stat_mode=STAT_SQ if bsp else 0, stat_rows=stP.rows if bsp else None)
+    se = None
+    if pl.se:
+        # SqueezeAndExcitation (models/mobilenet_base.py:109-112) on the activated depthwise output A = act(bn(D)):
+        # squeeze -> two tiny dense layers -> gate; the gated tensor S is the projection's operand
+        HWo = Ho * Wo
+        se = dict(pooled=_f32(N * HT, dev).view(N, HT), gate=_f32(N * HT, dev).view(N, HT), hpre=_f32(N * pl.se_hid, dev).view(N, pl.se_hid))
+        ops.se_squeeze(D, bD.scale, bD.shift, int(act), se["pooled"], N, HWo, HT)
+        ops.se_mlp_fwd(se["pooled"], pl.cmap, pl.se_w1, pl.se_b1, pl.se_w2, pl.se_b2, pl.se_act, se["hpre"], se["gate"], N, HT, pl.total,
+                       pl.se_hid)
+        Sx = _hidden(pl, M2, HT, T, dev)
+        ops.se_scale(D, bD.scale, bD.shift, int(act), se["gate"], Sx, M2, HWo, HT)
+        se["S"] = Sx
+        ops.gemm_nt(Sx, pl.Wp_pack, Pr, M2, pl.oup, HT, stats=stP.t if bsp else None, stat_mode=STAT_SQ if bsp else 0,
+                    stat_rows=stP.rows if bsp else None)
+    else:
+        ops.gemm_nt(D, pl.Wp_pack, Pr, M2, pl.oup, HT, a_mode=PRO_BNRELU, ac1=bD.scale, ac2=bD.shift, a_relu=int(act),
+                    stats=stP.t if bsp else None, stat_mode=STAT_SQ if bsp else 0, stat_rows=stP.rows if bsp else None)
     bP = bn_forward_coeffs(pl.bnp, stP, M2, dev)
     out = torch.empty(M2, pl.oup, dtype=T, device=dev)
     ops.bn_apply(Pr, bP.scale, bP.shift, False, x2d if pl.res else None, out, M2, pl.oup)
     if need_grad:
-        sv = dict(x=x2d, E=E, D=D, P=Pr, bE=bE, bD=bD, bP=bP, dims=(N, H, W, Ho, Wo))
+        sv = dict(x=x2d, E=E, D=D, P=Pr, bE=bE, bD=bD, bP=bP, dims=(N, H, W, Ho, Wo), se=se)
         return out, sv
     return out, None
 
@@ -192,14 +218,34 @@ def block_backward(pl, sv, G):
     st2P = _stats(pl.oup, dev, pl.bnp["mgr"])
     ops.act_bwd_stats(G, Pr, None, None, False, None, st2P.t, M2, pl.oup, stat_rows=st2P.rows)
     p1, p2, p3 = bn_backward_coeffs(pl.bnp, bP, st2P, M2, dev)
-    # projection weight gradient: dWp[n][k] = sum_m dP[m][n] * act(bn(D))[m][k]
-    ops.gemm_tn(G, pl.oup, D, HT, pl.Wp_grad, HT, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
-                vc1=bD.scale, vc2=bD.shift, v_relu=int(act))
-    # projection input gradient, masked by the depthwise ReLU, with the depthwise-BN backward statistics
+    se = sv.get("se")
+    # projection weight gradient: dWp[n][k] = sum_m dP[m][n] * A'[m][k], A' = act(bn(D)) (gated by the SE when there is one).
+    # The fused block's projection weight is one contiguous [oup, total] tensor: one launch per branch segment.
+    wp_jobs = ([(sg, h, pl.Wp_grad[stt:], pl.total) for sg, stt, h in zip(pl.seg, pl.start, pl.hid)] if pl.fused
+               else [(0, HT, pl.Wp_grad, HT)])
+    for sg, nv, out, si in wp_jobs:
+        if se is not None:
+            ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
+        else:
+            ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
+                        vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
     g = _hidden(pl, M2, HT, T, dev)
     st2D = _stats(HT, dev, pl.bnd["mgr"])
-    ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
-                zshift=bD.shift, mask=int(act), stats=st2D.t, stat_mode=STAT_Z, stat_rows=st2D.rows)
+    if se is not None:
+        # gradient wrt the gated tensor, then back through the gate (models/mobilenet_base.py:109-112) and the activation
+        HWo = Ho * Wo
+        dS = _hidden(pl, M2, HT, T, dev)
+        ops.gemm_nt(G, pl.WpT_pack, dS, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3)
+        nh = N * pl.se_hid
+        dgate, dz2, dpooled = (_f32(N * HT, dev).view(N, HT) for _ in range(3))
+        dz1 = _f32(nh, dev).view(N, pl.se_hid)
+        ops.se_bwd_gate(dS, D, bD.scale, bD.shift, int(act), se["gate"], se["pooled"], pl.cmap, pl.se_w1, pl.se_w2, se["hpre"], dgate, dz2,
+                        dz1, dpooled, pl.se_dw1, pl.se_db1, pl.se_dw2, pl.se_db2, N, HWo, HT, pl.total, pl.se_hid)
+        ops.se_bwd_apply(dS, D, bD.scale, bD.shift, int(act), se["gate"], dpooled, g, st2D.t, M2, HWo, HT, stat_rows=st2D.rows)
+    else:
+        # projection input gradient, masked by the depthwise activation, with the depthwise-BN backward statistics
+        ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
+                    zshift=bD.shift, mask=int(act), stats=st2D.t, stat_mode=STAT_Z, stat_rows=st2D.rows)
     d1, d2, d3 = bn_backward_coeffs(pl.bnd, bD, st2D, M2, dev)
     # depthwise backward per branch
     if pl.expand:
@@ -223,8 +269,13 @@ def block_backward(pl, sv, G):
             h = h + G
         return h
     e1, e2, e3 = bn_backward_coeffs(pl.bne, bE, st2E, M, dev)
-    # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k])
-    ops.gemm_tn(x2d, pl.inp, h, HT, pl.We_grad, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=E, vc1=e1, vc2=e2, vc3=e3)
+    # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k]); the
+    # fused block's expand weight is one contiguous [total, inp] tensor: one launch per branch segment
+    we_jobs = ([(sg, hh, pl.We_grad[stt * pl.inp:]) for sg, stt, hh in zip(pl.seg, pl.start, pl.hid)] if pl.fused
+               else [(0, HT, pl.We_grad)])
+    for sg, nv, out in we_jobs:
+        ops.gemm_tn(x2d, pl.inp, _seg(h, sg), nv, out, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=_seg(E, sg), vc1=e1[sg:], vc2=e2[sg:],
+                    vc3=e3[sg:])
     # expand input gradient (+ residual branch)
     Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
     ops.gemm_nt(h, pl.WeT_pack, Gx, M, pl.inp, HT, a_mode=PRO_BNBWD, a2=E, ac1=e1, ac2=e2, ac3=e3, add=G if pl.res else None)

@@ -53,7 +53,9 @@ class HSwish(nn.Module):
 
 
 class SqueezeAndExcitation(nn.Module):
-    """Squeeze-and-excitation gate (models/mobilenet_base.py:93-117); parameter container for the fused block."""
+    """Squeeze-and-excitation gate (models/mobilenet_base.py:93-117).  Parameter container: the gate runs inside the fused block's
+    executor (functional.block_forward: atomnas_se_squeeze / se_mlp_fwd / se_scale), where the activated depthwise output it acts
+    on is re-derived from the raw depthwise output instead of being materialised."""
 
     def __init__(self, n_feature, n_hidden, spatial_dims=[2, 3], active_fn=None):
         super().__init__()
@@ -63,7 +65,8 @@ class SqueezeAndExcitation(nn.Module):
         self.active_fn = active_fn()
 
     def forward(self, x):
-        raise NotImplementedError('SqueezeAndExcitation has no HIP kernel yet (AtomNAS+ / cfg 5 is a later row of the scope table)')
+        raise NotImplementedError('SqueezeAndExcitation runs inside InvertedResidualChannelsFused on the HIP path; a stand-alone call '
+                                  'has no kernel')
 
     def __repr__(self):
         return '{}({}, {}, spatial_dims={}, active_fn={})'.format(self._get_name(), self.n_feature, self.n_hidden,
@@ -175,8 +178,9 @@ class InvertedResidualChannels(nn.Module):
 class InvertedResidualChannelsFused(nn.Module):
     """Single expand conv + per-kernel depthwise slices + optional SE + single projection (:145-274).
 
-    Parameter container with the reference's layout (`expand_conv`, `depth_ops`, `project_conv`, `se_op`); the HIP
-    executor for this variant (cfg 5, AtomNAS+) is a later row of the scope table.
+    Same parameter layout as the reference (`expand_conv`, `depth_ops`, `project_conv`, `se_op`: state_dict keys and shapes).
+    Numerically it IS the branch block with concatenated weights, which is how the HIP executor always runs a block, so the
+    forward dispatches to the same executor (functional.block_forward) with the SE stage between depthwise and projection.
     """
 
     def __init__(self, inp, oup, stride, channels, kernel_sizes, expand, active_fn=None, batch_norm_kwargs=None,
@@ -229,7 +233,12 @@ class InvertedResidualChannelsFused(nn.Module):
         return list(self.get_named_depthwise_bn().values())
 
     def forward(self, x):
-        raise NotImplementedError('InvertedResidualChannelsFused has no HIP executor yet (cfg 5 / AtomNAS+)')
+        mgr = runtime.manager_of(self)
+        mgr.enter()
+        try:
+            return AF.run_block(runtime.plan_of(self), x, mgr.anchor)
+        finally:
+            mgr.leave()
 
     def __repr__(self):
         return '{}({}, {}, channels={}, kernel_sizes={}, expand={}, stride={}, se_ratio={})'.format(

@@ -221,6 +221,33 @@ def act_bwd_stats(dy, z, scale, shift, relu, g, stats2, M, C, stat_rows=None):
          _ld(g) if g is not None else 0, _p(stats2), _rows(stats2, stat_rows), M, C, dt_code(dy.dtype), _stream())
 
 
+def se_squeeze(d, scale, shift, act, pooled, N, HW, C):
+    call("atomnas_se_squeeze", _p(d), _ld(d), _ss(d), _p(scale), _p(shift), int(act), _p(pooled), pooled.stride(0), N, HW, C,
+         dt_code(d.dtype), _stream())
+
+
+def se_mlp_fwd(pooled, cmap, w1, b1, w2, b2, act, hpre, gate, N, HT, total, hid):
+    call("atomnas_se_mlp_fwd", _p(pooled), pooled.stride(0), _p(cmap), _p(w1), _p(b1), _p(w2), _p(b2), int(act), _p(hpre), _p(gate), N, HT,
+         total, hid, _stream())
+
+
+def se_scale(d, scale, shift, act, gate, out, M, HW, C):
+    call("atomnas_se_scale", _p(d), _ld(d), _ss(d), _p(scale), _p(shift), int(act), _p(gate), gate.stride(0), _p(out), _ld(out), _ss(out), M,
+         HW, C, dt_code(d.dtype), _stream())
+
+
+def se_bwd_gate(ds, d, scale, shift, act, gate, pooled, cmap, w1, w2, hpre, dgate, dz2, dz1, dpooled, dw1, db1, dw2, db2, N, HW, HT, total,
+                hid):
+    call("atomnas_se_bwd_gate", _p(ds), _ld(ds), _ss(ds), _p(d), _ld(d), _ss(d), _p(scale), _p(shift), int(act), _p(gate), _p(pooled),
+         gate.stride(0), _p(cmap), _p(w1), _p(w2), _p(hpre), _p(dgate), _p(dz2), _p(dz1), _p(dpooled), _p(dw1), _p(db1), _p(dw2), _p(db2), N,
+         HW, HT, total, hid, dt_code(d.dtype), _stream())
+
+
+def se_bwd_apply(ds, d, scale, shift, act, gate, dpooled, g, stats2, M, HW, C, stat_rows=None):
+    call("atomnas_se_bwd_apply", _p(ds), _ld(ds), _ss(ds), _p(d), _ld(d), _ss(d), _p(scale), _p(shift), int(act), _p(gate), _p(dpooled),
+         gate.stride(0), _p(g), _ld(g), _ss(g), _p(stats2), _rows(stats2, stat_rows), M, HW, C, dt_code(d.dtype), _stream())
+
+
 def im2col_stem(img, col, N, H, W):
     assert img.dtype == torch.float32 and img.is_contiguous()
     call("atomnas_im2col_stem", _p(img), _p(col), _ld(col), N, H, W, dt_code(col.dtype), _stream())

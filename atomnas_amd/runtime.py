@@ -217,6 +217,80 @@ class ArenaManager:
                     pack_jobs_f.append((so["Wd"][i], o_f, sp(h), k * k, k * k, sp(h), 0, 2))
                     pk["taps"].append((o_f, k * k, sp(h)))
                 plans.append((m, pl, dict(so=so, pk=pk)))
+            elif isinstance(m, mb.InvertedResidualChannelsFused):
+                # Fused block (models/mobilenet_base.py:145-274): ONE expand conv / BN over all `total` hidden channels, Narrow +
+                # depthwise per kernel size, optional SE, ONE projection conv + BN.  The kernels run on the same padded-segment
+                # layout as the branch block (HT = sum of segments padded to whole slabs); the total-wide parameters (expand
+                # weight / BN, projection weight, SE weights) are CONTIGUOUS masters in the arena, as the reference's state_dict
+                # has them, and reach the padded layout through per-segment pack jobs / per-segment finalize launches.
+                pl = BlockPlan()
+                pl.name, pl.module, pl.fused = name, m, True
+                pl.inp, pl.oup, pl.stride, pl.expand = m.input_dim, m.output_dim, m.stride, m.expand
+                pl.res = m.use_res_connect
+                pl.ks, pl.hid = list(m.kernel_sizes), list(m.channels)
+                nb = pl.nb = len(m.depth_ops)
+                for sub in m.modules():
+                    handled.add(id(sub))
+                sp = pl.segpad = pads if m.expand else pad8
+                pl.seg, pl.start = [], []
+                o = st = 0
+                for h in pl.hid:
+                    pl.seg.append(o)
+                    pl.start.append(st)
+                    o += sp(h)
+                    st += h
+                HT, total = o, st
+                pl.HT, pl.total = HT, total
+                so, pk = {}, {}
+                ldw, ldt = pad32(pl.inp), pad32(HT)
+                if m.expand:
+                    conv, bn, _ = list(m.expand_conv.children())
+                    so["We"] = lp.take(total * pl.inp)
+                    reg_slots.append(("dense", so["We"], total * pl.inp))
+                    bind_param(conv, "weight", so["We"], (total, pl.inp, 1, 1))
+                    so["bne"] = bn_slots(total)
+                    self._bind_bn(bind_param, bind_buf, lc, bn, so["bne"], 0, total)
+                    o_w, o_t = lpk.take(pad64(HT) * ldw), lpk.take(pad64(pl.inp) * ldt)
+                    for sg, stt, h in zip(pl.seg, pl.start, pl.hid):
+                        pack_jobs_t.append((so["We"] + stt * pl.inp, o_w + sg * ldw, h, pl.inp, pl.inp, ldw, 0, 0))
+                        pack_jobs_t.append((so["We"] + stt * pl.inp, o_t + sg, h, pl.inp, pl.inp, ldt, 0, 1))
+                    pk["We"], pk["WeT"] = (o_w, pad64(HT), ldw), (o_t, pad64(pl.inp), ldt)
+                so["Wd"] = [lp.take(sp(h) * k * k) for h, k in zip(pl.hid, pl.ks)]
+                so["bnd"] = bn_slots(HT)
+                pk["taps"] = []
+                idx = 1 if m.expand else 0
+                for i, op in enumerate(m.depth_ops):
+                    conv, bn, _ = list(list(op.children())[idx].children())
+                    h, k = pl.hid[i], pl.ks[i]
+                    reg_slots.append(("dw", so["Wd"][i], sp(h) * k * k))
+                    bind_param(conv, "weight", so["Wd"][i], (h, 1, k, k))
+                    self._bind_bn(bind_param, bind_buf, lc, bn, so["bnd"], pl.seg[i], h)
+                    o_f = lpf.take(k * k * sp(h))
+                    pack_jobs_f.append((so["Wd"][i], o_f, sp(h), k * k, k * k, sp(h), 0, 2))
+                    pk["taps"].append((o_f, k * k, sp(h)))
+                pconv, pbn = list(m.project_conv.children())
+                so["Wp"] = lp.take(pl.oup * total)
+                reg_slots.append(("dense", so["Wp"], pl.oup * total))
+                bind_param(pconv, "weight", so["Wp"], (pl.oup, total, 1, 1))
+                so["bnp"] = bn_slots(pl.oup)
+                self._bind_bn(bind_param, bind_buf, lc, pbn, so["bnp"], 0, pl.oup)
+                ldp, ldpt = pad32(HT), pad32(pl.oup)
+                o_w, o_t = lpk.take(pad64(pl.oup) * ldp), lpk.take(pad64(HT) * ldpt)
+                for sg, stt, h in zip(pl.seg, pl.start, pl.hid):
+                    pack_jobs_t.append((so["Wp"] + stt, o_w, pl.oup, h, total, ldp, sg, 0))
+                    pack_jobs_t.append((so["Wp"] + stt, o_t, pl.oup, h, total, ldpt, sg, 1))
+                pk["Wp"], pk["WpT"] = (o_w, pad64(pl.oup), ldp), (o_t, pad64(HT), ldpt)
+                pl.se = isinstance(m.se_op, mb.SqueezeAndExcitation)
+                if pl.se:
+                    se = m.se_op
+                    pl.se_hid = se.n_hidden
+                    for conv_, key in ((se.se_reduce, "se1"), (se.se_expand, "se2")):
+                        so[key + "w"] = lp.take(conv_.weight.numel())
+                        so[key + "b"] = lp.take(conv_.bias.numel())
+                        reg_slots.append(("dense", so[key + "w"], conv_.weight.numel()))
+                        bind_param(conv_, "weight", so[key + "w"], tuple(conv_.weight.shape))
+                        bind_param(conv_, "bias", so[key + "b"], tuple(conv_.bias.shape))
+                plans.append((m, pl, dict(so=so, pk=pk)))
             elif isinstance(m, mb.ConvBNReLU) and id(m) not in handled:
                 conv, bn, _ = list(m.children())
                 for sub in m.modules():
@@ -416,8 +490,12 @@ class ArenaManager:
     def _finish_plan(self, m, pl, info):
         from .functional import act_code
         P, G, S = self.P, self.G, self.S
+        if isinstance(pl, BlockPlan) and getattr(pl, "fused", False):
+            self._finish_fused_plan(m, pl, info)
+            return
         if isinstance(pl, BlockPlan):
             pl.valid = True
+            pl.fused = pl.se = False
             if pl.nb == 0:
                 return
             so, pk = info["so"], info["pk"]
@@ -477,6 +555,50 @@ class ArenaManager:
                     pl.taps = self.packF[o:o + kk * c].view(kk, c)
                 with torch.no_grad():
                     pl.bn["rv"][C:] = 1.0
+
+    def _finish_fused_plan(self, m, pl, info):
+        from .functional import act_code
+        P, G, S = self.P, self.G, self.S
+        so, pk = info["so"], info["pk"]
+        HT, total = pl.HT, pl.total
+        pl.valid = True
+        segs = [(sg, st, h) for sg, st, h in zip(pl.seg, pl.start, pl.hid)]   # (padded offset, contiguous offset, channels)
+
+        def bnv(sl, C, mods, segmented):
+            d = dict(gamma=P[sl["g"]:sl["g"] + C], beta=P[sl["b"]:sl["b"] + C], dgamma=G[sl["g"]:sl["g"] + C],
+                     dbeta=G[sl["b"]:sl["b"] + C], rm=S[sl["rm"]:sl["rm"] + C], rv=S[sl["rv"]:sl["rv"] + C], C=C, mods=mods, mgr=self)
+            if segmented:   # contiguous [total] vectors, padded [HT] kernel layout
+                d["segs"], d["Cpad"] = segs, HT
+            return d
+
+        idx = 1 if pl.expand else 0
+        dws = [list(op.children())[idx] for op in m.depth_ops]
+        pl.act = act_code(list(dws[0].children())[2])
+        if pl.expand:
+            pl.We_grad = G[so["We"]:so["We"] + total * pl.inp]
+            pl.bne = bnv(so["bne"], total, [list(m.expand_conv.children())[1]], True)
+            pl.We_pack, pl.WeT_pack = self._packview(pk["We"]), self._packview(pk["WeT"])
+        pl.Wd_grad = [G[o:o + pl.segpad(h) * k * k] for o, h, k in zip(so["Wd"], pl.hid, pl.ks)]
+        pl.bnd = bnv(so["bnd"], HT, [list(d.children())[1] for d in dws], False)
+        pl.Wp_grad = G[so["Wp"]:so["Wp"] + pl.oup * total]
+        pl.bnp = bnv(so["bnp"], pl.oup, [list(m.project_conv.children())[1]], False)
+        pl.Wp_pack, pl.WpT_pack = self._packview(pk["Wp"]), self._packview(pk["WpT"])
+        pl.taps = [self.packF[o:o + kk * c].view(kk, c) for (o, kk, c) in pk["taps"]]
+        with torch.no_grad():
+            rv = S[so["bnd"]["rv"]:so["bnd"]["rv"] + HT]
+            for sg, h in zip(pl.seg, pl.hid):
+                rv[sg + h:sg + pl.segpad(h)] = 1.0
+        if pl.se:
+            cmap = torch.full((HT,), -1, dtype=torch.int32)
+            for sg, st, h in segs:
+                cmap[sg:sg + h] = torch.arange(st, st + h, dtype=torch.int32)
+            pl.cmap = cmap.to(P.device)
+            n1, n2 = pl.se_hid * total, total * pl.se_hid
+            pl.se_w1, pl.se_b1 = P[so["se1w"]:so["se1w"] + n1], P[so["se1b"]:so["se1b"] + pl.se_hid]
+            pl.se_w2, pl.se_b2 = P[so["se2w"]:so["se2w"] + n2], P[so["se2b"]:so["se2b"] + total]
+            pl.se_dw1, pl.se_db1 = G[so["se1w"]:so["se1w"] + n1], G[so["se1b"]:so["se1b"] + pl.se_hid]
+            pl.se_dw2, pl.se_db2 = G[so["se2w"]:so["se2w"] + n2], G[so["se2b"]:so["se2b"] + total]
+            pl.se_act = act_code(m.se_op.active_fn)
 
     def _packview(self, t):
         off, rows, ld = t

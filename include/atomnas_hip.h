@@ -41,6 +41,7 @@ extern "C" {
 #define ATOMNAS_ACT_NONE 0
 #define ATOMNAS_ACT_RELU 1  /* max(a, 0);           backward passes where a > 0       */
 #define ATOMNAS_ACT_RELU6 2 /* min(max(a, 0), 6);   backward passes where 0 < a < 6   */
+#define ATOMNAS_ACT_SWISH 3 /* a * sigmoid(a);      backward multiplies by s*(1 + a*(1-s))   models/mobilenet_base.py:72-80 */
 
 /* prologue applied to a GEMM operand while it is loaded */
 #define ATOMNAS_PRO_NONE 0   /* a                                   */
@@ -133,6 +134,28 @@ int atomnas_pool_act_bwd(const void* dpooled, int ldp, const unsigned char* keep
 /* g = dy * [z*scale+shift > 0] (scale == NULL: no mask);  stats2 rows [sum g, sum g*z];  g may be NULL (statistics only) */
 int atomnas_act_bwd_stats(const void* dy, int lddy, const void* z, int ldz, const float* scale, const float* shift, int relu, void* g,
                           int ldg, float* stats2, int stat_rows, long M, int C, int dtype, void* stream);
+
+/* ---- Squeeze-and-Excitation of the fused block (AtomNAS+): models/mobilenet_base.py:93-117 inside :256-267.
+ *   A = act(D*scale+shift) is the activated depthwise output (never materialised), D the raw depthwise output [M = N*HW][C];
+ *   cmap[c]: row / column of the reference's SE weights (w1 [hid][total], w2 [total][hid]) for padded channel c, -1 for padding;
+ *   pooled / gate / dgate / dz2 / dpooled: fp32 [N][ldg];  hpre / dz1: fp32 [N][hid].
+ * forward:  pooled = mean_hw A;  hpre = w1*pooled + b1;  gate = sigmoid(w2*act(hpre) + b2);  out = A * gate[n] */
+int atomnas_se_squeeze(const void* d, int ldd, long d_ss, const float* scale, const float* shift, int act, float* pooled, int ldp, int N,
+                       int HW, int C, int dtype, void* stream);
+int atomnas_se_mlp_fwd(const float* pooled, int ldp, const int* cmap, const float* w1, const float* b1, const float* w2, const float* b2,
+                       int act, float* hpre, float* gate, int N, int HT, int total, int hid, void* stream);
+int atomnas_se_scale(const void* d, int ldd, long d_ss, const float* scale, const float* shift, int act, const float* gate, int ldg,
+                     void* out, int ldo, long o_ss, long M, int HW, int C, int dtype, void* stream);
+/* backward of the gate: dgate = sum_hw dS*A;  dz2 = dgate*gate*(1-gate);  dz1 = act'(hpre) * w2^T dz2;  dpooled = w1^T dz1;
+ *   dw1 += dz1^T pooled, db1 += sum dz1, dw2 += dz2^T act(hpre), db2 += sum dz2 (batch loops in image order: bit-reproducible) */
+int atomnas_se_bwd_gate(const void* ds, int ldds, long ds_ss, const void* d, int ldd, long d_ss, const float* scale, const float* shift,
+                        int act, const float* gate, const float* pooled, int ldg, const int* cmap, const float* w1, const float* w2,
+                        const float* hpre, float* dgate, float* dz2, float* dz1, float* dpooled, float* dw1, float* db1, float* dw2,
+                        float* db2, int N, int HW, int HT, int total, int hid, int dtype, void* stream);
+/* g = act'(D*scale+shift) * (dS*gate[n] + dpooled[n]/HW): the gradient wrt the depthwise BatchNorm output;  stats2 rows [sum g, sum g*D] */
+int atomnas_se_bwd_apply(const void* ds, int ldds, long ds_ss, const void* d, int ldd, long d_ss, const float* scale, const float* shift,
+                         int act, const float* gate, const float* dpooled, int ldg, void* g, int ldgo, long g_ss, float* stats2,
+                         int stat_rows, long M, int HW, int C, int dtype, void* stream);
 
 /* ---- stem and loss
  * im2col of the 3x3 stride-2 stem conv (models/mobilenet_supernet.py:126-132): img NCHW fp32 -> col [N*Ho*Wo][ld>=32] */
