@@ -135,12 +135,31 @@ __device__ __forceinline__ float act_apply(float a, Act m) {
   if (__builtin_expect(m.swish, 0)) return swish_f(a);
   return fminf(m.relu ? fmaxf(a, 0.f) : a, m.hi);
 }
+// vector form: ONE wave-uniform branch per V values (per-element calls leave a branch per element in the unrolled hot loops)
+template <int V> __device__ __forceinline__ void act_apply_v(float (&a)[V], Act m) {
+  if (__builtin_expect(m.swish, 0)) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = swish_f(a[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = fminf(m.relu ? fmaxf(a[e], 0.f) : a[e], m.hi);
+  }
+}
 // act_pass = the derivative is non-zero at pre-activation a (ReLU / ReLU6 / none)
 __device__ __forceinline__ bool act_pass(float a, Act m) { return !(m.relu && !(a > 0.f)) && a < m.hi; }
 // gradient c of the activated value back through the activation at pre-activation a
 __device__ __forceinline__ float act_bwd(float c, float a, Act m) {
   if (__builtin_expect(m.swish, 0)) return c * swish_grad(a);
   return act_pass(a, m) ? c : 0.f;
+}
+template <int V> __device__ __forceinline__ void act_bwd_v(float* c, const float (&a)[V], Act m) {
+  if (__builtin_expect(m.swish, 0)) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) c[e] *= swish_grad(a[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) c[e] = act_pass(a[e], m) ? c[e] : 0.f;
+  }
 }
 
 // Activation layouts (include/atomnas_hip.h).  plain: [M][ld], element (row, c) at row*ld + c.  slab-major (ss > 0): the channel

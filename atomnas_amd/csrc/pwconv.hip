@@ -76,10 +76,8 @@ __device__ __forceinline__ void load_pro(const Operand& o, long row, bool rowval
     VecIO<float, E>::load(o.c1 + k, s);
     VecIO<float, E>::load(o.c2 + k, h);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      float a = v[e] * s[e] + h[e];
-      v[e] = act_apply(a, act_of(o.relu));
-    }
+    for (int e = 0; e < E; ++e) v[e] = v[e] * s[e] + h[e];
+    act_apply_v<E>(v, act_of(o.relu));
   } else if constexpr (MODE == PRO_BNBWD) {
     float x[E], a1[E], a2[E], a3[E];
     VecIO<T, E>::load(reinterpret_cast<const T*>(o.p2) + lay_off(row, k, o.ld2, o.ss2), x);
@@ -113,10 +111,8 @@ __device__ __forceinline__ void load_pro_lds(const Operand& o, long row, bool ro
     VecIO<float, 8>::load(lc1, s);
     VecIO<float, 8>::load(lc2, h);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float a = v[e] * s[e] + h[e];
-      v[e] = act_apply(a, act_of(o.relu));
-    }
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * s[e] + h[e];
+    act_apply_v<8>(v, act_of(o.relu));
   } else if constexpr (MODE == PRO_BNBWD) {
     float x[8], a1[8], a2[8], a3[8];
     VecIO<bf16_t, 8>::load(reinterpret_cast<const bf16_t*>(o.p2) + lay_off(row, k, o.ld2, o.ss2), x);
@@ -192,12 +188,13 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
 #pragma unroll
         for (int i = 0; i < 8; ++i) zv[8 * h8 + i] = tmp[i];
         if (ep.mask) {
+          float a8[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int n = n8 + i;
-            const float a = (n < N) ? tmp[i] * ep.zscale[n] + ep.zshift[n] : 0.f;
-            c[8 * h8 + i] = act_bwd(c[8 * h8 + i], a, act_of(ep.mask));
+            a8[i] = (n < N) ? tmp[i] * ep.zscale[n] + ep.zshift[n] : 0.f;
           }
+          act_bwd_v<8>(&c[8 * h8], a8, act_of(ep.mask));
         }
       }
 #pragma unroll
@@ -416,11 +413,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
           float zs[8], zh[8];
           VecIO<float, 8>::load(ep.zscale + n8, zs);
           VecIO<float, 8>::load(ep.zshift + n8, zh);
+          float a8[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float a = zv[i] * zs[i] + zh[i];
-            c[8 * h8 + i] = act_bwd(c[8 * h8 + i], a, act_of(ep.mask));
-          }
+          for (int i = 0; i < 8; ++i) a8[i] = zv[i] * zs[i] + zh[i];
+          act_bwd_v<8>(&c[8 * h8], a8, act_of(ep.mask));
         }
       }
 #pragma unroll
@@ -621,13 +617,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float a = (float)acur[s][ks].a[e];
-              if constexpr (MODE == PRO_BNRELU) {
-                const float t = a * c1v[e] + c2v[e];
-                v[e] = act_apply(t, act_of(A.relu));
-              } else {
-                v[e] = c1v[e] * a + c2v[e] * (float)acur[s][ks].x[e] + c3v[e];
-              }
+              if constexpr (MODE == PRO_BNRELU) v[e] = a * c1v[e] + c2v[e];
+              else v[e] = c1v[e] * a + c2v[e] * (float)acur[s][ks].x[e] + c3v[e];
             }
+            if constexpr (MODE == PRO_BNRELU) act_apply_v<8>(v, act_of(A.relu));
             af[s] = MM::pack(v);
           }
         }

@@ -5,7 +5,13 @@
 Everything between the barriers is device work issued from Python once, captured with torch.cuda.graph (the HIP kernels
 are launched on the capturing stream through the C ABI, so they become graph nodes) and replayed every iteration.  Values
 that change per iteration (lr, rho, EMA decay) are staged through a 4-float device vector, inputs through static buffers.
-With a process group, the gradient arena is all-reduced by RCCL between two graphs (backward | optimizer).
+
+Data parallelism (utils/distributed.py:131-139, 155-161 of the reference: one blocking all-reduce of all gradients after
+backward): the gradient arena is summed over the ranks with RCCL.  With the nccl backend the collective is issued from INSIDE
+backward, bucket by bucket on a side stream as soon as the blocks that own a bucket have finished (the arena is laid out in
+module order, backward runs it from the end), and is captured into the same hipGraph as the kernels ("graph" mode); the 1/world
+scale rides in the optimizer kernel.  Other backends (gloo in the tests) and a failed capture use one blocking all-reduce between
+two graphs ("host" mode).
 """
 import os
 
@@ -41,6 +47,11 @@ class TrainStep:
         self.topk = self._scal[4:6].view(torch.int32)                  # top-1 / top-5 hits of the last step (common.py:73-79)
         self.loss_vec = torch.zeros(batch_size, dtype=torch.float32, device=dev)   # per-sample CE of the last step
         self._tables_version = -1
+        self._comm = None          # side stream of the bucketed all-reduce
+        self._buckets = []         # (first plan of the bucket, lo, hi) in backward order
+        self._fired = 0
+        self.comm_mode = None      # decided at the first step: "graph" | "host" | None (no collective)
+        self.g_all = None
         self.g_fwd_bwd = self.g_opt = None
         self._version = -1
         self.global_step = 0
@@ -73,6 +84,53 @@ class TrainStep:
         self._world = torch.full((1,), float(max(self.world_size, 1)), dtype=torch.float32, device=mgr.P.device)
         self._ws = torch.empty(4096 + 64 * max(len(w), 1), dtype=torch.float32, device=mgr.P.device)
         self._tables_version = mgr.version
+
+    # ---- gradient all-reduce overlapped with backward
+    def _build_buckets(self, target_floats=4 << 20):
+        """Cuts the gradient arena into ~16 MiB buckets at plan boundaries, from the end (backward order).  A bucket is complete
+        when the plan with the LOWEST offset in it has finished its backward."""
+        plans = sorted((p for p in self.mgr.plans.values() if getattr(p, "nb", 1) != 0), key=lambda p: p.g_lo)   # pruned-away blocks never run
+        self._buckets = []
+        hi = self.mgr.nP
+        acc_lo = None
+        for pl in reversed(plans):
+            acc_lo = pl.g_lo
+            if hi - acc_lo >= target_floats:
+                self._buckets.append((pl, acc_lo, hi))
+                hi = acc_lo
+        if hi > 0:
+            first = plans[0] if plans else None
+            if self._buckets and self._buckets[-1][0] is first:
+                pl, lo, bhi = self._buckets.pop()
+                self._buckets.append((pl, 0, bhi))
+            else:
+                self._buckets.append((first, 0, hi))
+
+    def _on_grad_done(self, pl):
+        if self._fired < len(self._buckets) and self._buckets[self._fired][0] is pl:
+            _, lo, hi = self._buckets[self._fired]
+            self._fired += 1
+            cur = torch.cuda.current_stream()
+            self._comm.wait_stream(cur)
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(self.mgr.G[lo:hi], group=self.pg)
+
+    def _fwd_bwd_overlapped(self):
+        mgr = self.mgr
+        self._fired = 0
+        mgr.grad_done_cb = self._on_grad_done
+        try:
+            self._fwd_bwd()
+        finally:
+            mgr.grad_done_cb = None
+        cur = torch.cuda.current_stream()
+        while self._fired < len(self._buckets):   # plans that took no part in this backward (none in the networks of this path)
+            _, lo, hi = self._buckets[self._fired]
+            self._fired += 1
+            self._comm.wait_stream(cur)
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(mgr.G[lo:hi], group=self.pg)
+        cur.wait_stream(self._comm)
 
     def _fwd_bwd(self):
         """zero_grad -> forward -> label-smoothed CE (mean) -> backward, HIP launches only.  The regularisers do not go through
@@ -120,12 +178,27 @@ class TrainStep:
         mgr.CNT.copy_(keep_c)
         # thread_local: the RCCL watchdog thread of a process group polls events while we capture; in the default "global" mode
         # such a call from another thread invalidates the capture
-        self.g_fwd_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode="thread_local"):
-            self._fwd_bwd()
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
-            self._opt()
+        self.g_all = None
+        if self.comm_mode == "graph":
+            # one graph: kernels, bucketed RCCL all-reduces on the side stream, optimizer tail
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._fwd_bwd_overlapped()
+                    self._opt()
+                self.g_all = g
+            except Exception as e:   # a runtime that cannot capture the collective: fall back to the blocking form
+                import logging
+                logging.warning("capturing the gradient all-reduce failed (%s); using one blocking all-reduce between two graphs", e)
+                torch.cuda.synchronize()
+                self.comm_mode = "host"
+        if self.g_all is None:
+            self.g_fwd_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode="thread_local"):
+                self._fwd_bwd()
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
+                self._opt()
         self._version = mgr.version
 
     # ---- public
@@ -145,7 +218,15 @@ class TrainStep:
         do_reduce = self._wants_reduce() if reduce is None else bool(reduce)
         if mgr.dirty or self._version != mgr.version:
             mgr.ensure()
-            self.g_fwd_bwd = self.g_opt = None
+            self.g_fwd_bwd = self.g_opt = self.g_all = None
+            self._buckets = []
+        if do_reduce and self.comm_mode is None:
+            backend = dist.get_backend(self.pg) if dist.is_initialized() else None
+            overlap_ok = backend == "nccl" and os.environ.get("ATOMNAS_OVERLAP_ALLREDUCE", "1") != "0"
+            self.comm_mode = "graph" if overlap_ok else "host"
+        if do_reduce and self.comm_mode == "graph" and not self._buckets:
+            self._comm = self._comm or torch.cuda.Stream()
+            self._build_buckets()
         h = mgr.hyper_host
         self._tables()
         h[ops.HYP_LR] = float(self.optimizer.param_groups[0]['lr'] if lr is None else lr)
@@ -156,13 +237,25 @@ class TrainStep:
         else:
             h[ops.HYP_EMA_DECAY] = -1.0
         mgr.push_hyper()
+        overlapped = do_reduce and self.comm_mode == "graph"
         if self.use_graph:
-            if self.g_fwd_bwd is None:
+            if self.g_fwd_bwd is None and self.g_all is None:
                 self._capture()
-            self.g_fwd_bwd.replay()
-            if do_reduce:
-                dist.all_reduce(mgr.G, group=self.pg)
-            self.g_opt.replay()
+                overlapped = do_reduce and self.comm_mode == "graph"
+            if overlapped and self.g_all is not None:
+                self.g_all.replay()
+            else:
+                if self.g_fwd_bwd is None:   # captured as one graph earlier, now asked to run without the collective
+                    was, self.comm_mode = self.comm_mode, "host"
+                    self._capture()
+                    self.comm_mode = was
+                self.g_fwd_bwd.replay()
+                if do_reduce:
+                    dist.all_reduce(mgr.G, group=self.pg)
+                self.g_opt.replay()
+        elif overlapped:
+            self._fwd_bwd_overlapped()
+            self._opt()
         else:
             self._fwd_bwd()
             if do_reduce:

@@ -302,6 +302,7 @@ class BlockFunction(torch.autograd.Function):
         N, H, W, _, _ = sv["dims"]
         gx = block_backward(pl, sv, G)
         ctx.sv = None
+        pl.mgr.grad_done(pl)
         return to_4d(gx, N, H, W, pl.inp), None, None
 
 
@@ -401,6 +402,7 @@ class ConvBNFunction(torch.autograd.Function):
         G, _ = to_2d(gout, pl.mgr.compute_dtype)
         gx = convbn_backward(pl, sv, G, ctx.x_needs)
         ctx.sv = None
+        pl.mgr.grad_done(pl)
         N, H, W, _, _ = sv["dims"]
         if gx is None:
             return None, None, None
@@ -490,6 +492,8 @@ class TailFunction(torch.autograd.Function):
         lp, fp, sv = ctx.lp, ctx.fp, ctx.sv
         gx = tail_backward(lp, fp, sv, dlogits)
         ctx.sv = None
+        lp.mgr.grad_done(fp)
+        lp.mgr.grad_done(lp)
         N, H, W = sv["dims"]
         return to_4d(gx, N, H, W, lp.cin), None, None, None, None, None, None, None
 
@@ -527,6 +531,8 @@ class TailLossFunction(torch.autograd.Function):
         lp, fp, sv = ctx.lp, ctx.fp, ctx.sv
         gx = tail_backward(lp, fp, sv, None, dl_padded=ctx.dl)
         ctx.sv = ctx.dl = None
+        lp.mgr.grad_done(fp)
+        lp.mgr.grad_done(lp)
         N, H, W = sv["dims"]
         return (to_4d(gx, N, H, W, lp.cin),) + (None,) * 12
 

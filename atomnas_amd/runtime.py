@@ -71,13 +71,20 @@ class BlockPlan:
     def __init__(self):
         self.valid = False
 
+    def __deepcopy__(self, memo):
+        return None   # plans point into the owner's arenas: a copied module gets its own at its first use (plan_of)
+
 
 class SimplePlan:
-    pass
+    def __deepcopy__(self, memo):
+        return None
 
 
 class ArenaManager:
     """Owns the arenas of one model (attached as model._arena)."""
+
+    def __deepcopy__(self, memo):
+        return None   # copy.deepcopy(model) must not drag the arenas, optimizers and EMA of the source along (common.get_ema_model)
 
     def __init__(self, model):
         self.model = model
@@ -154,6 +161,7 @@ class ArenaManager:
         for name, m in model.named_modules():
             if isinstance(m, mb.InvertedResidualChannels):
                 pl = BlockPlan()
+                pl.g_lo = lp.size
                 pl.name = name
                 pl.module = m
                 nb = len(m.ops)
@@ -169,7 +177,7 @@ class ArenaManager:
                     # an all-pruned block keeps only its (unused) pw_bn; give it ordinary slots
                     sl = bn_slots(pl.oup)
                     self._bind_bn(bind_param, bind_buf, lc, m.pw_bn, sl, 0, pl.oup)
-                    plans.append((m, pl, {}))
+                    pl.g_hi = lp.size; plans.append((m, pl, {}))
                     continue
                 # expanding blocks keep their hidden tensors slab-major (segments = whole 16-channel slabs); the first block of
                 # the network (no expansion: hidden = input, narrow) stays plain with 8-channel padding
@@ -216,7 +224,7 @@ class ArenaManager:
                     o_f = lpf.take(k * k * sp(h))
                     pack_jobs_f.append((so["Wd"][i], o_f, sp(h), k * k, k * k, sp(h), 0, 2))
                     pk["taps"].append((o_f, k * k, sp(h)))
-                plans.append((m, pl, dict(so=so, pk=pk)))
+                pl.g_hi = lp.size; plans.append((m, pl, dict(so=so, pk=pk)))
             elif isinstance(m, mb.InvertedResidualChannelsFused):
                 # Fused block (models/mobilenet_base.py:145-274): ONE expand conv / BN over all `total` hidden channels, Narrow +
                 # depthwise per kernel size, optional SE, ONE projection conv + BN.  The kernels run on the same padded-segment
@@ -224,6 +232,7 @@ class ArenaManager:
                 # weight / BN, projection weight, SE weights) are CONTIGUOUS masters in the arena, as the reference's state_dict
                 # has them, and reach the padded layout through per-segment pack jobs / per-segment finalize launches.
                 pl = BlockPlan()
+                pl.g_lo = lp.size
                 pl.name, pl.module, pl.fused = name, m, True
                 pl.inp, pl.oup, pl.stride, pl.expand = m.input_dim, m.output_dim, m.stride, m.expand
                 pl.res = m.use_res_connect
@@ -290,12 +299,13 @@ class ArenaManager:
                         reg_slots.append(("dense", so[key + "w"], conv_.weight.numel()))
                         bind_param(conv_, "weight", so[key + "w"], tuple(conv_.weight.shape))
                         bind_param(conv_, "bias", so[key + "b"], tuple(conv_.bias.shape))
-                plans.append((m, pl, dict(so=so, pk=pk)))
+                pl.g_hi = lp.size; plans.append((m, pl, dict(so=so, pk=pk)))
             elif isinstance(m, mb.ConvBNReLU) and id(m) not in handled:
                 conv, bn, _ = list(m.children())
                 for sub in m.modules():
                     handled.add(id(sub))
                 pl = SimplePlan()
+                pl.g_lo = lp.size
                 pl.name, pl.module = name, m
                 pl.cin, pl.cout, pl.k, pl.stride, pl.groups = conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.groups
                 kk = conv.kernel_size[0] * conv.kernel_size[1]
@@ -313,10 +323,11 @@ class ArenaManager:
                     pk["taps"] = (o_f, kk, pad8(conv.out_channels))
                 else:
                     raise NotImplementedError("grouped convolution other than depthwise")
-                plans.append((m, pl, dict(so=so, pk=pk)))
+                pl.g_hi = lp.size; plans.append((m, pl, dict(so=so, pk=pk)))
             elif isinstance(m, nn.Linear) and id(m) not in handled:
                 handled.add(id(m))
                 pl = SimplePlan()
+                pl.g_lo = lp.size
                 pl.name, pl.module = name, m
                 pl.cin, pl.cout = m.in_features, m.out_features
                 so = dict(W=lp.take(m.out_features * m.in_features), b=lp.take(pad8(m.out_features)))
@@ -328,7 +339,7 @@ class ArenaManager:
                     bind_param(m, "bias", so["b"], (m.out_features,))
                 pk = {}
                 pk["W"], pk["WT"] = pw_pack(so["W"], m.out_features, m.in_features, m.in_features)
-                plans.append((m, pl, dict(so=so, pk=pk)))
+                pl.g_hi = lp.size; plans.append((m, pl, dict(so=so, pk=pk)))
         # anything else that owns parameters (e.g. SE convs with bias) gets plain slots
         for name, m in model.named_modules():
             if id(m) in handled:
@@ -455,6 +466,15 @@ class ArenaManager:
         self.dirty = False
         self.version += 1
         self.pack()
+
+    # gradient-completion hook: every executor calls grad_done(plan) at the end of its backward; engine.TrainStep uses it to
+    # all-reduce the finished part of the gradient arena while the rest of backward is still running
+    grad_done_cb = None
+
+    def grad_done(self, pl):
+        cb = self.grad_done_cb
+        if cb is not None:
+            cb(pl)
 
     def _bind_bn(self, bind_param, bind_buf, lc, bn, slots, seg, c):
         if bn.affine:

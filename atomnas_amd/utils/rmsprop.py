@@ -68,6 +68,13 @@ class RMSprop(Optimizer):
                 if group['momentum'] > 0:
                     st['momentum_buffer'] = _view(mgr.BUF, off, shape, strides)
 
+    def load_state_dict(self, state_dict):
+        """torch's index-ordered format (what utils/common.py:123-137 saves).  The loaded state tensors are ordinary tensors; they
+        move into the optimizer arenas at the next materialisation."""
+        super().load_state_dict(state_dict)
+        if self._mgr is not None:
+            self._mgr.mark_dirty()
+
     def zero_grad(self, set_to_none=False):
         """Gradients live in one arena: a single memset (the kernels accumulate into it during backward)."""
         mgr = self._mgr or self._manager()

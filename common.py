@@ -116,26 +116,30 @@ def forward_loss(model, criterion, input, target, meter):
 
 
 def get_ema_model(ema, model_wrapper):
-    """A copy of the model carrying the EMA weights (common.py:155-172); the copy gets its own arenas."""
+    """A copy of the model carrying the EMA weights (common.py:155-172).  The copy materialises its own arenas; when the EMA
+    shadows live in the source model's EMA arenas (they do once engine.TrainStep has run) the 799 per-name copies of the reference
+    are TWO arena copies: the shadow arenas have the parameter / statistics arenas' layout by construction."""
     if ema is None:
         return model_wrapper
+    from atomnas_amd import runtime
     src = unwrap_model(model_wrapper)
-    clone = copy.deepcopy(_detached(src))
+    clone = copy.deepcopy(src)   # modules and tensors only: plans and the arena manager are not followed (runtime.py __deepcopy__)
     clone.cuda()
-    table = dict(clone.named_parameters())
-    table.update(dict(clone.named_buffers()))
+    smgr = getattr(src, '_arena', None)
+    cmgr = runtime.manager_of(clone)
+    cmgr.ensure()
     with torch.no_grad():
-        for name in ema.average_names():
-            table[name].copy_(ema.average(name))
+        if (smgr is not None and not smgr.dirty and getattr(ema, '_mgr', None) is smgr and smgr.EMA is not None
+                and cmgr.param_slots == smgr.param_slots and cmgr.buffer_slots == smgr.buffer_slots
+                and set(ema.average_names()) == set(cmgr.param_slots) | set(k for k, v in cmgr.buffer_slots.items() if v[0] == 'S')):
+            cmgr.P.copy_(smgr.EMA)
+            cmgr.S.copy_(smgr.SEMA)
+        else:
+            table = dict(clone.named_parameters())
+            table.update(dict(clone.named_buffers()))
+            for name in ema.average_names():
+                table[name].copy_(ema.average(name))
     return _SingleProcessWrapper(clone)
-
-
-def _detached(model):
-    """Shallow structural copy source for deepcopy: drops arena bookkeeping so that the clone materialises its own."""
-    shadow = copy.copy(model)
-    shadow.__dict__ = dict(model.__dict__)
-    shadow.__dict__.pop('_arena', None)
-    return shadow
 
 
 def profiling(model, use_cuda=True):

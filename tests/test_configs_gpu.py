@@ -251,3 +251,57 @@ def test_topk_counters_match_forward_loss(gpu_lib):
         assert_close("loss", loss, orc.ce_label_smooth(logits.double(), y, 0.1), rtol=1e-5, atol=1e-5)
         crit(logits.cuda(), y.cuda())                    # the counters accumulate until the meter zeroes them
         assert crit.topk_correct.tolist() == [2 * want[0], 2 * want[1]]
+
+
+def test_reference_written_checkpoint_resumes_identically(gpu_lib):
+    """Checkpoint interchange: a checkpoint WRITTEN BY THE REFERENCE (utils/common.py:123-137 -- model
+    state_dict, torch's index-ordered RMSprop state, EMA {info, shadow, param}) is loaded through train.load_checkpoint into freshly
+    built objects, and one more training iteration lands where the reference's own continuation lands (tests/golden/checkpoint_ref.pt,
+    generated by tools/make_golden.py checkpoint)."""
+    sys.path.insert(0, ROOT)
+    import train as T
+    from atomnas_amd import engine
+    from atomnas_amd.models import mobilenet_base as mb
+    from atomnas_amd.models import mobilenet_supernet as ms
+    from atomnas_amd.utils import model_profiling as mp, optim as aopt, prune as aprune, rmsprop
+    from kutil import check_digest
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "checkpoint_ref.pt"), weights_only=False)
+    torch.manual_seed(99)
+    model = ms.Model(**g["kw"])
+    model.apply(mb.init_weights_mnas)
+    model.set_compute_dtype(torch.float32)
+    mp.model_profiling(model, 64, 64, verbose=False)
+    model.cuda().train()
+    wrapper = torch.nn.Module()
+    wrapper.module = model
+    pinfo = aprune.get_bn_to_prune(model, {"bn_prune_filter": "expansion_only_skip_expand1"}, verbose=False)
+    opt = rmsprop.RMSprop(wrapper.parameters(), lr=0.002, alpha=0.9, momentum=0.9, eps=1e-3, eps_inside_sqrt=True)
+    ema = aopt.ExponentialMovingAverage(0.99)
+    for n, p in model.named_parameters():
+        ema.register(n, p)
+    for n, b in model.named_buffers():
+        if "running" in n:
+            ema.register(n, b)
+    last_epoch, best_val = T.load_checkpoint(g["checkpoint"], wrapper, opt, ema)
+    assert last_epoch == 0 and best_val == 0.75
+    assert mb.output_network(model) == g["kwparams"]
+    ts = engine.TrainStep(model, opt, ema, pinfo, weight_decay=1e-3, label_smoothing=0.1, batch_size=6, image_size=64, use_graph=False)
+    ts.global_step = 2
+    step = 2
+    x = (counter_fill(torch.empty(6, 3, 64, 64), 700 + step) * 4).float()
+    y = (torch.arange(6) * 3 + step) % 10
+    ts.set_batch(x.cuda(), y.cuda())
+    ts.step(lr=0.002 * (1 + step), rho=1e-3 * (1 + step))
+    torch.cuda.synchronize()
+    assert abs(ts.loss[0].item() - g["losses"][2]) < 2e-5 * max(1.0, g["losses"][2])
+    sd = model.state_dict()
+    for k, dg in g["after"]["sd"].items():
+        check_digest("sd " + k, sd[k], dg, rtol=2e-5)
+    for n, p in model.named_parameters():
+        check_digest("sq " + n, opt.state[p]["square_avg"], g["after"]["sq"][n], rtol=2e-4)
+        check_digest("buf " + n, opt.state[p]["momentum_buffer"], g["after"]["buf"][n], rtol=2e-4)
+    for k, dg in g["after"]["ema"].items():
+        check_digest("ema " + k, ema.average(k), dg, rtol=2e-5)
+    info = ema.state_dict()["info"]
+    for k, v in g["after"]["ema_info"].items():   # the per-variable counters the reference checkpoints
+        assert info[k]["num_updates"] == v["num_updates"] and abs(info[k]["last_momemtum"] - v["last_momemtum"]) < 1e-6, (k, info[k], v)

@@ -61,6 +61,17 @@ def _worker(rank, world, port, out):
         torch.cuda.synchronize()
         assert all(l == l for l in losses)
         assert float((ts.mgr.P - p0).abs().max()) > 0, "parameters did not move"
+        assert ts.comm_mode == "host"   # gloo: one blocking all-reduce between the two graphs
+        # the reduced gradient arena is the SUM of the per-rank gradients (the 1/world scale rides in the optimizer kernel)
+        ts._fwd_bwd()
+        torch.cuda.synchronize()
+        local = ts.mgr.G.detach().cpu().clone()
+        every = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(every, local)
+        dist.all_reduce(ts.mgr.G)
+        torch.cuda.synchronize()
+        assert not torch.equal(every[0], every[1])
+        assert torch.equal(ts.mgr.G.cpu(), every[0] + every[1]), float((ts.mgr.G.cpu() - every[0] - every[1]).abs().max())
         mine = ts.mgr.P.detach().cpu()
         parts = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
@@ -89,3 +100,49 @@ def test_two_ranks_one_gpu_graph_step(gpu_lib):
             p.terminate()
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert sorted(out.keys()) == list(range(world))
+
+
+def _nccl_worker(port, out):
+    """One rank, RCCL backend, collective forced on: the bucketed all-reduce issued from inside backward on the side stream is
+    captured into the step's hipGraph ("graph" mode).  With a single rank the sum is the identity, so the run must be bit-identical
+    to the same steps without any collective."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      ATOMNAS_FORCE_ALLREDUCE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from trainstep_diag import setup
+        res = []
+        for force in (True, False):
+            model, sd, spec, pinfo, opt, ema, engine = setup(torch.bfloat16, 64)
+            ts = engine.TrainStep(model, opt, ema, pinfo, weight_decay=1e-3, batch_size=8, image_size=64, use_graph=True)
+            g = torch.Generator().manual_seed(5)
+            for step in range(3):
+                ts.set_batch(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 10, (8,), generator=g).cuda())
+                ts.step(lr=0.002, rho=1e-3, reduce=force)
+            torch.cuda.synchronize()
+            if force:
+                assert ts.comm_mode == "graph" and ts.g_all is not None, (ts.comm_mode, ts.g_all)
+                assert len(ts._buckets) >= 1 and ts._fired == len(ts._buckets)
+                lo = sorted(b[1] for b in ts._buckets)
+                assert lo[0] == 0 and sum(b[2] - b[1] for b in ts._buckets) == ts.mgr.nP   # the buckets tile the arena
+            res.append((ts.mgr.P.clone(), ts.mgr.SQ.clone(), ts.loss.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        out["ok"] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_allreduce_is_captured_in_the_step_graph(gpu_lib):
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), out))
+    p.start()
+    p.join(timeout=300)
+    if p.is_alive():
+        p.terminate()
+    assert p.exitcode == 0 and out.get("ok") == 1

@@ -210,3 +210,31 @@ def test_e2e_test_config_resolves_on_cpu(tmp_path):
     assert flags.prune_params.method == "network_slimming" and flags.prune_params.rho == 1e-4
     assert flags.model_kwparams.active_fn == "nn.ReLU" and flags.model_kwparams.batch_norm_momentum == 0.01
     assert flags.resume == "" and flags.optimizer == "rmsprop"
+
+
+def test_init_weights_mnas_reproduces_the_reference_under_a_seed():
+    """SURVEY section 8 row a7 (models/mobilenet_base.py:440-459): conv ~ N(0, sqrt(2/fan_out)) with fan_out = k*k for depthwise,
+    BN (1, 0), classifier ~ U(+-1/sqrt(out_features)), zero bias.  Module construction order and the init calls consume torch's
+    RNG exactly as the reference does, so under the same seed every tensor is IDENTICAL to the reference's (digests generated by
+    tools/make_golden.py checkpoint from the reference itself)."""
+    import math
+    from kutil import check_digest
+    from atomnas_amd.models import mobilenet_base as mb
+    from atomnas_amd.models import mobilenet_supernet as ms
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "checkpoint_ref.pt"), weights_only=False)
+    torch.manual_seed(g["seed"])
+    model = ms.Model(**g["kw"])
+    model.apply(mb.init_weights_mnas)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g["init_digest"].keys())
+    for k, d in g["init_digest"].items():
+        check_digest(k, sd[k], d, rtol=1e-7)
+    # and the rule itself on a large layer (statistical)
+    conv = torch.nn.Conv2d(64, 64, 5, groups=64, bias=False)
+    dense = torch.nn.Conv2d(32, 256, 1, bias=False)
+    fc = torch.nn.Linear(512, 1000)
+    for m in (conv, dense, fc):
+        mb.init_weights_mnas(m)
+    assert abs(float(conv.weight.std()) - math.sqrt(2.0 / 25)) < 0.02
+    assert abs(float(dense.weight.std()) - math.sqrt(2.0 / 256)) < 0.005
+    assert float(fc.weight.abs().max()) <= 1 / math.sqrt(1000) + 1e-7 and float(fc.bias.abs().max()) == 0.0

@@ -282,6 +282,70 @@ def g_full_supernet():
                os.path.join(OUT, "full_supernet_eval.pt"))
 
 
+def g_checkpoint():
+    """A checkpoint WRITTEN BY THE REFERENCE (utils/common.py:123-137 save_status: model / optimizer / ema state_dicts, epoch
+    counters) after two training iterations of the tiny supernet in fp32, plus the reference's own continuation: one more
+    iteration after `load_state_dict` of everything into freshly built objects (train.py:299-317).  Also the initial state of
+    `init_weights_mnas` under a fixed torch seed (models/mobilenet_base.py:440-459)."""
+    torch.manual_seed(123)
+    model = ms.Model(**TINY)
+    model.apply(mb.init_weights_mnas)
+    init_digest = digests(sd_of(model))
+    rprof.model_profiling(model, 64, 64, use_cuda=False, num_forwards=0, verbose=False)
+    flags = {'bn_prune_filter': 'expansion_only_skip_expand1'}
+
+    def build(m):
+        pinfo = rprune.get_bn_to_prune(m, flags, verbose=False)
+        opt = rrms.RMSprop(m.parameters(), lr=0.002, alpha=0.9, momentum=0.9, eps=1e-3, eps_inside_sqrt=True, weight_decay=0)
+        ema = roptim.ExponentialMovingAverage(0.99)
+        for n, p in m.named_parameters():
+            ema.register(n, p)
+        for n, b in m.named_buffers():
+            if 'running_var' in n or 'running_mean' in n:
+                ema.register(n, b)
+        return pinfo, opt, ema
+
+    crit = roptim.CrossEntropyLabelSmooth(10, 0.1, reduction='none')
+
+    def iterate(m, pinfo, opt, ema, step):
+        named = dict(m.named_parameters())
+        x = (counter_fill(torch.empty(6, 3, 64, 64), 700 + step) * 4).float()
+        y = (torch.arange(6) * 3 + step) % 10
+        lr, rho = 0.002 * (1 + step), 1e-3 * (1 + step)
+        for g in opt.param_groups:
+            g['lr'] = lr
+        opt.zero_grad()
+        loss = torch.mean(crit(m(x), y))
+        (loss + roptim.cal_l2_loss(m, 1e-3, 'mnas') + rprune.cal_bn_l1_loss([named[n] for n in pinfo.weight], pinfo.penalty, rho)).backward()
+        opt.step()
+        for n in ema.average_names():
+            src = named[n] if n in named else dict(m.named_buffers())[n]
+            ema(n, src, step + 1)
+        return float(loss)
+
+    model.train()
+    pinfo, opt, ema = build(model)
+    losses = [iterate(model, pinfo, opt, ema, s) for s in range(2)]
+    ckpt = {'model': sd_of(model), 'optimizer': copy.deepcopy(opt.state_dict()), 'ema': copy.deepcopy(ema.state_dict()), 'last_epoch': 0,
+            'best_val': 0.75, 'meters': None}
+    # the reference's own resume into fresh objects, then one more iteration
+    torch.manual_seed(7)
+    model2 = ms.Model(**TINY)
+    rprof.model_profiling(model2, 64, 64, use_cuda=False, num_forwards=0, verbose=False)
+    model2.train()
+    pinfo2, opt2, ema2 = build(model2)
+    model2.load_state_dict(ckpt['model'])
+    opt2.load_state_dict(ckpt['optimizer'])
+    ema2.load_state_dict(ckpt['ema'])
+    losses.append(iterate(model2, pinfo2, opt2, ema2, 2))
+    out = dict(kw=TINY, seed=123, init_digest=init_digest, checkpoint=ckpt, losses=losses, kwparams=mb.output_network(model),
+               after=dict(sd=digests(sd_of(model2)), sq=digests({n: opt2.state[p]['square_avg'] for n, p in model2.named_parameters()}),
+                          buf=digests({n: opt2.state[p]['momentum_buffer'] for n, p in model2.named_parameters()}),
+                          ema=digests({k: ema2.average(k) for k in ema2.average_names()}),
+                          ema_info={k: dict(v) for k, v in list(ema2.state_dict()['info'].items())[:3]}))
+    torch.save(out, os.path.join(OUT, "checkpoint_ref.pt"))
+
+
 def g_fused_se():
     """InvertedResidualChannelsFused (models/mobilenet_base.py:145-274) with Swish and SqueezeAndExcitation (:93-117), as
     AtomNAS+ uses it (apps/eval/eval_se.yml: se_ratio 0.5): forward / backward / eval of three blocks (aligned, ragged, no SE)
@@ -289,7 +353,7 @@ def g_fused_se():
     import models.searched_network as sn
     out = {}
     cfgs = [dict(inp=8, oup=8, stride=1, channels=[16, 16, 16], ks=[3, 5, 7], expand=True, act="nn.Swish", se_ratio=0.5),
-            dict(inp=8, oup=12, stride=2, channels=[12, 20, 7], ks=[3, 5, 7], expand=True, act="nn.Swish", se_ratio=0.5),
+            dict(inp=8, oup=16, stride=2, channels=[12, 20, 7], ks=[3, 5, 7], expand=True, act="nn.Swish", se_ratio=0.5),
             dict(inp=16, oup=16, stride=1, channels=[15, 23, 13], ks=[3, 5, 7], expand=True, act="nn.ReLU", se_ratio=None)]
     for ci, cfg in enumerate(cfgs):
         blk = mb.InvertedResidualChannelsFused(cfg["inp"], cfg["oup"], cfg["stride"], cfg["channels"], cfg["ks"], cfg["expand"],
@@ -345,5 +409,6 @@ if __name__ == "__main__":
     g_tables()
     g_full_supernet()
     g_fused_se()
+    g_checkpoint()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

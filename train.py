@@ -84,29 +84,63 @@ def validate(epoch, model_wrapper, ema, criterion, meters, steps):
     return meters.flush(), eval_wrapper
 
 
+def load_pretrained(path, model_wrapper, ema):
+    """`pretrained:` of the reference (train.py:276-296): EMA dict (if any) and model weights of a checkpoint written by
+    utils/common.py:123-137 (or a bare state_dict), optionally remapped by position onto this model's keys."""
+    FLAGS = cfg.FLAGS
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    if ema and isinstance(ckpt, dict) and ckpt.get('ema'):
+        ema.load_state_dict(ckpt['ema'])
+        ema.to(next(model_wrapper.parameters()).device)
+    if isinstance(ckpt, dict) and 'model' in ckpt:
+        ckpt = ckpt['model']
+    if FLAGS.get('pretrained_model_remap_keys', False):
+        ckpt = {new: ckpt[old] for new, old in zip(model_wrapper.state_dict().keys(), ckpt.keys())}
+    from atomnas_amd.utils.common import unwrap_state_dict
+    target = set(model_wrapper.state_dict().keys())
+    if not any(k in target for k in ckpt):   # saved through the other wrapper form (`module.` prefix present / absent)
+        stripped = unwrap_state_dict(ckpt, verbose=False)
+        ckpt = stripped if any(k in target for k in stripped) else {'module.' + k: v for k, v in ckpt.items()}
+    model_wrapper.load_state_dict(ckpt)
+    logging.info('Loaded model {}.'.format(path))
+
+
+def load_checkpoint(ckpt, model_wrapper, optimizer, ema):
+    """`resume:` of the reference (train.py:299-317) on a checkpoint dict in the reference's format (utils/common.py:123-137:
+    'model', 'optimizer' -- torch's index-ordered optimizer state_dict --, 'ema' = {info, shadow, param}, 'last_epoch',
+    'best_val').  Checkpoints written here carry the optimizer's parameter ORDER by name as well: after a shrink it differs from
+    the model's (re-keyed variables are appended, utils/rmsprop.py:134-165) and torch maps saved state by position."""
+    target = set(model_wrapper.state_dict().keys())
+    sd = ckpt['model']
+    if not any(k in target for k in sd):
+        sd = ({k[len('module.'):]: v for k, v in sd.items()} if all(k.startswith('module.') for k in sd)
+              else {'module.' + k: v for k, v in sd.items()})
+    model_wrapper.load_state_dict(sd)
+    names = ckpt.get('optimizer_param_names')
+    if names:
+        table = dict(model_wrapper.named_parameters())
+        optimizer.param_groups[0]['params'] = [table[n] for n in names]
+    optimizer.load_state_dict(ckpt['optimizer'])
+    if ema:
+        ema.load_state_dict(ckpt['ema'])
+        ema.to(next(model_wrapper.parameters()).device)
+    return ckpt['last_epoch'], ckpt['best_val']
+
+
 def train_val_test():
     import common as mc
     FLAGS = cfg.FLAGS
     model, model_wrapper = mc.get_model()
     ema = mc.setup_ema(model)
+    if FLAGS.get('pretrained', None):
+        load_pretrained(FLAGS.pretrained, model_wrapper, ema)
     optimizer = optim.get_optimizer(model_wrapper, FLAGS)
     lr_scheduler = optim.get_lr_scheduler(optimizer, FLAGS)
     last_epoch, best_val = -1, 1.0
     FLAGS._global_step = 0
     if FLAGS.resume:
-        ckpt = torch.load(os.path.join(FLAGS.resume, 'latest_checkpoint.pt'), map_location='cpu')
-        model_wrapper.load_state_dict(ckpt['model'])
-        # torch maps saved optimizer state to parameters by POSITION; after a shrink the optimizer's order differs from the
-        # model's (re-keyed variables are appended, utils/rmsprop.py:134-165), so the saved order is restored by name first
-        names = ckpt.get('optimizer_param_names')
-        if names:
-            table = dict(model_wrapper.named_parameters())
-            optimizer.param_groups[0]['params'] = [table[n] for n in names]
-        optimizer.load_state_dict(ckpt['optimizer'])
-        if ema:
-            ema.load_state_dict(ckpt['ema'])
-        last_epoch = ckpt['last_epoch']
-        best_val = ckpt['best_val']
+        ckpt = torch.load(os.path.join(FLAGS.resume, 'latest_checkpoint.pt'), map_location='cpu', weights_only=False)
+        last_epoch, best_val = load_checkpoint(ckpt, model_wrapper, optimizer, ema)
         lr_scheduler.last_epoch = (last_epoch + 1) * FLAGS._steps_per_epoch
         FLAGS._global_step = (last_epoch + 1) * FLAGS._steps_per_epoch
     assert FLAGS.profiling, '`m.macs` is used for calculating penalty'
