@@ -63,8 +63,10 @@ def build(model_name, dtype, batch, seed):
 
 
 def algorithmic_bytes(tag_name, tag, itemsize):
-    """Algorithmic bytes of one launch from its shape tag (DESIGN.md 'roofline accounting'):
-    depthwise fwd reads X writes Y; depthwise bwd reads X and dY, writes dX; gemm_nt reads A writes C; gemm_tn reads U, V."""
+    """Algorithmic bytes of one launch from its shape tag, so that the sums over a step are SURVEY.md section 8(d)'s figures:
+    depthwise (3|X| + 2|Y|): forward reads X writes Y, backward reads X and dY, writes dX;
+    pointwise (3 MK + 2 MN) per layer: forward reads A writes C (MK + MN); backward reads dC and A, writes dA (MN + 2 MK), split
+    as input-gradient GEMM = dC + dA (its own MK + MN) and weight-gradient GEMM = the one extra read of A."""
     f = {k: int(v) for k, v in re.findall(r"([A-Za-z]+)(\d+)", tag)}   # "M802816 N24 K432 pro1 st1", "N256 H56 C144 k7 s1", ...
     if tag_name.startswith("atomnas_dwconv"):
         N, H, C, k, s = f["N"], f["H"], f["C"], f["k"], f["s"]
@@ -74,7 +76,10 @@ def algorithmic_bytes(tag_name, tag, itemsize):
     if tag_name == "atomnas_pw_gemm_nt":
         return (f["M"] * f["K"] + f["M"] * f["N"]) * itemsize
     if tag_name == "atomnas_pw_gemm_tn":
-        return (f["M"] * f["NU"] + f["M"] * f["NV"]) * itemsize
+        # "pro<u>,<v>": the operand with the BatchNorm-backward prologue (2) is the gradient dC; the other one is the layer input A
+        m = re.search(r"pro(\d),(\d)", tag)
+        a_is_u = m is not None and m.group(2) == "2"
+        return f["M"] * (f["NU"] if a_is_u else f["NV"]) * itemsize
     return 0
 
 
@@ -125,8 +130,6 @@ def cpu_baseline(model_name, seconds_budget=20.0):
     from atomnas_amd.models import mobilenet_supernet as ms
     hp = configs.SEARCH_HPARAMS
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
     torch.manual_seed(1995)
     model = ms.Model(**configs.model_kwparams(model_name), input_size=hp['image_size'])   # structure + init only (CPU tensors)
     model.apply(mb.init_weights_mnas)
@@ -139,7 +142,19 @@ def cpu_baseline(model_name, seconds_budget=20.0):
     h = dict(lr=0.016, rho=1e-4, weight_decay=hp['weight_decay'], wd_method='mnas', label_smoothing=hp['label_smoothing'],
              alpha=hp['alpha'], eps=hp['epsilon'], momentum=hp['momentum'], ema_decay=0.9999)
     opt_state, ema = {}, collections.OrderedDict((k, v.clone()) for k, v in sd.items() if v.is_floating_point())
-    orc.train_step(sd, spec, opt_state, ema, x, y, h, names, pen)   # warm-up
+    # thread count: torch's CPU kernels do not scale to all cores of a large host at this size; one timed step per candidate
+    # (64 threads / half / all cores), the fastest is used for the sample
+    best = None
+    for threads in sorted(set(t for t in (min(cores, 64), cores // 2, cores) if t >= 1)):
+        torch.set_num_threads(threads)
+        orc.train_step(sd, spec, opt_state, ema, x, y, h, names, pen)   # warm-up at this thread count
+        t0 = time.perf_counter()
+        orc.train_step(sd, spec, opt_state, ema, x, y, h, names, pen)
+        el = time.perf_counter() - t0
+        if best is None or el < best[0]:
+            best = (el, threads)
+    threads = best[1]
+    torch.set_num_threads(threads)
     n, t0 = 0, time.perf_counter()
     while True:
         orc.train_step(sd, spec, opt_state, ema, x, y, h, names, pen)
@@ -148,7 +163,7 @@ def cpu_baseline(model_name, seconds_budget=20.0):
         if n >= 3 and (dt > seconds_budget or n >= 10):
             break
     return dict(value=round(bs * n / dt, 2), unit="images/sec", cores=threads, kind="port",
-                sample="oracle/atomnas_oracle.train_step (fp32 torch CPU restatement of train.py:165-236), %s, bs %d, %d timed steps after 1 warm-up, %d threads of %d host cores" % (model_name, bs, n, threads, cores))
+                sample="oracle/atomnas_oracle.train_step (fp32 torch CPU restatement of train.py:165-236), %s, bs %d, %d timed steps after warm-up, %d threads (fastest of 64 / half / all %d host cores, one probe step each)" % (model_name, bs, n, threads, cores))
 
 
 def main():
