@@ -296,12 +296,12 @@ def test_reference_written_checkpoint_resumes_identically(gpu_lib):
     assert abs(ts.loss[0].item() - g["losses"][2]) < 2e-5 * max(1.0, g["losses"][2])
     sd = model.state_dict()
     for k, dg in g["after"]["sd"].items():
-        check_digest("sd " + k, sd[k], dg, rtol=2e-5)
+        check_digest("sd " + k, sd[k], dg, rtol=2e-5, atol=1e-6)
     for n, p in model.named_parameters():
-        check_digest("sq " + n, opt.state[p]["square_avg"], g["after"]["sq"][n], rtol=2e-4)
-        check_digest("buf " + n, opt.state[p]["momentum_buffer"], g["after"]["buf"][n], rtol=2e-4)
+        check_digest("sq " + n, opt.state[p]["square_avg"], g["after"]["sq"][n], rtol=5e-4, atol=1e-6)
+        check_digest("buf " + n, opt.state[p]["momentum_buffer"], g["after"]["buf"][n], rtol=5e-4, atol=2e-5)
     for k, dg in g["after"]["ema"].items():
-        check_digest("ema " + k, ema.average(k), dg, rtol=2e-5)
+        check_digest("ema " + k, ema.average(k), dg, rtol=2e-5, atol=1e-6)
     info = ema.state_dict()["info"]
     for k, v in g["after"]["ema_info"].items():   # the per-variable counters the reference checkpoints
         assert info[k]["num_updates"] == v["num_updates"] and abs(info[k]["last_momemtum"] - v["last_momemtum"]) < 1e-6, (k, info[k], v)

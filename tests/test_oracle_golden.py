@@ -214,3 +214,32 @@ def test_fused_se_blocks_and_searched_network():
     from atomnas_amd.utils import model_profiling as mp
     mp.model_profiling(model, 64, 64, verbose=False)
     assert model.n_macs == n["n_macs"]
+
+
+def test_resume_from_reference_checkpoint():
+    """The reference's checkpoint (utils/common.py:123-137) carries everything one more iteration needs: the oracle resumed from
+    tests/golden/checkpoint_ref.pt lands on the reference's own continuation (train.py:299-317).  Also guards the fixture itself:
+    the stored optimizer state must be the state BEFORE the continuation (torch's load_state_dict keeps the tensors it is given)."""
+    g = load("checkpoint_ref.pt")
+    ck, kw = g["checkpoint"], g["kw"]
+    sd = collections.OrderedDict((k, v.clone().double() if v.is_floating_point() else v.clone()) for k, v in ck["model"].items())
+    spec = _spec_of(kw)
+    names, pen, _ = orc.prune_penalties(spec, kw["input_size"])
+    pnames = [k for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    assert len(pnames) == len(ck["optimizer"]["state"])
+    opt_state = {k: dict(square_avg=ck["optimizer"]["state"][i]["square_avg"].clone().double(),
+                         momentum_buffer=ck["optimizer"]["state"][i]["momentum_buffer"].clone().double()) for i, k in enumerate(pnames)}
+    ema = collections.OrderedDict((k, v.clone().double()) for k, v in ck["ema"]["shadow"].items())
+    step = 2
+    x = (counter_fill(torch.empty(6, 3, 64, 64), 700 + step) * 4).double()
+    y = (torch.arange(6) * 3 + step) % 10
+    r = orc.train_step(sd, spec, opt_state, ema, x, y, dict(lr=0.002 * (1 + step), rho=1e-3 * (1 + step), weight_decay=1e-3, wd_method="mnas",
+                       label_smoothing=0.1, alpha=0.9, eps=1e-3, momentum=0.9, ema_decay=orc.ema_decay(0.99, step + 1)), names, pen)
+    assert abs(r["loss"] - g["losses"][2]) < 2e-5
+    for k, dg in g["after"]["sd"].items():
+        check_digest("sd " + k, sd[k], dg, rtol=2e-5, atol=1e-6)
+    for k in pnames:
+        check_digest("sq " + k, opt_state[k]["square_avg"], g["after"]["sq"][k], rtol=5e-4, atol=1e-6)   # the reference ran in fp32: g / sqrt(sq + eps) amplifies its rounding
+        check_digest("buf " + k, opt_state[k]["momentum_buffer"], g["after"]["buf"][k], rtol=5e-4, atol=2e-5)
+    for k, dg in g["after"]["ema"].items():
+        check_digest("ema " + k, ema[k], dg, rtol=2e-5, atol=1e-6)

@@ -328,6 +328,9 @@ def g_checkpoint():
     losses = [iterate(model, pinfo, opt, ema, s) for s in range(2)]
     ckpt = {'model': sd_of(model), 'optimizer': copy.deepcopy(opt.state_dict()), 'ema': copy.deepcopy(ema.state_dict()), 'last_epoch': 0,
             'best_val': 0.75, 'meters': None}
+    # torch's Optimizer.load_state_dict (and the reference's EMA.load_state_dict) keep the tensors they are handed, so the
+    # continuation below would advance `ckpt` in place: what goes into the fixture is a snapshot taken before the resume
+    ckpt_saved = copy.deepcopy(ckpt)
     # the reference's own resume into fresh objects, then one more iteration
     torch.manual_seed(7)
     model2 = ms.Model(**TINY)
@@ -338,7 +341,7 @@ def g_checkpoint():
     opt2.load_state_dict(ckpt['optimizer'])
     ema2.load_state_dict(ckpt['ema'])
     losses.append(iterate(model2, pinfo2, opt2, ema2, 2))
-    out = dict(kw=TINY, seed=123, init_digest=init_digest, checkpoint=ckpt, losses=losses, kwparams=mb.output_network(model),
+    out = dict(kw=TINY, seed=123, init_digest=init_digest, checkpoint=ckpt_saved, losses=losses, kwparams=mb.output_network(model),
                after=dict(sd=digests(sd_of(model2)), sq=digests({n: opt2.state[p]['square_avg'] for n, p in model2.named_parameters()}),
                           buf=digests({n: opt2.state[p]['momentum_buffer'] for n, p in model2.named_parameters()}),
                           ema=digests({k: ema2.average(k) for k in ema2.average_names()}),
