@@ -39,6 +39,7 @@ SIGNATURES = {
     "atomnas_fused_rmsprop_ema": [vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, i32, f64, vp, vp, vp],
     "atomnas_vec_sum": [vp, i32, f32, vp, vp],
     "atomnas_ema_update": [vp, vp, i64, vp, vp],
+    "atomnas_scale_by": [vp, i64, vp, i32, vp],
     "atomnas_reg_grad": [vp, vp, vp, i32, i32, vp, vp, vp],
     "atomnas_reg_value": [vp, vp, i32, i32, vp, f32, vp, vp, vp],
     "atomnas_pack_weights": [vp, vp, vp, i32, i32, vp],

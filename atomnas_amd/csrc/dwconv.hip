@@ -38,6 +38,9 @@
 #ifndef DW_SMALL_CB7
 #define DW_SMALL_CB7 32   // slab width of the k = 7 backward on 7x7 maps (64 needs more than 256 registers: 98 accumulators + prefetch)
 #endif
+#ifndef DW_BWD_MINB5
+#define DW_BWD_MINB5 2   // experiment: minimum resident workgroups per CU the k <= 5 backward instances are compiled for
+#endif
 #ifndef DW_RING
 #define DW_RING 1  // 1 = tiles are walked column-major and the LDS operand tile is a ring over rows: a tile below the previous one
                    // loads only its new rows (the (K-1)/S halo rows stay); 0 = every tile loads its whole haloed window
@@ -130,6 +133,7 @@ struct DwGeom {
   int LH, LW, RP;         // LDS operand tile: rows, cols, row pitch (floats)
   int nworkers;           // workgroups per slab (persistent loop over tiles)
   int nslabs;             // channel slabs
+  int xcd;                // 1: XCD-aware workgroup decode (plain layout), 0: plain order (slab-major layout)
 };
 
 static inline int lds_pitch(int lw, int cb) {
@@ -159,11 +163,13 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 
   const int tid = threadIdx.x;
   constexpr int C2 = CB / 2, CG = CB / 8;
-  // Workgroup b runs on XCD b % 8 (private L2 each).  The slabs that share 128-byte lines of a pixel (64 channels) must
-  // hit the same L2 at about the same time, or every line is fetched from HBM once per slab: consecutive workgroups of
-  // one XCD take the slabs of one worker (= one tile sequence).
+  // Workgroup b runs on XCD b % 8 (private L2 each).  PLAIN layout (g.xcd = 1): the slabs that share 128-byte lines of a pixel
+  // (64 channels) must hit the same L2 at about the same time, or every line is fetched from HBM once per slab: consecutive
+  // workgroups of one XCD take the slabs of one worker (= one tile sequence).  SLAB-MAJOR layout (g.xcd = 0): slabs are disjoint
+  // memory, nothing to share -- plain order, which spreads any number of workgroups evenly over the XCDs.
   const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;
-  const int slab = b_local % g.nslabs, worker = (b_local / g.nslabs) * 8 + b_xcd;
+  const int slab = g.xcd ? b_local % g.nslabs : (int)(blockIdx.x % g.nslabs);
+  const int worker = g.xcd ? (b_local / g.nslabs) * 8 + b_xcd : (int)(blockIdx.x / g.nslabs);
   if (worker >= g.nworkers) return;
   const int c_base = slab * CB;
   const int cpad = (g.C + 7) & ~7;
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
 // per (t, kx) that is a compile-time fact (tile and strip origins are even), per ky it is uniform for a row.
 template <typename T, int K, int S, int SW, int CB, int TM, int AM>   // TM: largest tile edge (14, or 7 for the 7x7 maps); AM as forward
 // (launch bounds for 3 resident workgroups, i.e. <= 168 VGPRs, make k = 5 spill 136 bytes and run 2.3x slower: measured, dropped)
-__global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, long gss, const T* __restrict__ yraw, int ldyr,
+__global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd(const T* __restrict__ gup, int ldg, long gss, const T* __restrict__ yraw, int ldyr,
                                                     long yrss, const float* __restrict__ c1, const float* __restrict__ c2p,
                                                     const float* __restrict__ c3, const T* __restrict__ x, int ldx, long xss,
                                                     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -419,8 +425,9 @@ __global__ __launch_bounds__(256, 2) void k_dwconv_bwd(const T* __restrict__ gup
 
   const int tid = threadIdx.x;
   constexpr int C2 = CB / 2, CG = CB / 8;
-  const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;   // XCD-aware decode, see k_dwconv_fwd
-  const int slab = b_local % g.nslabs, worker = (b_local / g.nslabs) * 8 + b_xcd;
+  const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;   // XCD-aware decode for the plain layout, see k_dwconv_fwd
+  const int slab = g.xcd ? b_local % g.nslabs : (int)(blockIdx.x % g.nslabs);
+  const int worker = g.xcd ? (b_local / g.nslabs) * 8 + b_xcd : (int)(blockIdx.x / g.nslabs);
   if (worker >= g.nworkers) return;
   const int c_base = slab * CB;
   const int cpad = (g.C + 7) & ~7;
@@ -779,22 +786,35 @@ static void pick_tiles(DwGeom& g, int rows, int cols, int sw, int cb, int even) 
   g.tiles_x = (cols + g.TW - 1) / g.TW;
 }
 
-// Persistent grid: exactly as many workgroups as are resident at once (a partial second round of workgroups costs up to 2x).
-static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap, long max_workers) {
+// Persistent grid: exactly as many workgroups as are resident at once (a partial second round of workgroups costs up to 2x:
+// a workgroup that does not fit waits for a whole worker lifetime).  Workgroup b runs on XCD b % 8, so what has to fit is the
+// PER-XCD count.  With the XCD-aware decode (plain layout) worker w lives on XCD w % 8: ceil(workers / 8) * nslabs workgroups on
+// (CUs / 8) * per_cu slots, i.e. whole multiples of 8 workers.  (Round 2 found workers = total_slots / nslabs here, e.g. 17
+// workers x 30 slabs at 14x14x480: XCD 0 got 3 x 30 = 90 workgroups for 64 slots and the kernel ran two rounds; fixing it took
+// the depthwise kernels from 25.4 to 20.7 ms per step.)  In plain order (slab-major layout) any count <= total slots is level.
+static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap, long max_workers, bool xcd_decode) {
   const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > cap) per_cu = cap;
-  long want = ((long)num_cus() * per_cu) / nslabs;
+  static const int level_env = getenv("ATOMNAS_DW_XCD_LEVEL") ? atoi(getenv("ATOMNAS_DW_XCD_LEVEL")) : 2;   // A/B: 0 round-1 rule, 1 aligned
+  const bool aligned = level_env == 1 || (level_env == 2 && xcd_decode);
+  g.xcd = (level_env == 2 && !xcd_decode) ? 0 : 1;
+  const long slots_xcd = (long)(num_cus() / 8) * per_cu;
+  long want = aligned ? (slots_xcd / nslabs) * 8 : ((long)num_cus() * per_cu) / nslabs;
+  if (want < 8) want = ((long)num_cus() * per_cu) / nslabs;   // more slabs than slots of an XCD: several rounds either way
   static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: force long tile walks
   if (max_env > 0 && want > max_env) want = max_env;
   if (max_workers > 0 && want > max_workers) want = max_workers;   // every worker owns one partial row (statistics, weight gradient)
   if (want > ntiles) want = ntiles;
+  if (aligned && want > 8) want = want / 8 * 8;
   if (want < 1) want = 1;
   g.nworkers = (int)want;
   g.nslabs = nslabs;
 }
-// grid for the XCD-aware decode (worker w lives on XCD w % 8): whole worker groups per XCD; surplus workgroups exit at once
-static inline unsigned dw_grid(const DwGeom& g) { return (unsigned)((g.nworkers + 7) / 8 * 8 * g.nslabs); }
+// grid: XCD-aware decode = whole worker groups per XCD (surplus workgroups exit at once); plain order = workers x slabs
+static inline unsigned dw_grid(const DwGeom& g) {
+  return g.xcd ? (unsigned)((g.nworkers + 7) / 8 * 8 * g.nslabs) : (unsigned)(g.nworkers * g.nslabs);
+}
 
 template <typename T, int K, int S>
 static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y,
@@ -808,12 +828,12 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   const int sw = 7;
   static const int cb_env = getenv("ATOMNAS_DW_FWD_CB") ? atoi(getenv("ATOMNAS_DW_FWD_CB")) : 0;
   // default 16; deviations measured in situ on the supernet's own shapes (bs 256 step, tools/bringup.py DETAIL=1 +
-  // tools/cmpdetail.py): 8-channel slabs for the stride-2 layers with few channels per pixel, 32 for 28x28x240 and C <= 32
+  // tools/cmpdetail.py, re-done after the XCD-level fix of set_workers): 8-channel slabs for the stride-2 layers with few channels
+  // per pixel, 32 for C <= 32
   int cb_rule = 16;
   if (S == 2 && C <= 96) cb_rule = 8;
   else if (S == 2 && K >= 5 && H <= 56) cb_rule = 8;
   else if (S == 1 && C <= 32) cb_rule = 32;
-  else if (S == 1 && H == 28 && K <= 5) cb_rule = 32;
   const int cb = slab_width((g.Wo <= 7 && g.Ho <= 7) ? 64 : (cb_env ? cb_env : cb_rule), cpad);
   pick_tiles(g, g.Ho, g.Wo, sw, cb, 0);
   ATOMNAS_REQUIRE(cb <= 32 || (g.TH <= 7 && g.TW <= 7), "dwconv_fwd: internal tile configuration error");
@@ -829,7 +849,7 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   {                                                                                                                      \
     auto kern = (relu == ACT_RELU6) ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, ACT_RELU6>                                    \
                                     : (relu == ACT_SWISH ? k_dwconv_fwd<T, K, S, 7, CBV, TMV, ACT_SWISH> : k_dwconv_fwd<T, K, S, 7, CBV, TMV, 0>);                                                                           \
-    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, stats ? stat_rows : 0);                                      \
+    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, stats ? stat_rows : 0, xss == 0);                                      \
     dim3 grid(dw_grid(g));                                                                                      \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)x, ldx, xss, sc, sh, relu, w, ldw, (T*)y, ldy, yss, stats, stat_ld, stat_rows, g); \
   }
@@ -856,11 +876,10 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
   // measured (tools/dwbench.py): 32-channel slabs win for stride 2 and for 7x7 maps with k <= 5, 16-channel slabs elsewhere
   // (k = 7 with 32 channels spills its 98 weight-gradient accumulators)
   static const int cb_env = getenv("ATOMNAS_DW_BWD_CB") ? atoi(getenv("ATOMNAS_DW_BWD_CB")) : 0;
-  // in-situ deviations (same sweep as the forward): 28x28 and 14x14 maps with k <= 5 prefer 32 (k = 3 at 14x14 does not),
-  // the 56x56 stride-2 layer prefers 16
+  // in-situ deviations (same sweep as the forward, re-done after the XCD-level fix of set_workers): k = 5 at 28x28 and 14x14
+  // prefers 32
   int cb_rule = (S == 2 || (H <= 7 && W <= 7 && K <= 5)) ? 32 : 16;
-  if (S == 2 && H == 56) cb_rule = 16;
-  else if (S == 1 && H == 28 && K <= 5) cb_rule = 32;
+  if (S == 1 && H == 28 && K == 5) cb_rule = 32;
   else if (S == 1 && H == 14 && K == 5) cb_rule = 32;
   // 7x7 maps: the whole image is one tile of 7 rows x 1 strip, so only wide slabs fill the 256 threads (64 channels: 224 work
   // items; 16 channels: 56).  The prefetch registers are sized for the 7-pixel tile there (template parameter TM).
@@ -886,7 +905,7 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
   {                                                                                                                       \
     auto kern = (relu == ACT_RELU6) ? k_dwconv_bwd<T, K, S, SW, CBV, TMV, ACT_RELU6>                                   \
                                     : (relu == ACT_SWISH ? k_dwconv_bwd<T, K, S, SW, CBV, TMV, ACT_SWISH> : k_dwconv_bwd<T, K, S, SW, CBV, TMV, 0>);                                                                           \
-    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, (stats || dw) ? part_rows : 0);                               \
+    set_workers(g, nslabs, resident_per_cu(kern, 256, lds), cap, (stats || dw) ? part_rows : 0, xss == 0 || gss == 0);                               \
     dim3 grid(dw_grid(g));                                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, gss, (const T*)yraw, ldyr, yrss, c1, c2, c3, (const T*)x, \
                        ldx, xss, sc, sh, relu, w, ldw, (T*)h, ldh, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g); \

@@ -76,6 +76,12 @@ __global__ __launch_bounds__(256) void k_ema(float* __restrict__ shadow, const f
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) shadow[i] = shadow[i] * d + (1.0f - d) * x[i];
 }
 
+// x *= hyper[idx]  (the BN running statistics summed over the ranks -> their average: hyper[HYP_GRAD_SCALE] = 1 / world)
+__global__ __launch_bounds__(256) void k_scale_by(float* __restrict__ x, long n, const float* __restrict__ hyper, int idx) {
+  const float f = hyper[idx];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= f;
+}
+
 // Weight packing jobs.  src is fp32 in the parameter arena with logical shape [rows][cols] (row pitch src_ld).
 //   mode 0 (PW):   dst[r*dst_ld + c_off + c] = src[r][c]            (storage T)   -> gemm_nt weight  [N][K]
 //   mode 1 (PW_T): dst[(c_off + c)*dst_ld + r] = src[r][c]          (storage T)   -> gemm_nt weight of the transposed product
@@ -132,6 +138,14 @@ extern "C" int atomnas_ema_update(float* shadow, const float* x, long n, const f
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_ema, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shadow, x, n, hyper);
   return check_launch("ema_update");
+}
+
+extern "C" int atomnas_scale_by(float* x, long n, const float* hyper, int idx, void* stream) {
+  ATOMNAS_REQUIRE(x && hyper && n > 0 && idx >= 0 && idx < 4, "scale_by: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_scale_by, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, hyper, idx);
+  return check_launch("scale_by");
 }
 
 extern "C" int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream) {

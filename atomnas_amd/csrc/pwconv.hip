@@ -940,6 +940,10 @@ static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, co
     long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;                                                       \
     if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
     if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;                                                             \
+    /* whole row ranges per chunk: ceil(mtiles / tpi) * nchunks items must still fit in one round (784 row tiles x 54   \
+       chunks on 2048 waves gave 38 ranges = 2052 items: one workgroup too many, i.e. a second round) */                \
+    const long max_ranges = waves / nchunks > 0 ? waves / nchunks : 1;                                                  \
+    if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges; \
     const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;                                      \
     dim3 grid((unsigned)((items + 3) / 4)), block(256);                                                                 \
     hipLaunchKernelGGL(kern, grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);                 \
@@ -984,7 +988,11 @@ template <typename T>
 static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     // column-stationary form when the output is the wide operand
-    if (K <= 192 && N >= 2 * K && N >= 96 && M >= 1024) {
+    static const int cs_maxk = getenv("ATOMNAS_NT_CS_MAXK") ? atoi(getenv("ATOMNAS_NT_CS_MAXK")) : 192;
+    // with the BatchNorm-backward prologue the 6-k-step instance (K = 192: 7x7 maps) needs 256 + 49 registers, one wave per SIMD;
+    // the LDS-weights kernel is 10 % faster there (in situ, M = 12544, N = 3456 / 1728), without a prologue it is 50 % slower
+    static const int cs_maxk_pro = getenv("ATOMNAS_NT_CS_MAXK_PRO") ? atoi(getenv("ATOMNAS_NT_CS_MAXK_PRO")) : 96;
+    if (K <= (mode == PRO_BNBWD ? cs_maxk_pro : cs_maxk) && K <= 192 && N >= 2 * K && N >= 96 && M >= 1024) {
       const int ksteps = (K + 31) / 32;
       if (ksteps == 1) launch_nt_cs<1>(mode, A, Wp, ldw, ep, M, N, K, st);
       else if (ksteps == 2) launch_nt_cs<2>(mode, A, Wp, ldw, ep, M, N, K, st);
@@ -995,7 +1003,8 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
   }
   if constexpr (sizeof(T) == 2) {
     static const int ws_env = getenv("ATOMNAS_NT_WS") ? atoi(getenv("ATOMNAS_NT_WS")) : 1;
-    if (ws_env && K > 192 && M >= 4096) return launch_nt_ws(mode, A, Wp, ldw, ep, M, N, K, st);
+    static const int ws_mink = getenv("ATOMNAS_NT_WS_MINK") ? atoi(getenv("ATOMNAS_NT_WS_MINK")) : 97;
+    if (ws_env && K >= ws_mink && M >= 4096) return launch_nt_ws(mode, A, Wp, ldw, ep, M, N, K, st);
   }
   constexpr int KS = 4 * Mma<T>::EPL;
   const int Kpad = (K + KS - 1) / KS * KS;

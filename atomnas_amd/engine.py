@@ -26,12 +26,15 @@ from .utils import prune as aprune
 class TrainStep:
 
     def __init__(self, model, optimizer, ema=None, prune_info=None, weight_decay=1e-5, wd_method='mnas', label_smoothing=0.1,
-                 batch_size=256, image_size=224, use_graph=True, process_group=None, world_size=1):
+                 batch_size=256, image_size=224, use_graph=True, process_group=None, world_size=1, allreduce_bn=False):
         self.model, self.optimizer, self.ema, self.prune_info = model, optimizer, ema, prune_info
         self.weight_decay, self.wd_method = weight_decay, wd_method
         self.use_graph = use_graph
         self.world_size = world_size
         self.pg = process_group
+        # average the BN running statistics over the ranks every step, BEFORE their EMA (the reference's order: optimizer.step,
+        # allreduce_bn, ema -- train.py:213-226); the optimizer does not read them, so they travel with the gradient collectives
+        self.allreduce_bn = bool(allreduce_bn)
         dev = next(model.parameters()).device
         self.mgr = runtime.manager_of(model)
         self.mgr.attach_optimizer(optimizer)
@@ -115,6 +118,12 @@ class TrainStep:
             with torch.cuda.stream(self._comm):
                 dist.all_reduce(self.mgr.G[lo:hi], group=self.pg)
 
+    def _reduce_bn(self):
+        """utils/distributed.py:164-169 on the statistics arena: one collective + one launch (x 1/world from the hyper vector)"""
+        mgr = self.mgr
+        dist.all_reduce(mgr.S, group=self.pg)
+        ops.scale_by(mgr.S, mgr.nS, mgr.hyper, ops.HYP_GRAD_SCALE)
+
     def _fwd_bwd_overlapped(self):
         mgr = self.mgr
         self._fired = 0
@@ -130,6 +139,10 @@ class TrainStep:
             self._comm.wait_stream(cur)
             with torch.cuda.stream(self._comm):
                 dist.all_reduce(mgr.G[lo:hi], group=self.pg)
+        if self.allreduce_bn:
+            self._comm.wait_stream(cur)
+            with torch.cuda.stream(self._comm):
+                self._reduce_bn()
         cur.wait_stream(self._comm)
 
     def _fwd_bwd(self):
@@ -252,6 +265,8 @@ class TrainStep:
                 self.g_fwd_bwd.replay()
                 if do_reduce:
                     dist.all_reduce(mgr.G, group=self.pg)
+                    if self.allreduce_bn:
+                        self._reduce_bn()
                 self.g_opt.replay()
         elif overlapped:
             self._fwd_bwd_overlapped()
@@ -260,6 +275,8 @@ class TrainStep:
             self._fwd_bwd()
             if do_reduce:
                 dist.all_reduce(mgr.G, group=self.pg)
+                if self.allreduce_bn:
+                    self._reduce_bn()
             self._opt()
         self.global_step += 1
         if self.ema is not None:   # bookkeeping the reference keeps per variable (utils/optim.py:62-63); checkpointed

@@ -5,6 +5,8 @@ Nothing here computes on the host; a missing library or a failed launch raises.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -35,9 +37,12 @@ def _rows(stats, stat_rows):
     return stats.shape[0]
 
 
+_TN_WS_FLOATS = int(os.environ.get("ATOMNAS_TN_WS_MB", "32")) << 18   # experiment switch: cap of the partial-output scratch
+
+
 def tn_workspace(nu, nv, dev):
     """scratch for the per-row-chunk partial outputs of atomnas_pw_gemm_tn (at most 32 MiB)"""
-    return torch.empty(max(2 * nu * nv, min(256 * nu * nv, 8 << 20)), dtype=torch.float32, device=dev)
+    return torch.empty(max(2 * nu * nv, min(256 * nu * nv, _TN_WS_FLOATS)), dtype=torch.float32, device=dev)
 
 
 
@@ -277,6 +282,10 @@ def vec_sum(x, n, scale, out):
 
 def ema_update(shadow, x, n, hyper):
     call("atomnas_ema_update", _p(shadow), _p(x), n, _p(hyper), _stream())
+
+
+def scale_by(x, n, hyper, idx):
+    call("atomnas_scale_by", _p(x), n, _p(hyper), idx, _stream())
 
 
 def pack_weights(arena, packbuf, jobs_dev, njobs, dtype):

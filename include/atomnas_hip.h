@@ -178,6 +178,9 @@ int atomnas_fused_rmsprop_ema(float* p, const float* g, float* sq, float* buf, f
 /* out[0] = scale * sum_i x[i], fixed summation order: mean of the per-sample losses (train.py:178-180) */
 int atomnas_vec_sum(const float* x, int n, float scale, float* out, void* stream);
 int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper, void* stream);
+/* x[i] *= hyper[idx]: the BN running statistics summed over the ranks become their average (utils/distributed.py:164-169,
+ * allreduce_bn; hyper[3] = 1 / world) */
+int atomnas_scale_by(float* x, long n, const float* hyper, int idx, void* stream);
 /* regularisers as gradient contributions / values over a job table {long off; int count; float coef;}:
  *   cal_l2_loss (utils/optim.py:210-249): g += wd*p, value 0.5*wd*sum p^2;  cal_bn_l1_loss (utils/prune.py:161-167):
  *   g += rho*penalty*sign(gamma), value rho*penalty*sum|gamma|.  mult_ptr / grad_out_ptr: optional device scalars. */

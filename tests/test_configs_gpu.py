@@ -294,14 +294,33 @@ def test_reference_written_checkpoint_resumes_identically(gpu_lib):
     ts.step(lr=0.002 * (1 + step), rho=1e-3 * (1 + step))
     torch.cuda.synchronize()
     assert abs(ts.loss[0].item() - g["losses"][2]) < 2e-5 * max(1.0, g["losses"][2])
+    # Tolerances (tools/ckpt_diag.py, GPU): against the fp64 oracle the HIP fp32 step and the reference's own fp32 arithmetic are
+    # equally far off (median 2e-6 of the update, up to 3e-3 where the update is a few ulps of the parameter: gamma ~ 1 moving by
+    # 2e-5, BN biases in front of another BN moving by rounding noise).  So: element-wise on the first 512 elements of every tensor,
+    # relative to the size of the reference's UPDATE plus a few ulps of the value; digests of the whole tensors with a loose bound.
     sd = model.state_dict()
-    for k, dg in g["after"]["sd"].items():
-        check_digest("sd " + k, sd[k], dg, rtol=2e-5, atol=1e-6)
-    for n, p in model.named_parameters():
-        check_digest("sq " + n, opt.state[p]["square_avg"], g["after"]["sq"][n], rtol=5e-4, atol=1e-6)
-        check_digest("buf " + n, opt.state[p]["momentum_buffer"], g["after"]["buf"][n], rtol=5e-4, atol=2e-5)
-    for k, dg in g["after"]["ema"].items():
-        check_digest("ema " + k, ema.average(k), dg, rtol=2e-5, atol=1e-6)
+    head = g["after_head"]
+    ck = g["checkpoint"]
+
+    def close(name, got, want, old, rel, ulps):
+        got, want = got.detach().double().cpu().flatten()[:512], want.double()
+        upd = float((want - old.double().flatten()[:512]).abs().max()) if old is not None else float(want.abs().max())
+        tol = rel * upd + ulps * 6e-8 * max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        assert err <= tol, (name, err, tol, upd)
+    pnames = [n for n, _ in model.named_parameters()]
+    for k, want in head["sd"].items():
+        if want.is_floating_point():
+            close("sd " + k, sd[k], want, ck["model"][k], 4e-3, 8)
+        else:
+            assert torch.equal(sd[k].cpu().flatten()[:512], want), k
+        check_digest("sd " + k, sd[k], g["after"]["sd"][k], rtol=2e-4, atol=1e-5)
+    for i, (n, p) in enumerate(model.named_parameters()):
+        st0 = ck["optimizer"]["state"][i]
+        close("sq " + n, opt.state[p]["square_avg"], head["sq"][n], None, 2e-3, 1e-5)   # floor 6e-13: squares of gradients that are rounding noise
+        close("buf " + n, opt.state[p]["momentum_buffer"], head["buf"][n], st0["momentum_buffer"] * 0.9, 4e-3, 16)
+    for k, want in head["ema"].items():
+        close("ema " + k, ema.average(k), want, ck["ema"]["shadow"][k], 4e-3, 8)
     info = ema.state_dict()["info"]
     for k, v in g["after"]["ema_info"].items():   # the per-variable counters the reference checkpoints
         assert info[k]["num_updates"] == v["num_updates"] and abs(info[k]["last_momemtum"] - v["last_momemtum"]) < 1e-6, (k, info[k], v)

@@ -50,6 +50,9 @@ def _worker(rank, world, port, out):
         ema = aopt.ExponentialMovingAverage(0.99)
         for n, p in model.named_parameters():
             ema.register(n, p)
+        for n, b in model.named_buffers():
+            if "running" in n:
+                ema.register(n, b)
         ts = engine.TrainStep(model, opt, ema, pinfo, batch_size=8, image_size=64, use_graph=True, world_size=world)
         g = torch.Generator().manual_seed(100 + rank)   # every rank its own batch
         ts.set_batch(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 10, (8,), generator=g).cuda())
@@ -80,6 +83,26 @@ def _worker(rank, world, port, out):
         both = [torch.zeros_like(lo) for _ in range(world)]
         dist.all_gather(both, lo)
         assert not torch.equal(both[0], both[1]), "ranks were supposed to see different batches"
+        # allreduce_bn (utils/distributed.py:164-169, train.py:213-226): the running statistics are averaged over the ranks
+        # BEFORE their EMA, so the shadows of the statistics are rank-identical too
+        from atomnas_amd import ops
+
+        def gathered(t):
+            mine_ = t.detach().cpu().clone()
+            allr = [torch.zeros_like(mine_) for _ in range(world)]
+            dist.all_gather(allr, mine_)
+            return allr
+        s_before = gathered(ts.mgr.S)
+        assert not torch.equal(s_before[0], s_before[1]), "per-rank BN statistics expected before allreduce_bn"
+        ts.allreduce_bn = True
+        sema0 = ts.mgr.SEMA.detach().clone()
+        ts.step(lr=0.003, rho=1e-4)
+        torch.cuda.synchronize()
+        s_after = gathered(ts.mgr.S)
+        assert torch.equal(s_after[0], s_after[1]), "allreduce_bn left rank-local statistics"
+        d = torch.tensor(float(ts.mgr.hyper_host[ops.HYP_EMA_DECAY]), dtype=torch.float32)
+        want = sema0.cpu() * d + (1.0 - d) * s_after[0]
+        assert torch.allclose(ts.mgr.SEMA.cpu(), want, rtol=1e-6, atol=1e-7), float((ts.mgr.SEMA.cpu() - want).abs().max())
         out[rank] = 1
     finally:
         dist.destroy_process_group()

@@ -345,7 +345,13 @@ def g_checkpoint():
                after=dict(sd=digests(sd_of(model2)), sq=digests({n: opt2.state[p]['square_avg'] for n, p in model2.named_parameters()}),
                           buf=digests({n: opt2.state[p]['momentum_buffer'] for n, p in model2.named_parameters()}),
                           ema=digests({k: ema2.average(k) for k in ema2.average_names()}),
-                          ema_info={k: dict(v) for k, v in list(ema2.state_dict()['info'].items())[:3]}))
+                          ema_info={k: dict(v) for k, v in list(ema2.state_dict()['info'].items())[:3]}),
+               # the first 512 elements of every tensor as well: the GPU test measures errors relative to the size of the UPDATE
+               # (a digest of the new value cannot: gamma ~ 1 moves by 1e-5, a BN bias in front of another BN by 1e-8)
+               after_head=dict(sd={k: v.flatten()[:512].clone() for k, v in sd_of(model2).items()},
+                               sq={n: opt2.state[p]['square_avg'].flatten()[:512].clone() for n, p in model2.named_parameters()},
+                               buf={n: opt2.state[p]['momentum_buffer'].flatten()[:512].clone() for n, p in model2.named_parameters()},
+                               ema={k: ema2.average(k).flatten()[:512].clone() for k in ema2.average_names()}))
     torch.save(out, os.path.join(OUT, "checkpoint_ref.pt"))
 
 

@@ -150,7 +150,8 @@ def train_val_test():
     step = engine.TrainStep(model, optimizer, ema, FLAGS._bn_to_prune, weight_decay=FLAGS.weight_decay,
                             wd_method=FLAGS.weight_decay_method, label_smoothing=FLAGS.label_smoothing,
                             batch_size=FLAGS.per_gpu_batch_size, image_size=FLAGS.image_size,
-                            world_size=udist.get_world_size_fallback())
+                            world_size=udist.get_world_size_fallback(),
+                            allreduce_bn=bool(FLAGS.use_distributed and FLAGS.get('allreduce_bn', False)))
     val_criterion = optim.CrossEntropyLabelSmooth(FLAGS.model_kwparams['num_classes'], 0.0, reduction='none')
     val_meters = mc.get_meters('val')
     steps_per_epoch = FLAGS.get('max_steps_per_epoch', None) or FLAGS._steps_per_epoch
@@ -163,9 +164,7 @@ def train_val_test():
             step.set_batch(x, y)
             step.global_step = FLAGS._global_step
             step.step(lr=optimizer.param_groups[0]['lr'], rho=rho_scheduler(FLAGS._global_step))
-            lr_scheduler.step()
-            if FLAGS.use_distributed and FLAGS.allreduce_bn:
-                udist.allreduce_bn(model)
+            lr_scheduler.step()   # (allreduce_bn, when configured, happens inside the step: before the EMA, as in the reference)
             FLAGS._global_step += 1
             seen += x.shape[0]
             if FLAGS._global_step % FLAGS.log_interval == 0 and udist.is_master():
