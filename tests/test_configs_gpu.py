@@ -302,10 +302,10 @@ def test_reference_written_checkpoint_resumes_identically(gpu_lib):
     head = g["after_head"]
     ck = g["checkpoint"]
 
-    def close(name, got, want, old, rel, ulps):
+    def close(name, got, want, old, rel, ulps, floor=0.0):
         got, want = got.detach().double().cpu().flatten()[:512], want.double()
         upd = float((want - old.double().flatten()[:512]).abs().max()) if old is not None else float(want.abs().max())
-        tol = rel * upd + ulps * 6e-8 * max(1.0, float(want.abs().max()))
+        tol = rel * upd + ulps * 6e-8 * max(1.0, float(want.abs().max())) + floor
         err = float((got - want).abs().max())
         assert err <= tol, (name, err, tol, upd)
     pnames = [n for n, _ in model.named_parameters()]
@@ -318,7 +318,9 @@ def test_reference_written_checkpoint_resumes_identically(gpu_lib):
     for i, (n, p) in enumerate(model.named_parameters()):
         st0 = ck["optimizer"]["state"][i]
         close("sq " + n, opt.state[p]["square_avg"], head["sq"][n], None, 2e-3, 1e-5)   # floor 6e-13: squares of gradients that are rounding noise
-        close("buf " + n, opt.state[p]["momentum_buffer"], head["buf"][n], st0["momentum_buffer"] * 0.9, 4e-3, 16)
+        # floor: a gradient that is exactly zero in real arithmetic (BN bias in front of another BN) is ~5e-7 of rounding noise in
+        # either implementation, and enters the buffer divided by sqrt(eps) = 0.03
+        close("buf " + n, opt.state[p]["momentum_buffer"], head["buf"][n], st0["momentum_buffer"] * 0.9, 4e-3, 16, floor=5e-5)
     for k, want in head["ema"].items():
         close("ema " + k, ema.average(k), want, ck["ema"]["shadow"][k], 4e-3, 8)
     info = ema.state_dict()["info"]

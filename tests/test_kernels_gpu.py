@@ -247,7 +247,9 @@ def _slab(t2d, C):
 @pytest.mark.parametrize("N,C,H,W", [(3, 48, 15, 15), (2, 144, 28, 28), (2, 16, 44, 37)])
 def test_dwconv_slab_layout_is_bit_identical_to_plain(gpu_lib, k, stride, N, C, H, W):
     """The hidden tensors of a block are slab-major ([C/16][M][16], include/atomnas_hip.h).  The layout changes addresses only:
-    same work decomposition, same arithmetic order -> every output bit equals the plain-layout result."""
+    same arithmetic per element -> every output bit equals the plain-layout result.  The per-channel sums (statistics, weight
+    gradient) group their partials by worker, and the number of workers depends on the layout (plain: whole groups per XCD), so
+    those agree to summation-order rounding."""
     ops = _ops()
     from atomnas_amd.ops import Slab
     dtype = torch.bfloat16
@@ -271,9 +273,13 @@ def test_dwconv_slab_layout_is_bit_identical_to_plain(gpu_lib, k, stride, N, C, 
         ops.dwconv_bwd(wrap(gb), wrap(yb_), cvec(c1), cvec(c2), cvec(c3), wrap(xb), cvec(sc), cvec(sh), True, taps(w), h, dw, st2, C,
                        N, H, W, C, k, stride)
         torch.cuda.synchronize()
-        res.append((y.to_plain()[:, :C] if slab else y[:, :C], st, h.to_plain()[:, :C] if slab else h[:, :C], dw, st2))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+        res.append((y.to_plain()[:, :C] if slab else y[:, :C], h.to_plain()[:, :C] if slab else h[:, :C],
+                    st.view(64, 2, -1).sum(0), dw, st2.view(64, 2, -1).sum(0)))
+    for i, (a, b) in enumerate(zip(*res)):
+        if i < 2:
+            assert torch.equal(a, b)
+        else:
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max())), (i, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("M,N,K", [(2000, 432, 24), (5000, 80, 1440), (333, 40, 139), (4100, 96, 576)])
