@@ -649,6 +649,194 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
   if (do_stats) nt_flush_stats(ep, s_stat, WROWS, nc0, N, rs, R, tid);
 }
 
+// ------------------------------------------------------------------------------------------------ fused expand backward
+// Backward of the expand 1x1 convolution (ConvBNReLU(inp, hid, 1), models/mobilenet_base.py:316-320) for the early stages, where
+// inp is 16..48 and the hidden tensors are the whole cost: the input gradient dX = dE * We and the weight gradient dWe = dE^T x
+// both need dE = c1*h + c2*Eraw + c3 (the BatchNorm backward of the two hidden streams h and Eraw).  As two GEMMs (gemm_nt with
+// the BNBWD prologue + gemm_tn) the two streams are read twice; here they are read ONCE:
+//   * k_gemm_nt_ws's structure for dX: a workgroup owns 64-row blocks, streams h / Eraw from HBM straight into MFMA B fragments
+//     (prologue in registers), the weights of a 64-channel chunk come from LDS;
+//   * the same fragments are written transposed into LDS ([channel][row], double-buffered) and, one chunk later, multiplied with
+//     the block's x^T (staged once per row block): R[inp][64 channels] += x^T dE, accumulated in registers over the workgroup's
+//     rows for ALL chunks (NCH x UT accumulator tiles per wave: the chunk loop is unrolled so that their indices are static);
+//   * per-workgroup partials of R in the caller's workspace, summed in workgroup order by reduce_parts (bit-reproducible).
+#ifndef XB_MINB2_LIMIT
+#define XB_MINB2_LIMIT 64   // accumulator registers (4 * UT * NCH) up to which the kernel is compiled for two workgroups per CU
+#endif
+constexpr int XB_DP = 64 + 8;   // transposed LDS pitch (elements): rows of the block + pad; 144 bytes, 16-byte aligned rows
+
+template <int UT, int NCH>
+__global__ __launch_bounds__(256, 2) void k_expand_bwd(Operand A, const bf16_t* __restrict__ Wp, int ldw, int wrows, const bf16_t* __restrict__ x,
+                                                    int ldx, Epilogue ep, float* __restrict__ ws, long M, int N, int K) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  constexpr int WROWS = 64;
+  constexpr int WBUF = WROWS * WS_WP;
+  constexpr int WPASS = WROWS * 8 / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_xb[];
+  T* s_w = reinterpret_cast<T*>(smem_xb);                      // [2][64][WS_WP] weights of a chunk, rows permuted (k_gemm_nt_ws)
+  float* s_c = reinterpret_cast<float*>(s_w + 2 * WBUF);       // [2][3][WS_KC] BatchNorm-backward coefficients of a chunk
+  T* s_d = reinterpret_cast<T*>(s_c + 2 * 3 * WS_KC);          // [2][64 channels][XB_DP] dE of a chunk, transposed
+  T* s_x = s_d + 2 * 64 * XB_DP;                               // [16*UT][XB_DP] x of the row block, transposed
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int nchunk = (K + WS_KC - 1) / WS_KC;
+  const int K8 = (K + 7) & ~7;
+  const long rblocks = (M + 63) / 64;
+
+  const int sseg = tid & 7;
+  int srow_g[WPASS], srow_l[WPASS];
+#pragma unroll
+  for (int p = 0; p < WPASS; ++p) {
+    const int r = (tid + 256 * p) >> 3;
+    const int n = r & 63;
+    srow_g[p] = r;
+    srow_l[p] = ((n >> 2) & 3) * 16 + (((n >> 4) << 2) | (n & 3));
+  }
+  bf16x8 wreg[WPASS];
+  f32x4 creg = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage_load = [&](int c) {
+    const int k = c * WS_KC + sseg * 8;
+#pragma unroll
+    for (int p = 0; p < WPASS; ++p) {
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+      wreg[p] = z;
+      if (k < ldw && srow_g[p] < wrows) wreg[p] = *reinterpret_cast<const bf16x8*>(Wp + (long)srow_g[p] * ldw + k);
+    }
+    if (tid < 3 * 16) {
+      const int v = tid >> 4, kk = c * WS_KC + (tid & 15) * 4;
+      const float* src = (v == 0) ? A.c1 : (v == 1 ? A.c2 : A.c3);
+      creg = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kk < K8) creg = *reinterpret_cast<const f32x4*>(src + kk);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < WPASS; ++p) *reinterpret_cast<bf16x8*>(s_w + buf * WBUF + srow_l[p] * WS_WP + sseg * 8) = wreg[p];
+    if (tid < 3 * 16) *reinterpret_cast<f32x4*>(s_c + buf * 3 * WS_KC + (tid >> 4) * WS_KC + (tid & 15) * 4) = creg;
+  };
+
+  f32x4 racc[NCH][UT];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < UT; ++t) racc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int rs = blockIdx.x, R = gridDim.x;
+  for (long rb = rs; rb < rblocks; rb += R) {
+    const long row = rb * 64 + wave * 16 + j;
+    const bool rowvalid = row < M;
+    // x of the block, transposed: piece = (row r, 8 channels cg); channels >= N and rows >= M are zero
+    for (int idx = tid; idx < 64 * 2 * UT; idx += 256) {
+      const int r = idx & 63, cg = idx >> 6;
+      const long xr = rb * 64 + r;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+      if (xr < M && cg * 8 < ((N + 7) & ~7)) v = *reinterpret_cast<const bf16x8*>(x + xr * ldx + cg * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_x[(cg * 8 + e) * XB_DP + r] = (cg * 8 + e < N) ? v[e] : (bf16_t)0.f;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    WsRaw<PRO_BNBWD> anx[2], acur[2];
+    auto load_a = [&](int c) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int k = c * WS_KC + ks * 32 + 8 * q;
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+        anx[ks].a = z;
+        anx[ks].x = z;
+        if (rowvalid && k < K) {
+          anx[ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row, k, A.ld1, A.ss1));
+          anx[ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row, k, A.ld2, A.ss2));
+        }
+      }
+    };
+    // weight-gradient product of chunk cc (its transposed dE tile is complete: a barrier has passed since it was written)
+    auto wgrad = [&](int cc, f32x4 (&ra)[UT]) {
+      const T* d = s_d + (cc & 1) * 64 * XB_DP;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const bf16x8 db = *reinterpret_cast<const bf16x8*>(d + (16 * wave + j) * XB_DP + 32 * k2 + 8 * q);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          const bf16x8 xa = *reinterpret_cast<const bf16x8*>(s_x + (16 * t + j) * XB_DP + 32 * k2 + 8 * q);
+          ra[t] = MM::mma(xa, db, ra[t]);
+        }
+      }
+    };
+
+    stage_load(0);
+    load_a(0);
+    stage_store(0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c <= NCH; ++c) {
+      if (c > 0 && c <= nchunk) wgrad(c - 1, racc[c > 0 ? c - 1 : 0]);
+      if (c < NCH && c < nchunk) {
+        const int buf = c & 1;
+        acur[0] = anx[0];
+        acur[1] = anx[1];
+        if (c + 1 < nchunk) {
+          stage_load(c + 1);
+          load_a(c + 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int kl = ks * 32 + 8 * q;
+          float c1v[8], c2v[8], c3v[8];
+          const float* cb = s_c + buf * 3 * WS_KC;
+          VecIO<float, 8>::load(cb + kl, c1v);
+          VecIO<float, 8>::load(cb + WS_KC + kl, c2v);
+          VecIO<float, 8>::load(cb + 2 * WS_KC + kl, c3v);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = rowvalid ? c1v[e] * (float)acur[ks].a[e] + c2v[e] * (float)acur[ks].x[e] + c3v[e] : 0.f;
+          const bf16x8 af = MM::pack(v);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(s_w + buf * WBUF + (t * 16 + j) * WS_WP + kl);
+            acc[t] = MM::mma(wf, af, acc[t]);
+          }
+          T* d = s_d + buf * 64 * XB_DP + kl * XB_DP + wave * 16 + j;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e * XB_DP] = af[e];
+        }
+        if (c + 1 < nchunk) stage_store(buf ^ 1);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);   // the chunk loop is unrolled for static accumulator indices only: no motion across chunks
+      }
+    }
+    nt_epilogue<T>(ep, acc, row, rowvalid, 16 * q, N, false, nullptr, 0, 0, j);
+    __syncthreads();   // s_x and the last dE tile are free for the next row block
+  }
+
+  // this workgroup's partial of R = x^T dE: element (x channel uc, hidden channel vc) at ws[(rs * N + uc) * K + vc]
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int vc = c * 64 + 16 * wave + j;
+    if (c < nchunk && vc < K) {
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int uc = 16 * t + 4 * q + r;
+          if (uc < N) ws[((long)rs * N + uc) * K + vc] = racc[c][t][r];
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ gemm_tn
 // Out[i*si + j*sj] += sum_m U[m][i] * V[m][j].  A block owns up to 16*UT_MAX columns of U (all four waves use all of
 // them) and 64 columns of V (one 16-column tile per wave) and a contiguous chunk of rows; 32-row slabs of both operands
@@ -1127,6 +1315,29 @@ static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Opera
   return 0;
 }
 
+// fused expand backward: supported shapes and launch
+static inline int xb_nch(int HT) {
+  const int n = (HT + WS_KC - 1) / WS_KC;
+  return n <= 5 ? 5 : (n <= 7 ? 7 : (n <= 12 ? 12 : 0));
+}
+template <int UT, int NCH>
+static int launch_expand_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, int wrows, const bf16_t* x, int ldx, const Epilogue& ep, float* dwe,
+                                 float* ws, long ws_floats, long M, int N, int K, hipStream_t st) {
+  auto kern = k_expand_bwd<UT, NCH>;
+  const size_t lds = (size_t)2 * 64 * WS_WP * sizeof(bf16_t) + 2 * 3 * WS_KC * sizeof(float) + (size_t)2 * 64 * XB_DP * sizeof(bf16_t) +
+                     (size_t)16 * UT * XB_DP * sizeof(bf16_t);
+  const long rblocks = (M + 63) / 64;
+  long R = (long)num_cus() * resident_per_cu(kern, 256, lds);   // one round of resident workgroups
+  if (R > rblocks) R = rblocks;
+  const long max_parts = ws_floats / ((long)N * K);   // every workgroup owns one partial of the weight gradient
+  if (R > max_parts) R = max_parts;
+  ATOMNAS_REQUIRE(R >= 1, "expand_bwd: workspace too small for one partial (%ld floats)", (long)N * K);
+  hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(256), lds, st, A, W, ldw, wrows, x, ldx, ep, ws, M, N, K);
+  if (int rc = check_launch("expand_bwd")) return rc;
+  // dWe[n * inp + k] += sum over workgroups of R[k][n], in workgroup order
+  return reduce_parts(ws, (long)N * K, (int)R, (long)N * K, dwe, K, 1, N, st);
+}
+
 static int check_operand(const char* who, const Operand& o, int mode, int C) {
   ATOMNAS_REQUIRE(o.p1 != nullptr && (o.ss1 > 0 || (o.ld1 >= C && o.ld1 % 8 == 0)), "%s: bad main stream (ld=%d, C=%d)", who, o.ld1, C);
   if (mode == PRO_BNRELU) ATOMNAS_REQUIRE(o.c1 && o.c2, "%s: BNRELU prologue needs scale and shift", who);
@@ -1198,3 +1409,40 @@ extern "C" int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, long u_ss,
   if (dtype == DT_F32) return launch_tn<float>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, ws, ws_floats, st);
   return launch_tn<bf16_t>(u_mode, U, NU, v_mode, V, NV, out, si, sj, M, ws, ws_floats, st);
 }
+
+// 1 when atomnas_expand_bwd has an instance for this shape: bf16 storage, and the weight-gradient accumulators (4 registers per
+// (16 input channels, 64 hidden channels) tile) leave room for two workgroups per CU.  Measured in situ (bs 256): 24 -> 432 and
+// 16 -> 288 run 1.7x / 1.4x faster than the two GEMMs; 40 -> 720 (144 accumulator registers, one workgroup per CU, spills) was
+// 1.7x SLOWER and has no instance.
+extern "C" int atomnas_expand_bwd_supported(int inp, int hid, int dtype) {
+  if (dtype != DT_BF16 || inp < 1 || inp > 48 || hid < 1 || xb_nch(hid) == 0) return 0;
+  return 4 * ((inp + 15) / 16) * xb_nch(hid) <= XB_MINB2_LIMIT;
+}
+
+// Backward of the expand convolution (models/mobilenet_base.py:316-320), both gradients from ONE pass over the hidden streams:
+//   dE = c1*h + c2*e + c3 (BatchNorm backward of h = dL/d act(bn(E)) masked, e = E raw);  gx[M, inp] = dE * We (+ add);
+//   dwe[n * inp + k] += sum_m dE[m][n] * x[m][k].   wt: We^T packed by atomnas_pack_weights ([inp padded to 64][ldw >= hid]).
+extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde, long e_ss, const float* c1, const float* c2,
+                                  const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx,
+                                  int ldgx, float* dwe, float* ws, long ws_floats, long M, int inp, int hid, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(atomnas_expand_bwd_supported(inp, hid, dtype), "expand_bwd: unsupported shape inp=%d hid=%d dtype=%d", inp, hid, dtype);
+  ATOMNAS_REQUIRE(h && e && c1 && c2 && c3 && x && wt && gx && dwe && ws && M > 0, "expand_bwd: bad arguments");
+  ATOMNAS_REQUIRE((h_ss >= M * 16 || (h_ss == 0 && ldh >= hid && ldh % 8 == 0)) && (e_ss >= M * 16 || (e_ss == 0 && lde >= hid && lde % 8 == 0)),
+                  "expand_bwd: bad hidden layout");
+  ATOMNAS_REQUIRE(ldx >= inp && ldx % 8 == 0 && ldgx >= inp && ldgx % 8 == 0 && (!add || (ldadd >= inp && ldadd % 8 == 0)), "expand_bwd: bad pitch");
+  ATOMNAS_REQUIRE(ldw >= (hid + 31) / 32 * 32 && ldw % 8 == 0, "expand_bwd: packed weight pitch %d too small for hid=%d", ldw, hid);
+  Operand A{h, ldh, e, lde, h_ss, e_ss, c1, c2, c3, 0};
+  Epilogue ep{gx, ldgx, 0, add, ldadd, nullptr, 0, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, STAT_NONE, 0};
+  hipStream_t st = (hipStream_t)stream;
+  const int ut = (inp + 15) / 16, nch = xb_nch(hid);
+  const bf16_t* W = (const bf16_t*)wt;
+  const bf16_t* X = (const bf16_t*)x;
+  const int wrows = (inp + 63) / 64 * 64;
+#define XB_CASE(UTV, NCHV) \
+  if (ut == UTV && nch == NCHV) return launch_expand_bwd_cfg<UTV, NCHV>(A, W, ldw, wrows, X, ldx, ep, dwe, ws, ws_floats, M, inp, hid, st);
+  XB_CASE(1, 5) XB_CASE(1, 7) XB_CASE(1, 12) XB_CASE(2, 5) XB_CASE(2, 7) XB_CASE(3, 5)
+#undef XB_CASE
+  set_error("expand_bwd: no instance for inp=%d hid=%d", inp, hid);
+  return 1;
+}
+

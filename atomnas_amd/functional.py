@@ -138,6 +138,7 @@ def bn_backward_coeffs(bn, st, stats2, count, dev):
 
 
 # ---------------------------------------------------------------------------------------------- atomic block
+_FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))   # experiment switch (same-box A/B of the two layouts)
 
 
@@ -269,6 +270,11 @@ def block_backward(pl, sv, G):
             h = h + G
         return h
     e1, e2, e3 = bn_backward_coeffs(pl.bne, bE, st2E, M, dev)
+    Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
+    if pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and ops.expand_bwd_supported(pl.inp, HT, T):
+        # early stages (16 -> 288, 24 -> 432): input and weight gradient of the expand convolution from ONE pass over h and E
+        ops.expand_bwd(h, E, e1, e2, e3, x2d, pl.WeT_pack, G if pl.res else None, Gx, pl.We_grad, M, pl.inp, HT)
+        return Gx
     # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k]); the
     # fused block's expand weight is one contiguous [total, inp] tensor: one launch per branch segment
     we_jobs = ([(sg, hh, pl.We_grad[stt * pl.inp:]) for sg, stt, hh in zip(pl.seg, pl.start, pl.hid)] if pl.fused
@@ -277,7 +283,6 @@ def block_backward(pl, sv, G):
         ops.gemm_tn(x2d, pl.inp, _seg(h, sg), nv, out, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=_seg(E, sg), vc1=e1[sg:], vc2=e2[sg:],
                     vc3=e3[sg:])
     # expand input gradient (+ residual branch)
-    Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
     ops.gemm_nt(h, pl.WeT_pack, Gx, M, pl.inp, HT, a_mode=PRO_BNBWD, a2=E, ac1=e1, ac2=e2, ac3=e3, add=G if pl.res else None)
     return Gx
 

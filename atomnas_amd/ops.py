@@ -188,6 +188,27 @@ def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc
          NV, _p(out), si, sj, M, _p(ws), ws.numel() if ws is not None else 0, dt_code(u.dtype), _stream())
 
 
+def expand_bwd_supported(inp, hid, dtype):
+    return bool(_lib.load().atomnas_expand_bwd_supported(int(inp), int(hid), dt_code(dtype)))
+
+
+def expand_bwd_workspace(inp, hid, dev):
+    """scratch for the per-workgroup partials of the expand weight gradient: one per resident workgroup (at most 1024), 64 MiB cap"""
+    return torch.empty(min(1024 * inp * hid, 16 << 20), dtype=torch.float32, device=dev)
+
+
+def expand_bwd(h, e, c1, c2, c3, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None):
+    """Fused backward of the expand convolution (include/atomnas_hip.h): gx = dE * We (+ add), dwe += dE^T x, dE = c1*h + c2*e + c3."""
+    _chk_cuda(h, e, x, gx, dwe, wt_pack)
+    wt, ldw = wt_pack, wt_pack.stride(0)
+    if ws is None:
+        ws = expand_bwd_workspace(inp, hid, x.device)
+    if _lib.PROFILE is not None:
+        _lib.profile_tag("M%d N%d K%d fusedbwd" % (M, inp, hid))
+    call("atomnas_expand_bwd", _p(h), _ld(h), _ss(h), _p(e), _ld(e), _ss(e), _p(c1), _p(c2), _p(c3), _p(x), _ld(x), _p(wt), ldw,
+         _p(add), _ld(add) if add is not None else 0, _p(gx), _ld(gx), _p(dwe), _p(ws), ws.numel(), M, inp, hid, dt_code(x.dtype), _stream())
+
+
 def bn_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, save_mean,
                     save_invstd, C, stat_rows=None, stat_ld=None):
     call("atomnas_bn_finalize_fwd", _p(stats), _rows(stats, stat_rows), pad8(C) if stat_ld is None else stat_ld, float(count), _p(gamma), _p(beta), eps,

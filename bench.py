@@ -75,6 +75,8 @@ def algorithmic_bytes(tag_name, tag, itemsize):
         return (x + y) * itemsize if tag_name.endswith("fwd") else (2 * x + y) * itemsize
     if tag_name == "atomnas_pw_gemm_nt":
         return (f["M"] * f["K"] + f["M"] * f["N"]) * itemsize
+    if tag_name == "atomnas_expand_bwd":   # input-gradient GEMM (its MK + MN) + the weight gradient's one extra read of the block input
+        return (f["M"] * f["K"] + 2 * f["M"] * f["N"]) * itemsize
     if tag_name == "atomnas_pw_gemm_tn":
         # "pro<u>,<v>": the operand with the BatchNorm-backward prologue (2) is the gradient dC; the other one is the layer input A
         m = re.search(r"pro(\d),(\d)", tag)
@@ -102,7 +104,7 @@ def kernel_profile(ts, itemsize):
         a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
         a["launches"] += 1
         a["ms"] += e0.elapsed_time(e1)
-        if tag and name in ("atomnas_dwconv_fwd", "atomnas_dwconv_bwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn"):
+        if tag and name in ("atomnas_dwconv_fwd", "atomnas_dwconv_bwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn", "atomnas_expand_bwd"):
             a["bytes"] += algorithmic_bytes(name, tag, itemsize)
     return agg
 

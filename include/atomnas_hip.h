@@ -103,6 +103,18 @@ int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, long u_ss, const void
                        const void* v2, int ldv2, long v2_ss, const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out, long si, long sj, long M,
                        float* ws, long ws_floats, int dtype, void* stream);
 
+/* Backward of the expand convolution ConvBNReLU(inp, hid, 1) (models/mobilenet_base.py:316-320) with both gradients from ONE pass
+ *   over the two hidden streams (bf16 storage; shapes per atomnas_expand_bwd_supported: the early, activation-dominated stages):
+ *     dE = c1*h + c2*e + c3   (BatchNorm backward; h = masked gradient of the activated hidden tensor, e = raw conv output)
+ *     gx[M, inp] = dE * We (+ add: the residual branch);   dwe[n*inp + k] += sum_m dE[m][n] * x[m][k]
+ *   wt = We^T packed by atomnas_pack_weights ([inp padded to 64][ldw >= hid rounded up to 32]); ws: ws_floats floats for the
+ *   per-workgroup partials of the weight gradient (inp*hid floats each; summed in workgroup order).  Replaces one
+ *   atomnas_pw_gemm_nt (BNBWD prologue) + one atomnas_pw_gemm_tn, which read h and e twice. */
+int atomnas_expand_bwd_supported(int inp, int hid, int dtype);
+int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde, long e_ss, const float* c1, const float* c2,
+                       const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx, int ldgx,
+                       float* dwe, float* ws, long ws_floats, long M, int inp, int hid, int dtype, void* stream);
+
 /* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;
  *      kwargs from models/mobilenet_supernet.py:95-98; calibration mode utils/common.py:214-226.
  * finalize forward: stats = stat_rows partial rows [2][stat_ld] of [sum x, sum x^2] over `count` elements (stat_ld >= C rounded

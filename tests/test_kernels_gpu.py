@@ -310,3 +310,46 @@ def test_gemm_slab_layout_is_bit_identical_to_plain(gpu_lib, M, N, K):
         res.append((C.to_plain()[:, :N] if slab else C[:, :N], st, out, out2))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- fused expand backward
+@pytest.mark.parametrize("slab", [True, False])
+@pytest.mark.parametrize("M,inp,hid,res", [(5000, 24, 432, True), (777, 16, 288, False), (4100, 40, 300, True), (130, 8, 48, False),
+                                           (9000, 16, 768, True), (2500, 32, 3 * 112, False)])
+def test_expand_bwd_fused_matches_the_two_gemm_form(gpu_lib, M, inp, hid, res, slab):
+    """atomnas_expand_bwd = atomnas_pw_gemm_nt(BNBWD prologue) + atomnas_pw_gemm_tn of the expand convolution's backward
+    (models/mobilenet_base.py:316-320) with h and E read once.  The input gradient runs the same MFMA sequence per row,
+    the weight gradient groups its partial sums by workgroup (rounding-level difference); both are also checked against fp64."""
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    dtype = torch.bfloat16
+    assert ops.expand_bwd_supported(inp, hid, dtype) and not ops.expand_bwd_supported(40, 720, dtype)   # see pwconv.hip
+    g = torch.Generator().manual_seed(M + inp + hid)
+    r = lambda *s: torch.randn(*s, generator=g)
+    act2d = lambda t, c: torch.cat([t.to(dtype), torch.zeros(t.shape[0], pad8(c) - c, dtype=dtype)], 1).cuda()
+    H, E, X, Gres = act2d(r(M, hid), hid), act2d(r(M, hid), hid), act2d(r(M, inp), inp), act2d(r(M, inp), inp)
+    We = r(hid, inp) / inp ** 0.5                      # the expand weight [hid, inp]
+    c1, c2, c3 = cvec(torch.rand(hid, generator=g) + 0.5), cvec(r(hid) * 0.2), cvec(r(hid) * 0.2)
+    wt = pack_w(We, dtype, transposed=True)            # We^T packed: [pad64(inp)][pad32(hid)]
+    wh = (lambda t: Slab.from_plain(t, hid)) if slab else (lambda t: t)
+    Hs, Es = wh(H), wh(E)
+    gx1, gx2 = fresh(M, inp, dtype), fresh(M, inp, dtype)
+    dw1 = torch.full((hid, inp), 0.25, dtype=torch.float32, device="cuda")   # gradients ACCUMULATE into the arena
+    dw2 = dw1.clone()
+    ops.expand_bwd(Hs, Es, c1, c2, c3, X, wt, Gres if res else None, gx1, dw1.view(-1), M, inp, hid)
+    ops.gemm_tn(X, inp, Hs, hid, dw2.view(-1), 1, inp, M, v_mode=ops.PRO_BNBWD, v2=Es, vc1=c1, vc2=c2, vc3=c3)
+    ops.gemm_nt(Hs, wt, gx2, M, inp, hid, a_mode=ops.PRO_BNBWD, a2=Es, ac1=c1, ac2=c2, ac3=c3, add=Gres if res else None)
+    torch.cuda.synchronize()
+    # same MFMA sequence per row; the prologue's multiply-adds may be contracted differently, which can move a bf16 operand by an ulp
+    assert float((gx1.float() != gx2.float()).float().mean()) < 0.02
+    assert torch.allclose(gx1.float(), gx2.float(), rtol=2e-2, atol=2e-2 * float(gx2.float().abs().max()))
+    assert torch.allclose(dw1, dw2, rtol=1e-3, atol=1e-3 * float(dw2.abs().max())), float((dw1 - dw2).abs().max())   # bf16 operand flips as above
+    # fp64 reference of the same arithmetic (dE rounded to bf16 as the MFMA operand)
+    dE = (c1[:hid].double().cpu() * H[:, :hid].double().cpu() + c2[:hid].double().cpu() * E[:, :hid].double().cpu() + c3[:hid].double().cpu())
+    dE = dE.float().to(dtype).double()
+    Wb = We.to(dtype).double()
+    ref_gx = dE @ Wb + (Gres[:, :inp].double().cpu() if res else 0)
+    ref_dw = dE.t() @ X[:, :inp].double().cpu() + 0.25
+    assert_close("gx", gx1[:, :inp], ref_gx, rtol=1e-2, atol=1e-2 * float(ref_gx.abs().max()))
+    assert_close("dwe", dw1, ref_dw, rtol=2e-3, atol=2e-3 * float(ref_dw.abs().max()))
+    assert float(gx1[:, inp:].abs().max()) == 0 if pad8(inp) > inp else True
