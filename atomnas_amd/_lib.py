@@ -41,6 +41,8 @@ SIGNATURES = {
     "atomnas_vec_sum": [vp, i32, f32, vp, vp],
     "atomnas_ema_update": [vp, vp, i64, vp, vp],
     "atomnas_scale_by": [vp, i64, vp, i32, vp],
+    "atomnas_zero": [vp, i64, vp],
+    "atomnas_add_i64": [vp, i64, i64, vp],
     "atomnas_reg_grad": [vp, vp, vp, i32, i32, vp, vp, vp],
     "atomnas_reg_value": [vp, vp, i32, i32, vp, f32, vp, vp, vp],
     "atomnas_pack_weights": [vp, vp, vp, i32, i32, vp],

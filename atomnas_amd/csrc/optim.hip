@@ -82,6 +82,19 @@ __global__ __launch_bounds__(256) void k_scale_by(float* __restrict__ x, long n,
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= f;
 }
 
+// zero-fill with 16-byte stores (n16 pieces) plus a 4-byte tail.  A kernel rather than hipMemsetAsync: as a captured memset node
+// the 44 MB gradient arena was not cleared on replay (bs 256 supernet, ROCm 7.2: the replayed step trained on accumulated
+// gradients), while kernel nodes replay faithfully.
+__global__ __launch_bounds__(256) void k_zero(f32x4* __restrict__ p16, long n16, float* __restrict__ tail, int ntail) {
+  const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p16[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_add_i64(long* __restrict__ p, long n, long v) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] += v;
+}
+
 // Weight packing jobs.  src is fp32 in the parameter arena with logical shape [rows][cols] (row pitch src_ld).
 //   mode 0 (PW):   dst[r*dst_ld + c_off + c] = src[r][c]            (storage T)   -> gemm_nt weight  [N][K]
 //   mode 1 (PW_T): dst[(c_off + c)*dst_ld + r] = src[r][c]          (storage T)   -> gemm_nt weight of the transposed product
@@ -146,6 +159,27 @@ extern "C" int atomnas_scale_by(float* x, long n, const float* hyper, int idx, v
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_scale_by, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, hyper, idx);
   return check_launch("scale_by");
+}
+
+// p[0 .. bytes) = 0 (gradient arena, per-step scalars, accumulated outputs); p 16-byte aligned, bytes a multiple of 4
+extern "C" int atomnas_zero(void* p, long bytes, void* stream) {
+  ATOMNAS_REQUIRE(p && bytes > 0 && bytes % 4 == 0 && ((unsigned long long)p & 15ull) == 0, "zero: needs a 16-byte aligned pointer and whole words");
+  const long n16 = bytes / 16;
+  const int ntail = (int)((bytes % 16) / 4);
+  long blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_zero, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (f32x4*)p, n16, (float*)p + n16 * 4, ntail);
+  return check_launch("zero");
+}
+
+// p[i] += v for the int64 counters (num_batches_tracked of every BatchNorm, models/mobilenet_base.py:142; the dropout step counter)
+extern "C" int atomnas_add_i64(long* p, long n, long v, void* stream) {
+  ATOMNAS_REQUIRE(p && n > 0, "add_i64: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_add_i64, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, n, v);
+  return check_launch("add_i64");
 }
 
 extern "C" int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream) {

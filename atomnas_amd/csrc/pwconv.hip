@@ -154,9 +154,8 @@ constexpr int NT_MAX_STAT = 8192;  // widest output for which the epilogue stati
 // (reduced over the 16 pixels with cross-lane adds, then added by lane j == 0 into the WAVE-PRIVATE LDS row sw[2][swd] at local
 // channel nl: plain read-modify-write in program order, no atomics -- the statistics are bit-reproducible).
 template <typename T>
-__device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&acc)[4], long row, bool rowvalid, int nb, int N,
-                                            bool do_stats, float* sw, int swd, int nl, int j) {
-  float c[16], zv[16];
+__device__ __forceinline__ void nt_epilogue_core(const Epilogue& ep, const f32x4 (&acc)[4], long row, bool rowvalid, int nb, int N,
+                                                 float (&c)[16], float (&zv)[16]) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -220,7 +219,13 @@ __device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&ac
 #pragma unroll
     for (int i = 0; i < 16; ++i) c[i] = 0.f;
   }
+}
 
+template <typename T>
+__device__ __forceinline__ void nt_epilogue(const Epilogue& ep, const f32x4 (&acc)[4], long row, bool rowvalid, int nb, int N,
+                                            bool do_stats, float* sw, int swd, int nl, int j) {
+  float c[16], zv[16];
+  nt_epilogue_core<T>(ep, acc, row, rowvalid, nb, N, c, zv);
   if (do_stats) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -329,6 +334,129 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
   if (do_stats) nt_flush_stats(ep, s_stat, SWD, nc0, N, rs, R, tid);
 }
 
+
+// ------------------------------------------------------------------------------------------------ gemm_nt, narrow (N <= 64, K <= 64)
+// The stem and the first (non-expanding) block: 3.2e6 rows of 16..32 channels on either side.  The row-stationary kernel spends
+// 4-8 weight-fragment loads and 128 cross-lane statistics operations on every 16-row tile that moves 1-2 KiB, and waits for each
+// tile's activations before it starts the next.  Here the weight fragments and prologue coefficients of the lane's k positions
+// stay in registers, the next tile's activations are in flight while the current one is computed, and the statistics are
+// accumulated per lane and reduced once at the end (as in the column-stationary kernel).
+template <int MODE, int KST>
+__global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  constexpr int SWD = 64;
+  extern __shared__ float s_stat[];  // [4 waves][2][64] when statistics are taken
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int wrow = 16 * (j >> 2) + (j & 3);
+  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+  if (do_stats) {
+    for (int i = tid; i < 8 * SWD; i += 256) s_stat[i] = 0.f;
+    __syncthreads();
+  }
+  bf16x8 wf[KST][4];
+  float p1[KST][8], p2[KST][8], p3[KST][8];
+#pragma unroll
+  for (int ks = 0; ks < KST; ++ks) {
+    const int k = ks * 32 + 8 * q;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[ks][t] = MM::raw(Wp + (long)(wrow + 4 * t) * ldw + k);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p1[ks][e] = p2[ks][e] = p3[ks][e] = 0.f;
+    if constexpr (MODE != PRO_NONE) {
+      if (k < K) {   // per-channel vectors are readable up to K rounded up to 8
+        VecIO<float, 8>::load(A.c1 + k, p1[ks]);
+        VecIO<float, 8>::load(A.c2 + k, p2[ks]);
+        if constexpr (MODE == PRO_BNBWD) VecIO<float, 8>::load(A.c3 + k, p3[ks]);
+      }
+    }
+  }
+  struct Raw { bf16x8 a, x; };
+  Raw nx[KST];
+  const long mtiles = (M + 15) / 16;
+  const long stride = (long)gridDim.x * 4;
+  auto fetch = [&](long mt) {
+    const long row = mt * 16 + j;
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const int k = ks * 32 + 8 * q;
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+      nx[ks].a = z;
+      nx[ks].x = z;
+      if (row < M && k < K) {
+        nx[ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row, k, A.ld1, A.ss1));
+        if constexpr (MODE == PRO_BNBWD)
+          nx[ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row, k, A.ld2, A.ss2));
+      }
+    }
+  };
+  float s1[16], s2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+
+  long mt = (long)blockIdx.x * 4 + wave;
+  if (mt < mtiles) fetch(mt);
+  for (; mt < mtiles; mt += stride) {
+    Raw cur[KST];
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) cur[ks] = nx[ks];
+    if (mt + stride < mtiles) fetch(mt + stride);
+    const long row = mt * 16 + j;
+    const bool rowvalid = row < M;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const int k = ks * 32 + 8 * q;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = (float)cur[ks].a[e];
+        if constexpr (MODE == PRO_NONE) v[e] = a;
+        else if constexpr (MODE == PRO_BNRELU) v[e] = a * p1[ks][e] + p2[ks][e];
+        else v[e] = p1[ks][e] * a + p2[ks][e] * (float)cur[ks].x[e] + p3[ks][e];
+      }
+      if constexpr (MODE == PRO_BNRELU) act_apply_v<8>(v, act_of(A.relu));
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (!rowvalid || k + e >= K) v[e] = 0.f;
+      const bf16x8 af = MM::pack(v);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
+    }
+    float c[16], zv[16];
+    nt_epilogue_core<T>(ep, acc, row, rowvalid, 16 * q, N, c, zv);
+    if (do_stats) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s1[i] += c[i];
+        s2[i] += (ep.stat_mode == STAT_SQ) ? c[i] * c[i] : c[i] * zv[i];
+      }
+    }
+  }
+  if (do_stats) {
+    float* sw = s_stat + wave * 2 * SWD;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float a = s1[i], b = s2[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (j == 0 && 16 * q + i < N) {
+        sw[16 * q + i] = a;
+        sw[SWD + 16 * q + i] = b;
+      }
+    }
+    nt_flush_stats(ep, s_stat, SWD, 0, N, blockIdx.x, gridDim.x, tid);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ gemm_nt, column-stationary
 // For the expand-like shapes (K <= 192, N large: the 6x-wide hidden tensor is the OUTPUT).  A wave owns one 64-channel
@@ -1187,6 +1315,32 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
       else if (ksteps == 3) launch_nt_cs<3>(mode, A, Wp, ldw, ep, M, N, K, st);
       else launch_nt_cs<6>(mode, A, Wp, ldw, ep, M, N, K, st);
       return check_launch("gemm_nt_cs");
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    static const int small_env = getenv("ATOMNAS_NT_SMALL") ? atoi(getenv("ATOMNAS_NT_SMALL")) : 1;
+    if (small_env && N <= 64 && K <= 64 && M >= 65536) {
+      const long mtiles = (M + 15) / 16;
+      const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
+      const size_t lds = do_stats ? (size_t)8 * 64 * sizeof(float) : 0;
+      const bf16_t* W = (const bf16_t*)Wp;
+#define SM_LAUNCH(MODE, KSTV)                                                                                  \
+  {                                                                                                            \
+    auto kern = k_gemm_nt_small<MODE, KSTV>;                                                                   \
+    long R = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                \
+    if (R > (mtiles + 3) / 4) R = (mtiles + 3) / 4;                                                            \
+    if (do_stats && R > ep.stat_rows) R = ep.stat_rows;                                                        \
+    if (R < 1) R = 1;                                                                                          \
+    hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(256), lds, st, A, W, ldw, ep, M, N, K);                   \
+  }
+#define SM_CASE(MODE) \
+  if (K <= 32) SM_LAUNCH(MODE, 1) else SM_LAUNCH(MODE, 2)
+      if (mode == PRO_NONE) { SM_CASE(PRO_NONE) }
+      else if (mode == PRO_BNRELU) { SM_CASE(PRO_BNRELU) }
+      else { SM_CASE(PRO_BNBWD) }
+#undef SM_CASE
+#undef SM_LAUNCH
+      return check_launch("gemm_nt_small");
     }
   }
   if constexpr (sizeof(T) == 2) {

@@ -152,7 +152,7 @@ class TrainStep:
         identical on every rank (train.py:171-185)."""
         mgr = self.mgr
         mgr.zero_grad()
-        self._scal.zero_()
+        ops.zero_(self._scal)
         loss = self.model(self.x, loss_args=(self.y, self.label_smoothing, self.loss_vec, self.topk, self.loss[0:1]))
         loss.backward()
 
@@ -171,7 +171,7 @@ class TrainStep:
                               group['eps'], group['eps_inside_sqrt'], group['momentum'], l2_value=self.loss[1:2], ws=self._ws)
         if self.ema is not None:
             ops.ema_update(mgr.SEMA, mgr.S, mgr.nS, mgr.hyper)
-        mgr.step_counter.add_(1)
+        ops.add_i64(mgr.step_counter, 1)
 
     def _capture(self):
         mgr = self.mgr

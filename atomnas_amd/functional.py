@@ -55,7 +55,8 @@ def to_4d(y2d, N, H, W, C):
 
 
 def _f32(n, dev, zero=False):
-    return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
+    t = torch.empty(n, dtype=torch.float32, device=dev)
+    return ops.zero_(t) if zero else t
 
 
 class StatBuf:
@@ -253,7 +254,7 @@ def block_backward(pl, sv, G):
         h = _hidden(pl, M, HT, T, dev)
         st2E = _stats(HT, dev, pl.bne["mgr"])
     else:
-        h = torch.zeros(M, pl.inp, dtype=T, device=dev) if pl.nb > 1 else torch.empty(M, pl.inp, dtype=T, device=dev)
+        h = ops.zeros(M, pl.inp, dtype=T, device=dev) if pl.nb > 1 else torch.empty(M, pl.inp, dtype=T, device=dev)
         st2E = None
     for i in range(pl.nb):
         o, c = pl.seg[i], pl.segpad(pl.hid[i])
@@ -353,7 +354,7 @@ def convbn_forward(pl, x, need_grad):
         sv["kind"] = "dw"
     bs = bn_uses_batch_stats(pl.bn)
     Cp = pad8(pl.cout)
-    Y = torch.empty(M, Cp, dtype=T, device=dev) if sv["kind"] != "dw" else torch.zeros(M, Cp, dtype=T, device=dev)
+    Y = torch.empty(M, Cp, dtype=T, device=dev) if sv["kind"] != "dw" else ops.zeros(M, Cp, dtype=T, device=dev)
     st = _stats(pl.cout, dev, pl.bn["mgr"]) if bs else None
     if sv["kind"] == "dw":
         ops.dwconv_fwd(a2d, None, None, 0, pl.taps, Y, st.t if bs else None, pl.cout, N, H, W, pl.cout, pl.k, pl.stride,
@@ -380,7 +381,7 @@ def convbn_backward(pl, sv, G, need_input_grad):
     ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, int(act), g, st2.t, M, pl.cout, stat_rows=st2.rows)
     c1, c2, c3 = bn_backward_coeffs(pl.bn, b, st2, M, dev)
     if sv["kind"] == "dw":
-        h = torch.zeros(N * H * W, pad8(pl.cout), dtype=T, device=dev)
+        h = ops.zeros(N * H * W, pad8(pl.cout), dtype=T, device=dev)
         ops.dwconv_bwd(g, Y, c1, c2, c3, a2d, None, None, 0, pl.taps, h, pl.W_grad, None, 0, N, H, W, pl.cout, pl.k, pl.stride)
         return h
     K = sv["K"]
@@ -465,7 +466,7 @@ def tail_backward(lp, fp, sv, dlogits, dl_padded=None):
     if dl_padded is not None:
         dl = dl_padded
     else:
-        dl = torch.zeros(N, pad8(Kc), dtype=T, device=dev)
+        dl = ops.zeros(N, pad8(Kc), dtype=T, device=dev)
         dl[:, :Kc] = dlogits
     # classifier
     ops.gemm_tn(dl, Kc, sv["pooled"], fp.cin, fp.W_grad, fp.cin, 1, N)

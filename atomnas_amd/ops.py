@@ -305,6 +305,26 @@ def ema_update(shadow, x, n, hyper):
     call("atomnas_ema_update", _p(shadow), _p(x), n, _p(hyper), _stream())
 
 
+def zero_(t):
+    """t[...] = 0 with the library's fill kernel (contiguous storage, 16-byte aligned); returns t"""
+    if isinstance(t, Slab):
+        zero_(t.t)
+        return t
+    assert t.is_contiguous()
+    if t.numel():
+        call("atomnas_zero", _p(t), t.numel() * t.element_size(), _stream())
+    return t
+
+
+def zeros(*shape, dtype, device):
+    return zero_(torch.empty(*shape, dtype=dtype, device=device))
+
+
+def add_i64(t, v):
+    assert t.dtype == torch.int64 and t.is_contiguous()
+    call("atomnas_add_i64", _p(t), t.numel(), int(v), _stream())
+
+
 def scale_by(x, n, hyper, idx):
     call("atomnas_scale_by", _p(x), n, _p(hyper), idx, _stream())
 

@@ -647,7 +647,7 @@ class ArenaManager:
             ops.pack_weights(self.P, self.packF, self.jobsF, self.njobsF, torch.float32)
 
     def zero_grad(self):
-        self.G.zero_()
+        ops.zero_(self.G)
 
     def push_hyper(self):
         """host -> device copy of (lr, rho, EMA decay, grad scale), stream-ordered before the kernels that read them"""
@@ -689,7 +689,7 @@ class ArenaManager:
     def leave(self):
         self._depth -= 1
         if self._depth == 0 and self.bn_trained:
-            self.CNT.add_(1)
+            ops.add_i64(self.CNT, 1)
             self.bn_trained = False
 
 

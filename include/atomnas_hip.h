@@ -193,6 +193,10 @@ int atomnas_ema_update(float* shadow, const float* x, long n, const float* hyper
 /* x[i] *= hyper[idx]: the BN running statistics summed over the ranks become their average (utils/distributed.py:164-169,
  * allreduce_bn; hyper[3] = 1 / world) */
 int atomnas_scale_by(float* x, long n, const float* hyper, int idx, void* stream);
+/* housekeeping of the step without framework kernels: zero-fill (16-byte aligned, whole words), int64 counters += v
+ * (num_batches_tracked of the BatchNorms, the dropout step counter) */
+int atomnas_zero(void* p, long bytes, void* stream);
+int atomnas_add_i64(long* p, long n, long v, void* stream);
 /* regularisers as gradient contributions / values over a job table {long off; int count; float coef;}:
  *   cal_l2_loss (utils/optim.py:210-249): g += wd*p, value 0.5*wd*sum p^2;  cal_bn_l1_loss (utils/prune.py:161-167):
  *   g += rho*penalty*sign(gamma), value rho*penalty*sum|gamma|.  mult_ptr / grad_out_ptr: optional device scalars. */

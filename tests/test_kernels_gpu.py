@@ -132,7 +132,9 @@ GEMM_SHAPES = [(100, 24, 16), (1000, 432, 24), (333, 40, 139), (64, 16, 432), (2
                (20000, 1440, 80),
                # weight-shared kernel (bf16, K > 192, M >= 4096): one / two 64-channel chunks, channel groups, ragged M, K and N,
                # and enough rows for two subtiles per wave
-               (4100, 24, 432), (5000, 80, 1440), (4097, 139, 203), (4200, 192, 3456), (140000, 40, 720), (70000, 96, 250)]
+               (4100, 24, 432), (5000, 80, 1440), (4097, 139, 203), (4200, 192, 3456), (140000, 40, 720), (70000, 96, 250),
+               # narrow kernel (bf16, N <= 64, K <= 64, M >= 65536): the stem and the first block; one / two k-steps, ragged everything
+               (70001, 32, 27), (66000, 16, 32), (65599, 32, 16), (80000, 24, 40), (65536, 64, 64)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
