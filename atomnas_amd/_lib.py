@@ -21,6 +21,8 @@ SIGNATURES = {
     "atomnas_pw_gemm_tn": [i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32,
                            vp, i64, i64, i64, vp, i64, i32, vp],
     "atomnas_expand_bwd": [vp, i32, i64, vp, i32, i64, vp, vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, i64, i32, i32, i32, vp],
+    "atomnas_project_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, i32, vp, i64, i64, vp, i64, i64,
+                            i32, i32, i32, vp],
     "atomnas_bn_finalize_fwd": [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     "atomnas_bn_finalize_bwd": [vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
@@ -51,7 +53,8 @@ SIGNATURES = {
     "atomnas_gather_dim": [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp],
 }
 NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version": (i32, []),
-             "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32])}
+             "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32]),
+             "atomnas_project_bwd_supported": (i32, [i32, i32, i32])}
 
 _lib = None
 

@@ -589,6 +589,167 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused project backward
+// Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) for the early stages (oup <= 48): the
+// column-stationary input-gradient GEMM  g = mask(dP * Wp)  already holds, per 16-row tile, dP (as its MFMA operand) and the raw
+// depthwise output z of its 64 channels (for the activation mask and the BatchNorm statistics).  The weight gradient
+// dWp[o][n] = sum_m dP[m][o] * act(bn(z))[m][n] needs exactly those two, so the wave also transposes both through a PRIVATE LDS
+// region (no workgroup barrier: LDS operations of one wave complete in order) and accumulates R[oup][64] with 16x16x16 MFMAs
+// (contraction over the tile's 16 rows).  One partial per (row range, chunk) in the caller's workspace, summed in range order by
+// reduce_parts.  This removes atomnas_pw_gemm_tn's second pass over z.
+constexpr int PB_RP = 16 + 4;   // rows of a tile + pad (elements): 40-byte rows, 8-byte aligned fragment reads
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int KSTEPS, int UT>
+__global__ __launch_bounds__(256) void k_project_bwd_cs(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, float* __restrict__ ws,
+                                                        long M, int N, int K, int nchunks, int tiles_per_item) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  constexpr int MODE = PRO_BNBWD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_pb[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* s_p = reinterpret_cast<T*>(smem_pb) + wave * (16 * UT + 64) * PB_RP;   // [16*UT][PB_RP] dP of the tile, transposed
+  T* s_a = s_p + 16 * UT * PB_RP;                                           // [64][PB_RP] act(bn(z)) of the tile, transposed
+  const int q = lane >> 4, j = lane & 15;
+  const int wrow = 16 * (j >> 2) + (j & 3);
+  const long item = (long)blockIdx.x * 4 + wave;
+  const long mtiles = (M + 15) / 16;
+  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
+  if (item >= nranges * nchunks) return;
+  const int chunk = (int)(item % nchunks);
+  const long range = item / nchunks;
+  const int nc = chunk * 64;
+  const int nb = nc + 16 * q;
+  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+
+  typename MM::frag wf[KSTEPS][4];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[ks][t] = MM::raw(Wp + (long)(nc + wrow + 4 * t) * ldw + ks * 32 + 8 * q);
+
+  float s1[16], s2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+  f32x4 racc[UT][4];
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) racc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // rows of s_p beyond the k positions the lanes write (K rounded up to 32 per k-step covers 16*UT whenever 32*KSTEPS >= 16*UT)
+  const long mt_beg = range * tiles_per_item;
+  const long mt_end = mt_beg + tiles_per_item < mtiles ? mt_beg + tiles_per_item : mtiles;
+  for (long mt = mt_beg; mt < mt_end; ++mt) {
+    const long row = mt * 16 + j;
+    const bool rowvalid = row < M;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      float av[8];
+      load_pro<T, MODE>(A, row, rowvalid, ks * 32 + 8 * q, K, av);
+      const typename MM::frag af = MM::pack(av);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
+      // dP transposed: s_p[o][row j], o = ks*32 + 8q + e (rows >= 16*UT do not exist: those o are >= K rounded up to 16)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int o = ks * 32 + 8 * q + e;
+        if (o < 16 * UT) s_p[o * PB_RP + j] = af[e];
+      }
+    }
+    float c[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[4 * t + r] = acc[t][r];
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+      const int n8 = nb + 8 * h8;
+      float zv[8], a8[8], o8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) zv[i] = a8[i] = o8[i] = 0.f;
+      if (rowvalid && n8 < N) {
+        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss), zv);
+        float zs[8], zh[8];
+        VecIO<float, 8>::load(ep.zscale + n8, zs);
+        VecIO<float, 8>::load(ep.zshift + n8, zh);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = zv[i] * zs[i] + zh[i];
+        act_bwd_v<8>(&c[8 * h8], a8, act_of(ep.mask));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (n8 + i >= N) c[8 * h8 + i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
+        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
+        if (do_stats) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            s1[8 * h8 + i] += o8[i];
+            s2[8 * h8 + i] += o8[i] * zv[i];
+          }
+        }
+        act_apply_v<8>(a8, act_of(ep.mask));   // the projection's forward operand act(bn(z))
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (n8 + i >= N) a8[i] = 0.f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s_a[(16 * q + 8 * h8 + i) * PB_RP + j] = from_f32<T>(a8[i]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // R[o][n] += sum over the tile's 16 rows: A = dP^T (lane: o = 16t + j, rows 4q..4q+3), B = act(bn(z)) (lane: n = 16u + j)
+    s16x4 bfr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bfr[u] = *reinterpret_cast<const s16x4*>(s_a + (16 * u + j) * PB_RP + 4 * q);
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const s16x4 afr = *reinterpret_cast<const s16x4*>(s_p + (16 * t + j) * PB_RP + 4 * q);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) racc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afr, bfr[u], racc[t][u], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the next tile overwrites s_p / s_a
+  }
+
+  if (do_stats) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float a = s1[i], b = s2[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (j == 0 && nb + i < N) {
+        ep.stats[(long)range * 2 * N + nb + i] = a;
+        ep.stats[(long)range * 2 * N + N + nb + i] = b;
+        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, nb + i);
+        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, (long)N + nb + i);
+      }
+    }
+  }
+  // partial of the weight gradient: (o, n) at ws[(range * K + o) * N + n]
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = nc + 16 * u + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * t + 4 * q + r;
+        if (o < K && n < N) ws[((long)range * K + o) * N + n] = racc[t][u][r];
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ gemm_nt, weights shared in LDS
 // For the contraction-heavy shapes (K > 192: the linear projection forward, the expand input-gradient): the 6x-wide hidden
 // tensor is the INPUT, streamed once from HBM straight into MFMA B fragments (prologue applied in registers).  In the
@@ -1469,6 +1630,34 @@ static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Opera
   return 0;
 }
 
+// fused project backward (column-stationary input gradient + weight gradient)
+template <int KSTEPS, int UT>
+static int launch_project_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, const Epilogue& ep, float* dwp, long si, long sj, float* ws,
+                                  long ws_floats, long M, int N, int K, hipStream_t st) {
+  const int nchunks = (N + 63) / 64;
+  const long mtiles = (M + 15) / 16;
+  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+  auto kern = k_project_bwd_cs<KSTEPS, UT>;
+  const size_t lds = (size_t)4 * (16 * UT + 64) * PB_RP * sizeof(bf16_t);
+  const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;
+  long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;
+  if (tiles_per_item < 8) tiles_per_item = 8;
+  if (do_stats) {
+    const long min_tpi = (mtiles + ep.stat_rows - 1) / ep.stat_rows;   // every row range owns one partial row of the statistics
+    if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;
+  }
+  const long max_parts = ws_floats / ((long)K * N);   // ... and one partial of the weight gradient
+  ATOMNAS_REQUIRE(max_parts >= 1, "project_bwd: workspace too small for one partial (%ld floats)", (long)K * N);
+  long max_ranges = waves / nchunks > 0 ? waves / nchunks : 1;
+  if (max_ranges > max_parts) max_ranges = max_parts;
+  if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges;
+  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
+  const long items = nranges * nchunks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, A, W, ldw, ep, ws, M, N, K, nchunks, (int)tiles_per_item);
+  if (int rc = check_launch("project_bwd")) return rc;
+  return reduce_parts(ws, (long)K * N, (int)nranges, (long)K * N, dwp, N, si, sj, st);
+}
+
 // fused expand backward: supported shapes and launch
 static inline int xb_nch(int HT) {
   const int n = (HT + WS_KC - 1) / WS_KC;
@@ -1598,5 +1787,39 @@ extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void*
 #undef XB_CASE
   set_error("expand_bwd: no instance for inp=%d hid=%d", inp, hid);
   return 1;
+}
+
+// 1 when atomnas_project_bwd has an instance for this shape (bf16 storage, oup <= 48, hid >= 96 and >= 2 * oup)
+extern "C" int atomnas_project_bwd_supported(int oup, int hid, int dtype) {
+  return dtype == DT_BF16 && oup >= 1 && oup <= 48 && hid >= 96 && hid >= 2 * oup && hid <= NT_MAX_STAT;
+}
+
+// Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) in ONE pass over the raw depthwise output:
+//   dP = c1*g + c2*p + c3   (BatchNorm backward of the block-output BN; g, p: [M, oup])
+//   gh[M, hid] = act'(z*zscale + zshift) * (dP * Wp)            -- gradient wrt the raw depthwise-BN output, masked
+//   stats rows [sum gh, sum gh*z]                               -- for the depthwise BN's backward
+//   dwp[o*si + n*sj] += sum_m dP[m][o] * act(z*zscale + zshift)[m][n]
+// wpt: Wp^T packed by atomnas_pack_weights ([hid padded to 64][ldw >= oup rounded up to 32]).
+extern "C" int atomnas_project_bwd(const void* g, int ldg, const void* p, int ldp, const float* c1, const float* c2, const float* c3,
+                                   const void* wpt, int ldw, const void* z, int ldz, long z_ss, const float* zscale, const float* zshift,
+                                   int act, void* gh, int ldgh, long gh_ss, float* stats, int stat_rows, float* dwp, long si, long sj,
+                                   float* ws, long ws_floats, long M, int oup, int hid, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(atomnas_project_bwd_supported(oup, hid, dtype), "project_bwd: unsupported shape oup=%d hid=%d dtype=%d", oup, hid, dtype);
+  ATOMNAS_REQUIRE(g && p && c1 && c2 && c3 && wpt && z && zscale && zshift && gh && stats && dwp && ws && M > 0, "project_bwd: bad arguments");
+  ATOMNAS_REQUIRE(act >= ACT_RELU && act <= ACT_SWISH && stat_rows > 0, "project_bwd: bad activation / stat_rows");
+  ATOMNAS_REQUIRE(ldg >= oup && ldg % 8 == 0 && ldp >= oup && ldp % 8 == 0, "project_bwd: bad pitch");
+  ATOMNAS_REQUIRE((z_ss >= M * 16 || (z_ss == 0 && ldz >= hid && ldz % 8 == 0)) && (gh_ss >= M * 16 || (gh_ss == 0 && ldgh >= hid && ldgh % 8 == 0)),
+                  "project_bwd: bad hidden layout");
+  ATOMNAS_REQUIRE(ldw >= (oup + 31) / 32 * 32 && ldw % 8 == 0, "project_bwd: packed weight pitch %d too small for oup=%d", ldw, oup);
+  Operand A{g, ldg, p, ldp, 0, 0, c1, c2, c3, 0};
+  Epilogue ep{gh, ldgh, 0, nullptr, 0, z, ldz, gh_ss, z_ss, zscale, zshift, act, nullptr, stats, STAT_Z, stat_rows};
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* W = (const bf16_t*)wpt;
+  const int ut = (oup + 15) / 16;
+  if (oup <= 32) {
+    if (ut == 1) return launch_project_bwd_cfg<1, 1>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+    return launch_project_bwd_cfg<1, 2>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  }
+  return launch_project_bwd_cfg<2, 3>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
 }
 

@@ -139,6 +139,7 @@ def bn_backward_coeffs(bn, st, stats2, count, dev):
 
 
 # ---------------------------------------------------------------------------------------------- atomic block
+_FUSED_PROJECT_BWD = bool(int(os.environ.get("ATOMNAS_FUSED_PROJECT_BWD", "1")))   # experiment switch (A/B against the two-GEMM form)
 _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))   # experiment switch (same-box A/B of the two layouts)
 
@@ -225,7 +226,9 @@ def block_backward(pl, sv, G):
     # The fused block's projection weight is one contiguous [oup, total] tensor: one launch per branch segment.
     wp_jobs = ([(sg, h, pl.Wp_grad[stt:], pl.total) for sg, stt, h in zip(pl.seg, pl.start, pl.hid)] if pl.fused
                else [(0, HT, pl.Wp_grad, HT)])
-    for sg, nv, out, si in wp_jobs:
+    # early stages (oup <= 48, no SE): the weight gradient rides in the input-gradient kernel below (one pass over D)
+    fused_pb = (_FUSED_PROJECT_BWD and se is None and not pl.fused and pl.expand and ops.project_bwd_supported(pl.oup, HT, T))
+    for sg, nv, out, si in ([] if fused_pb else wp_jobs):
         if se is not None:
             ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
         else:
@@ -244,6 +247,9 @@ def block_backward(pl, sv, G):
         ops.se_bwd_gate(dS, D, bD.scale, bD.shift, int(act), se["gate"], se["pooled"], pl.cmap, pl.se_w1, pl.se_w2, se["hpre"], dgate, dz2,
                         dz1, dpooled, pl.se_dw1, pl.se_db1, pl.se_dw2, pl.se_db2, N, HWo, HT, pl.total, pl.se_hid)
         ops.se_bwd_apply(dS, D, bD.scale, bD.shift, int(act), se["gate"], dpooled, g, st2D.t, M2, HWo, HT, stat_rows=st2D.rows)
+    elif fused_pb:
+        ops.project_bwd(G, Pr, p1, p2, p3, pl.WpT_pack, D, bD.scale, bD.shift, int(act), g, st2D.t, pl.Wp_grad, HT, 1, M2, pl.oup, HT,
+                        stat_rows=st2D.rows)
     else:
         # projection input gradient, masked by the depthwise activation, with the depthwise-BN backward statistics
         ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,

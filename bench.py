@@ -77,6 +77,8 @@ def algorithmic_bytes(tag_name, tag, itemsize):
         return (f["M"] * f["K"] + f["M"] * f["N"]) * itemsize
     if tag_name == "atomnas_expand_bwd":   # input-gradient GEMM (its MK + MN) + the weight gradient's one extra read of the block input
         return (f["M"] * f["K"] + 2 * f["M"] * f["N"]) * itemsize
+    if tag_name == "atomnas_project_bwd":  # input-gradient GEMM (MK + MN, K = oup, N = hid) + the weight gradient's extra read of the hidden input
+        return (f["M"] * f["K"] + 2 * f["M"] * f["N"]) * itemsize
     if tag_name == "atomnas_pw_gemm_tn":
         # "pro<u>,<v>": the operand with the BatchNorm-backward prologue (2) is the gradient dC; the other one is the layer input A
         m = re.search(r"pro(\d),(\d)", tag)
@@ -104,7 +106,7 @@ def kernel_profile(ts, itemsize):
         a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
         a["launches"] += 1
         a["ms"] += e0.elapsed_time(e1)
-        if tag and name in ("atomnas_dwconv_fwd", "atomnas_dwconv_bwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn", "atomnas_expand_bwd"):
+        if tag and name in ("atomnas_dwconv_fwd", "atomnas_dwconv_bwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn", "atomnas_expand_bwd", "atomnas_project_bwd"):
             a["bytes"] += algorithmic_bytes(name, tag, itemsize)
     return agg
 

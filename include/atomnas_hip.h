@@ -115,6 +115,19 @@ int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde
                        const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx, int ldgx,
                        float* dwe, float* ws, long ws_floats, long M, int inp, int hid, int dtype, void* stream);
 
+/* Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) in ONE pass over the raw depthwise
+ *   output z (bf16 storage; shapes per atomnas_project_bwd_supported: oup <= 48, the early stages):
+ *     dP = c1*g + c2*p + c3                                      (BatchNorm backward of the block-output BN; g, p: [M, oup])
+ *     gh[M, hid] = act'(z*zscale + zshift) * (dP * Wp),  statistics rows [sum gh, sum gh*z]
+ *     dwp[o*si + n*sj] += sum_m dP[m][o] * act(z*zscale + zshift)[m][n]
+ *   wpt = Wp^T packed by atomnas_pack_weights ([hid padded to 64][ldw >= oup rounded up to 32]); ws: per-row-range partials of the
+ *   weight gradient (oup*hid floats each).  Replaces atomnas_pw_gemm_nt(BNBWD, mask, STAT_Z) + atomnas_pw_gemm_tn. */
+int atomnas_project_bwd_supported(int oup, int hid, int dtype);
+int atomnas_project_bwd(const void* g, int ldg, const void* p, int ldp, const float* c1, const float* c2, const float* c3, const void* wpt,
+                        int ldw, const void* z, int ldz, long z_ss, const float* zscale, const float* zshift, int act, void* gh, int ldgh,
+                        long gh_ss, float* stats, int stat_rows, float* dwp, long si, long sj, float* ws, long ws_floats, long M, int oup,
+                        int hid, int dtype, void* stream);
+
 /* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;
  *      kwargs from models/mobilenet_supernet.py:95-98; calibration mode utils/common.py:214-226.
  * finalize forward: stats = stat_rows partial rows [2][stat_ld] of [sum x, sum x^2] over `count` elements (stat_ld >= C rounded

@@ -355,3 +355,52 @@ def test_expand_bwd_fused_matches_the_two_gemm_form(gpu_lib, M, inp, hid, res, s
     assert_close("gx", gx1[:, :inp], ref_gx, rtol=1e-2, atol=1e-2 * float(ref_gx.abs().max()))
     assert_close("dwe", dw1, ref_dw, rtol=2e-3, atol=2e-3 * float(ref_dw.abs().max()))
     assert float(gx1[:, inp:].abs().max()) == 0 if pad8(inp) > inp else True
+
+
+# ---------------------------------------------------------------------------------------------- fused project backward
+@pytest.mark.parametrize("slab", [True, False])
+@pytest.mark.parametrize("act", [1, 2, 3])
+@pytest.mark.parametrize("M,oup,hid", [(5000, 24, 432), (1500, 16, 288), (4100, 40, 720), (1031, 8, 96), (3000, 48, 203 + 5), (20000, 32, 336)])
+def test_project_bwd_fused_matches_the_two_gemm_form(gpu_lib, M, oup, hid, act, slab):
+    """atomnas_project_bwd = atomnas_pw_gemm_nt(BNBWD prologue, activation mask, STAT_Z) + atomnas_pw_gemm_tn of the projection's backward
+    (models/mobilenet_base.py:338) with the raw depthwise output read once.  Same MFMA sequence for the input gradient; the weight
+    gradient groups its partials by row range.  Both also against fp64."""
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    dtype = torch.bfloat16
+    assert ops.project_bwd_supported(oup, hid, dtype)
+    g = torch.Generator().manual_seed(M + oup + hid + act)
+    r = lambda *s: torch.randn(*s, generator=g)
+    act2d = lambda t, c: torch.cat([t.to(dtype), torch.zeros(t.shape[0], pad8(c) - c, dtype=dtype)], 1).cuda()
+    G, P, Z = act2d(r(M, oup), oup), act2d(r(M, oup), oup), act2d(r(M, hid) * 2, hid)
+    Wp = r(oup, hid) / hid ** 0.5                       # projection weight [oup, hid]
+    c1, c2, c3 = cvec(torch.rand(oup, generator=g) + 0.5), cvec(r(oup) * 0.2), cvec(r(oup) * 0.2)
+    zs, zh = cvec(torch.rand(hid, generator=g) + 0.5), cvec(r(hid) * 0.5)
+    wpt = pack_w(Wp, dtype, transposed=True)            # Wp^T packed: [pad64(hid)][pad32(oup)]
+    wz = (lambda t: Slab.from_plain(t, hid)) if slab else (lambda t: t)
+    Zs = wz(Z)
+    mk = lambda: (Slab(M, hid, dtype, "cuda", zero=True) if slab else fresh(M, hid, dtype))
+    gh1, gh2 = mk(), mk()
+    st1, st2 = poisoned_stats(128, hid), poisoned_stats(128, hid)
+    dw1 = torch.full((oup, hid), 0.5, dtype=torch.float32, device="cuda")
+    dw2 = dw1.clone()
+    ops.project_bwd(G, P, c1, c2, c3, wpt, Zs, zs, zh, act, gh1, st1, dw1.view(-1), hid, 1, M, oup, hid)
+    ops.gemm_tn(G, oup, Zs, hid, dw2.view(-1), hid, 1, M, u_mode=ops.PRO_BNBWD, u2=P, uc1=c1, uc2=c2, uc3=c3, v_mode=ops.PRO_BNRELU, vc1=zs,
+                vc2=zh, v_relu=act)
+    ops.gemm_nt(G, wpt, gh2, M, hid, oup, a_mode=ops.PRO_BNBWD, a2=P, ac1=c1, ac2=c2, ac3=c3, z=Zs, zscale=zs, zshift=zh, mask=act, stats=st2,
+                stat_mode=ops.STAT_Z)
+    torch.cuda.synchronize()
+    a, b = (gh1.to_plain() if slab else gh1)[:, :hid].float(), (gh2.to_plain() if slab else gh2)[:, :hid].float()
+    assert float((a != b).float().mean()) < 0.02
+    assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+    assert not torch.isnan(st1).any()
+    s1, s2 = st1.sum(0), st2.sum(0)
+    assert torch.allclose(s1, s2, rtol=1e-3, atol=2e-3 * float(s2.abs().max())), float((s1 - s2).abs().max())
+    assert torch.allclose(dw1, dw2, rtol=1e-3, atol=2e-3 * float(dw2.abs().max())), float((dw1 - dw2).abs().max())
+    # fp64 reference of the weight gradient (operands rounded to bf16 as the MFMAs see them)
+    dP = (c1[:oup].double().cpu() * G[:, :oup].double().cpu() + c2[:oup].double().cpu() * P[:, :oup].double().cpu() + c3[:oup].double().cpu())
+    dP = dP.float().to(dtype).double()
+    pre = Z[:, :hid].double().cpu() * zs[:hid].double().cpu() + zh[:hid].double().cpu()
+    A = {1: torch.relu(pre), 2: pre.clamp(0, 6), 3: pre * torch.sigmoid(pre)}[act].float().to(dtype).double()
+    ref_dw = dP.t() @ A + 0.5
+    assert_close("dwp", dw1, ref_dw, rtol=2e-3, atol=3e-3 * float(ref_dw.abs().max()))

@@ -47,7 +47,7 @@ print("  sum of kernel times %.2f ms" % tot)
 if os.environ.get("DETAIL"):
     det = collections.OrderedDict()
     for name, tag, e0, e1 in prof:
-        if name in ("atomnas_dwconv_bwd", "atomnas_dwconv_fwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn", "atomnas_expand_bwd"):
+        if name in ("atomnas_dwconv_bwd", "atomnas_dwconv_fwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn", "atomnas_expand_bwd", "atomnas_project_bwd"):
             a = det.setdefault((name, tag), [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
     for (name, tag), v in det.items(): print("    %-22s %-40s n=%2d %8.3f ms" % (name[8:], tag, v[0], v[1]))
 ts.use_graph = True
