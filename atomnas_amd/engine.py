@@ -58,6 +58,7 @@ class TrainStep:
         self.g_fwd_bwd = self.g_opt = None
         self._version = -1
         self.global_step = 0
+        self._seed_grad = None
 
     # ---- pieces
     def _prune_weights(self):
@@ -154,7 +155,9 @@ class TrainStep:
         mgr.zero_grad()
         ops.zero_(self._scal)
         loss = self.model(self.x, loss_args=(self.y, self.label_smoothing, self.loss_vec, self.topk, self.loss[0:1]))
-        loss.backward()
+        if self._seed_grad is None or self._seed_grad.shape != loss.shape:
+            self._seed_grad = torch.ones_like(loss)   # allocated once: backward() would fill a fresh ones tensor every step
+        loss.backward(self._seed_grad)
 
     def _opt(self):
         """[gradients summed over ranks] -> + world * rho * penalty * sign(gamma) -> RMSprop on g / world + wd * p (+ EMA of the

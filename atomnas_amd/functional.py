@@ -140,6 +140,7 @@ def bn_backward_coeffs(bn, st, stats2, count, dev):
 
 # ---------------------------------------------------------------------------------------------- atomic block
 _FUSED_PROJECT_BWD = bool(int(os.environ.get("ATOMNAS_FUSED_PROJECT_BWD", "1")))   # experiment switch (A/B against the two-GEMM form)
+_FUSED_EXPAND_SEG = bool(int(os.environ.get("ATOMNAS_FUSED_EXPAND_SEG", "1")))   # experiment switch: per-segment fused expand backward
 _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))   # experiment switch (same-box A/B of the two layouts)
 
@@ -281,6 +282,16 @@ def block_backward(pl, sv, G):
     if pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and ops.expand_bwd_supported(pl.inp, HT, T):
         # early stages (16 -> 288, 24 -> 432): input and weight gradient of the expand convolution from ONE pass over h and E
         ops.expand_bwd(h, E, e1, e2, e3, x2d, pl.WeT_pack, G if pl.res else None, Gx, pl.We_grad, M, pl.inp, HT)
+        return Gx
+    if (_FUSED_EXPAND_SEG and pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and pl.nb > 1
+            and all(ops.expand_bwd_supported(pl.inp, pl.segpad(hh), T) for hh in pl.hid)):
+        # 40 -> 720: the accumulators of the whole hidden width do not fit two workgroups per CU, those of one branch segment
+        # (240 channels) do: one launch per segment, the input gradient accumulating through `add` (each launch reads and writes
+        # its own rows of Gx only)
+        for i in range(pl.nb):
+            o, c = pl.seg[i], pl.segpad(pl.hid[i])
+            ops.expand_bwd(_seg(h, o), _seg(E, o), e1[o:], e2[o:], e3[o:], x2d, pl.WeT_pack[:, o:], (G if pl.res else None) if i == 0 else Gx, Gx,
+                           pl.We_grad[o * pl.inp:], M, pl.inp, c)
         return Gx
     # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k]); the
     # fused block's expand weight is one contiguous [total, inp] tensor: one launch per branch segment
