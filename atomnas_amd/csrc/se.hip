@@ -268,12 +268,6 @@ __global__ __launch_bounds__(256) void k_se_bwd_apply(const T* __restrict__ ds, 
 
 using namespace atomnas;
 
-#define SE_DISPATCH(KERN, GRID, LDS, ...)                                                         \
-  do {                                                                                            \
-    if (dtype == DT_F32) hipLaunchKernelGGL(KERN<float>, GRID, dim3(256), LDS, st, __VA_ARGS__);  \
-    else hipLaunchKernelGGL(KERN<bf16_t>, GRID, dim3(256), LDS, st, __VA_ARGS__);                 \
-  } while (0)
-
 extern "C" int atomnas_se_squeeze(const void* d, int ldd, long d_ss, const float* scale, const float* shift, int act, float* pooled,
                                   int ldp, int N, int HW, int C, int dtype, void* stream) {
   ATOMNAS_REQUIRE(d && scale && shift && pooled && N > 0 && HW > 0 && C > 0 && ldp >= (C + 7) / 8 * 8, "se_squeeze: bad arguments");
