@@ -862,13 +862,12 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   return check_launch("dwconv_fwd");
 }
 
-template <typename T, int K, int S>
-static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int ldyr, long yrss, const float* c1, const float* c2,
-                      const float* c3, const void* x, int ldx, long xss, const float* sc, const float* sh, int relu, const float* w,
-                      int ldw, void* h, int ldh, long hss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C,
-                      hipStream_t st) {
+template <typename T, int K, int S, int SW>
+static int launch_bwd_sw(const void* gup, int ldg, long gss, const void* yraw, int ldyr, long yrss, const float* c1, const float* c2,
+                         const float* c3, const void* x, int ldx, long xss, const float* sc, const float* sh, int relu, const float* w,
+                         int ldw, void* h, int ldh, long hss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C,
+                         hipStream_t st) {
   constexpr int P = (K - 1) / 2;
-  constexpr int SW = (S == 2) ? 14 : 7;
   DwGeom g;
   g.N = N; g.H = H; g.W = W; g.C = C;
   g.Ho = (H + 2 * P - K) / S + 1; g.Wo = (W + 2 * P - K) / S + 1;
@@ -885,7 +884,8 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
   // items; 16 channels: 56).  The prefetch registers are sized for the 7-pixel tile there (template parameter TM).
   const bool small = (S == 1 && H <= 7 && W <= 7);
   if (small) cb_rule = (K == 7) ? DW_SMALL_CB7 : 64;
-  const int cb = slab_width(cb_env ? cb_env : cb_rule, cpad);
+  if (S == 1 && SW == 14) cb_rule = 32;   // one 14-pixel strip per row: 16 channel pairs x 14 rows = 224 work items
+  const int cb = slab_width((S == 1 && SW == 14) ? cb_rule : (cb_env ? cb_env : cb_rule), cpad);
   pick_tiles(g, H, W, SW, cb, S == 2);
   // output window of an input tile: rows ceil((hi0+P-K+1)/S) .. floor((hi0+TH-1+P)/S)
   g.LH = fdiv(g.TH - 1 + P, S) - cdiv(P - (K - 1), S) + 1;
@@ -910,7 +910,10 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)gup, ldg, gss, (const T*)yraw, ldyr, yrss, c1, c2, c3, (const T*)x, \
                        ldx, xss, sc, sh, relu, w, ldw, (T*)h, ldh, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g); \
   }
-  if constexpr (S == 1) {
+  if constexpr (S == 1 && SW == 14) {
+    ATOMNAS_REQUIRE(cb == 32 && !small, "dwconv_bwd: wide strips need 32-channel slabs and tiles of 14 pixels");
+    BWD_CASE(32, 14)
+  } else if constexpr (S == 1) {
     if (small) {
       if (cb == 8) BWD_CASE(8, 7) else if (cb == 16) BWD_CASE(16, 7) else if (cb == 32) BWD_CASE(32, 7) else BWD_CASE(64, 7)
     } else {
@@ -924,6 +927,22 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
   // dw[c][t] += sum over workers of the partials, in worker order
   if (dw) return reduce_parts(dw_ws, (long)C * K * K, g.nworkers, (long)C * K * K, dw, C * K * K, 0, 1, st);
   return 0;
+}
+
+template <typename T, int K, int S>
+static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int ldyr, long yrss, const float* c1, const float* c2,
+                      const float* c3, const void* x, int ldx, long xss, const float* sc, const float* sh, int relu, const float* w,
+                      int ldw, void* h, int ldh, long hss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C,
+                      hipStream_t st) {
+  // experiment (ATOMNAS_DW_BWD_SW14=k-mask, bit 0: k = 3, bit 1: k = 5): 14-pixel strips for stride 1 -- 27 % fewer LDS reads per FMA
+  if constexpr (sizeof(T) == 2 && S == 1 && K <= 5) {
+    static const int wide_env = getenv("ATOMNAS_DW_BWD_SW14") ? atoi(getenv("ATOMNAS_DW_BWD_SW14")) : 0;
+    if (((wide_env >> (K == 3 ? 0 : 1)) & 1) && H > 7 && W >= 14 && C >= 32)
+      return launch_bwd_sw<T, K, S, 14>(gup, ldg, gss, yraw, ldyr, yrss, c1, c2, c3, x, ldx, xss, sc, sh, relu, w, ldw, h, ldh, hss, dw, stats,
+                                         stat_ld, part_rows, dw_ws, N, H, W, C, st);
+  }
+  return launch_bwd_sw<T, K, S, (S == 2) ? 14 : 7>(gup, ldg, gss, yraw, ldyr, yrss, c1, c2, c3, x, ldx, xss, sc, sh, relu, w, ldw, h, ldh, hss, dw,
+                                                    stats, stat_ld, part_rows, dw_ws, N, H, W, C, st);
 }
 
 #if DW_TIMING

@@ -1576,15 +1576,19 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
   return 0;
 }
 
-// V tile width.  Staging U (re-read per V tile) costs 2-3x staging V in the late layers (-DTN_TIMING), but 128-column V tiles on
-// 64-row slabs (same LDS) measured 10-25 % SLOWER there (tools/tnbench2.py), so they stay an experiment (ATOMNAS_TN_WIDE=1);
-// what did help the 320-column case is two U tiles of 160 columns instead of one of 320 (fewer accumulator registers).
+// V tile width.  The U slab is re-staged (transposed) for every V tile, so with a wide U (many accumulator tiles) a 128-column V tile
+// halves that work at the price of LDS / registers.  Measured in situ per shape (bs 256 step, after the early-stage weight gradients
+// moved into the fused backward kernels; profiles/r02_bs256_per_shape_timing.txt): NU 40..96 (4 / 6 accumulator tiles): 128 columns
+// on 64-row slabs -15..-30 %; NU 320 (two U tiles of 160): 128 columns on 128-row slabs -20 %; NU 192 (12 tiles): 64 columns stay
+// best (+20..35 % otherwise).  ATOMNAS_TN_WIDE = 0 / 1 / 2 forces one form (A/B).
 template <int UTT>
 static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
                          float* ws, long ws_floats, hipStream_t st) {
-  static const int wide_env = getenv("ATOMNAS_TN_WIDE") ? atoi(getenv("ATOMNAS_TN_WIDE")) : 0;
+  static const int wide_env = getenv("ATOMNAS_TN_WIDE") ? atoi(getenv("ATOMNAS_TN_WIDE")) : -1;
   if constexpr (UTT >= 4 && UTT <= 12) {
-    if (wide_env && NV >= 256) return launch_tn2_cfg<UTT, 2, 64>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+    const int wide = wide_env >= 0 ? wide_env : ((UTT == 4 || UTT == 6) ? 1 : (UTT == 10 ? 2 : 0));
+    if (wide == 1 && NV >= 256) return launch_tn2_cfg<UTT, 2, 64>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+    if (wide == 2 && NV >= 256) return launch_tn2_cfg<UTT, 2, 128>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
   }
   return launch_tn2_cfg<UTT, 1, 128>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
 }

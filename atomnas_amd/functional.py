@@ -140,6 +140,34 @@ def bn_backward_coeffs(bn, st, stats2, count, dev):
 
 # ---------------------------------------------------------------------------------------------- atomic block
 _FUSED_PROJECT_BWD = bool(int(os.environ.get("ATOMNAS_FUSED_PROJECT_BWD", "1")))   # experiment switch (A/B against the two-GEMM form)
+# experiment switch: the separate weight-gradient GEMMs of a block run on a side stream next to the input-gradient chain (they only
+# write the gradient arena); joined before the block's backward returns.
+_SIDE_WGRAD = bool(int(os.environ.get("ATOMNAS_SIDE_WGRAD", "0")))
+_side_stream = [None]
+
+
+class _Side:
+    def __enter__(self):
+        self.ctx = None
+        if _SIDE_WGRAD:
+            if _side_stream[0] is None:
+                _side_stream[0] = torch.cuda.Stream()
+            _side_stream[0].wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(_side_stream[0])
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def _join_side():
+    if _SIDE_WGRAD and _side_stream[0] is not None:
+        torch.cuda.current_stream().wait_stream(_side_stream[0])
+
+
 # experiment switch: fused expand backward per branch segment where the whole hidden width has no instance (40 -> 3 x 240).  Measured in
 # situ: 1.30 ms against 1.19 ms for the two GEMMs (x is re-staged and Gx re-read per segment): off
 _FUSED_EXPAND_SEG = bool(int(os.environ.get("ATOMNAS_FUSED_EXPAND_SEG", "0")))
@@ -231,12 +259,13 @@ def block_backward(pl, sv, G):
                else [(0, HT, pl.Wp_grad, HT)])
     # early stages (oup <= 48, no SE): the weight gradient rides in the input-gradient kernel below (one pass over D)
     fused_pb = (_FUSED_PROJECT_BWD and se is None and not pl.fused and pl.expand and ops.project_bwd_supported(pl.oup, HT, T))
-    for sg, nv, out, si in ([] if fused_pb else wp_jobs):
-        if se is not None:
-            ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
-        else:
-            ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
-                        vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
+    with _Side():
+        for sg, nv, out, si in ([] if fused_pb else wp_jobs):
+            if se is not None:
+                ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
+            else:
+                ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
+                            vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
     g = _hidden(pl, M2, HT, T, dev)
     st2D = _stats(HT, dev, pl.bnd["mgr"])
     if se is not None:
@@ -276,6 +305,7 @@ def block_backward(pl, sv, G):
             ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], E, None, None, 0, pl.taps[i], h, pl.Wd_grad[i], None, 0, N, H,
                            W, c, pl.ks[i], s)
     if not pl.expand:
+        _join_side()
         if pl.res:
             h = h + G
         return h
@@ -284,6 +314,7 @@ def block_backward(pl, sv, G):
     if pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and ops.expand_bwd_supported(pl.inp, HT, T):
         # early stages (16 -> 288, 24 -> 432): input and weight gradient of the expand convolution from ONE pass over h and E
         ops.expand_bwd(h, E, e1, e2, e3, x2d, pl.WeT_pack, G if pl.res else None, Gx, pl.We_grad, M, pl.inp, HT)
+        _join_side()
         return Gx
     if (_FUSED_EXPAND_SEG and pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and pl.nb > 1
             and all(ops.expand_bwd_supported(pl.inp, pl.segpad(hh), T) for hh in pl.hid)):
@@ -294,16 +325,19 @@ def block_backward(pl, sv, G):
             o, c = pl.seg[i], pl.segpad(pl.hid[i])
             ops.expand_bwd(_seg(h, o), _seg(E, o), e1[o:], e2[o:], e3[o:], x2d, pl.WeT_pack[:, o:], (G if pl.res else None) if i == 0 else Gx, Gx,
                            pl.We_grad[o * pl.inp:], M, pl.inp, c)
+        _join_side()
         return Gx
     # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k]); the
     # fused block's expand weight is one contiguous [total, inp] tensor: one launch per branch segment
     we_jobs = ([(sg, hh, pl.We_grad[stt * pl.inp:]) for sg, stt, hh in zip(pl.seg, pl.start, pl.hid)] if pl.fused
                else [(0, HT, pl.We_grad)])
-    for sg, nv, out in we_jobs:
-        ops.gemm_tn(x2d, pl.inp, _seg(h, sg), nv, out, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=_seg(E, sg), vc1=e1[sg:], vc2=e2[sg:],
-                    vc3=e3[sg:])
+    with _Side():
+        for sg, nv, out in we_jobs:
+            ops.gemm_tn(x2d, pl.inp, _seg(h, sg), nv, out, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=_seg(E, sg), vc1=e1[sg:], vc2=e2[sg:],
+                        vc3=e3[sg:])
     # expand input gradient (+ residual branch)
     ops.gemm_nt(h, pl.WeT_pack, Gx, M, pl.inp, HT, a_mode=PRO_BNBWD, a2=E, ac1=e1, ac2=e2, ac3=e3, add=G if pl.res else None)
+    _join_side()
     return Gx
 
 

@@ -196,7 +196,9 @@ def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,NU,NV", [(100, 24, 16), (1000, 24, 432), (3000, 40, 139), (700, 320, 1152), (257, 700, 40), (50, 3, 7)])
+@pytest.mark.parametrize("M,NU,NV", [(100, 24, 16), (1000, 24, 432), (3000, 40, 139), (700, 320, 1152), (257, 700, 40), (50, 3, 7),
+                                     # 128-column V tiles: 4 / 6 accumulator tiles on 64-row slabs, two U tiles of 160 on 128-row slabs
+                                     (2000, 96, 1728), (1500, 40, 720), (3100, 80, 300)])
 @pytest.mark.parametrize("variant", ["none_none", "none_bnbwd", "bnbwd_bnrelu"])
 def test_gemm_tn(gpu_lib, dtype, M, NU, NV, variant):
     ops = _ops()
