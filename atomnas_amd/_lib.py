@@ -56,6 +56,7 @@ NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version":
              "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32]),
              "atomnas_project_bwd_supported": (i32, [i32, i32, i32])}
 
+ABI_VERSION = 2   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None
 
 
@@ -85,6 +86,9 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
+    if lib.atomnas_abi_version() != ABI_VERSION:
+        raise AtomnasHipError("%s has ABI version %d, this package binds version %d: rebuild with `python -m atomnas_amd.build`"
+                              % (LIB_PATH, lib.atomnas_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -60,6 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
+#define ATOMNAS_ABI_VERSION 2   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
