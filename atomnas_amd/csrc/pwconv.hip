@@ -464,6 +464,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* 
 // (no weight traffic in the row loop), and the per-channel statistics are accumulated per lane across the rows and reduced
 // once at the end (the row-stationary kernel pays 128 cross-lane operations per tile for them).  A is re-read once per
 // chunk, from L2: it is the narrow operand (K/N of the output bytes).
+#ifndef CS_PREFETCH
+#define CS_PREFETCH 1   // experiment switch: 0 = every tile waits for its own loads
+#endif
 template <int MODE, int KSTEPS>
 __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K,
                                                     int nchunks, int tiles_per_item) {
@@ -496,16 +499,85 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
 
   const long mt_beg = range * tiles_per_item;
   const long mt_end = mt_beg + tiles_per_item < mtiles ? mt_beg + tiles_per_item : mtiles;
+  // The raw operands of the NEXT tile (A, its second stream, the epilogue's z) are in flight while the current tile is computed
+  // (up to 3 k-steps: with 6 the registers are gone).  Without it a wave waits out a full memory round trip per tile.
+  // Only where it does not cost a wave per SIMD: the plain-operand instances (the expand forward); with a prologue the extra
+  // registers take k_gemm_nt_cs<BNBWD, 3> from two waves per SIMD to one.
+  // Measured in situ (same box): K = 40 -8 %, K = 80 / 96 -6 / -14 %; K = 16 / 24 (one k-step, already 3 TB/s) 0 / +7 %: two and
+  // three k-steps only.
+  constexpr bool PF = CS_PREFETCH && (KSTEPS == 2 || KSTEPS == 3) && MODE == PRO_NONE;
+  struct Raw { bf16x8 a[KSTEPS], x[KSTEPS], z[2]; };
+  Raw nx;
+  auto fetch = [&](long mt) {
+    const long row = mt * 16 + j;
+    bf16x8 zero8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero8[e] = (bf16_t)0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int k = ks * 32 + 8 * q;
+      nx.a[ks] = zero8;
+      nx.x[ks] = zero8;
+      if (row < M && k < K) {
+        nx.a[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row, k, A.ld1, A.ss1));
+        if constexpr (MODE == PRO_BNBWD)
+          nx.x[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row, k, A.ld2, A.ss2));
+      }
+    }
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+      const int n8 = nb + 8 * h8;
+      nx.z[h8] = zero8;
+      if (ep.z && row < M && n8 < N) nx.z[h8] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss));
+    }
+  };
+  if constexpr (PF) {
+    if (mt_beg < mt_end) fetch(mt_beg);
+  }
   for (long mt = mt_beg; mt < mt_end; ++mt) {
     const long row = mt * 16 + j;
     const bool rowvalid = row < M;
+    Raw cur;
+    if constexpr (PF) {
+      cur = nx;
+      if (mt + 1 < mt_end) fetch(mt + 1);
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       float av[8];
-      load_pro<T, MODE>(A, row, rowvalid, ks * 32 + 8 * q, K, av);
+      if constexpr (PF) {
+        const int k = ks * 32 + 8 * q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = (float)cur.a[ks][e];
+        if (rowvalid && k < K) {
+          if constexpr (MODE == PRO_BNRELU) {
+            float sc[8], sh[8];
+            VecIO<float, 8>::load(A.c1 + k, sc);
+            VecIO<float, 8>::load(A.c2 + k, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = av[e] * sc[e] + sh[e];
+            act_apply_v<8>(av, act_of(A.relu));
+          } else if constexpr (MODE == PRO_BNBWD) {
+            float a1[8], a2[8], a3[8];
+            VecIO<float, 8>::load(A.c1 + k, a1);
+            VecIO<float, 8>::load(A.c2 + k, a2);
+            VecIO<float, 8>::load(A.c3 + k, a3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = a1[e] * av[e] + a2[e] * (float)cur.x[ks][e] + a3[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (k + e >= K) av[e] = 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) av[e] = 0.f;
+        }
+      } else {
+        load_pro<T, MODE>(A, row, rowvalid, ks * 32 + 8 * q, K, av);
+      }
       const typename MM::frag af = MM::pack(av);
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
@@ -536,7 +608,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
         for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
       }
       if (ep.z) {
-        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss), zv);
+        if constexpr (PF) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) zv[i] = (float)cur.z[h8][i];
+        } else {
+          VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss), zv);
+        }
         if (ep.mask) {
           float zs[8], zh[8];
           VecIO<float, 8>::load(ep.zscale + n8, zs);
