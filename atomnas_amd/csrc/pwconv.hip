@@ -1515,7 +1515,11 @@ static int launch_nt_ws(int mode, const Operand& A, const void* Wp, int ldw, con
   const size_t lds_stat = do_stats ? (size_t)8 * 64 * ncg * sizeof(float) : 0;
   // two 16-row subtiles per wave (each weight fragment read feeds two MFMAs) when there are enough 128-row blocks
   static const int rt_env = getenv("ATOMNAS_NT_WS_RT") ? atoi(getenv("ATOMNAS_NT_WS_RT")) : 0;
-  const int rt = rt_env ? rt_env : (M >= 32768 ? 2 : 1);   // measured in situ: 7x7 maps (M = 12544) prefer 64-row blocks
+  // measured in situ per shape (bs 256 step, same box, ATOMNAS_NT_WS_RT=1/2): one subtile per wave is faster wherever the prologue is
+  // BN-apply (the projection forward: M = 50176 -28 %, 200704 -15 %, 802816 -7 % -- the two-subtile BNRELU instance with two chunks
+  // needs 335 registers, one wave per SIMD) and on the small maps; two subtiles only pay with the two-stream BN-backward prologue
+  // on the large maps (M = 200704: -3 %)
+  const int rt = rt_env ? rt_env : ((mode == PRO_BNBWD && M >= 100000) ? 2 : 1);
 #define WS_LAUNCH(MODE, NCGV, RTV)                                                                                       \
   {                                                                                                                      \
     auto kern = k_gemm_nt_ws<MODE, NCGV, RTV>;                                                                           \
