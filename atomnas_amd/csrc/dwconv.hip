@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
 #endif
 
   // block reduction of the weight gradient and the statistics, one flush per workgroup: lanes l, l+C2, l+2*C2, ... of a
-  // wave hold the same channel pair -> butterfly over those first, then one LDS atomic per value from the first C2 lanes
+  // wave hold the same channel pair -> butterfly over those first, then the first C2 lanes of each wave add their values in LDS
   {
     const int lane = tid & 63;
 #pragma unroll

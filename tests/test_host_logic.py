@@ -238,3 +238,31 @@ def test_init_weights_mnas_reproduces_the_reference_under_a_seed():
     assert abs(float(conv.weight.std()) - math.sqrt(2.0 / 25)) < 0.02
     assert abs(float(dense.weight.std()) - math.sqrt(2.0 / 256)) < 0.005
     assert float(fc.weight.abs().max()) <= 1 / math.sqrt(1000) + 1e-7 and float(fc.bias.abs().max()) == 0.0
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every binding in atomnas_amd/_lib.py has the argument list of its prototype in include/atomnas_hip.h: same count, and per
+    position pointer / 32-bit int / 64-bit long / float / double.  (ctypes would silently pass a mis-sized argument.)"""
+    import ctypes
+    from atomnas_amd import _lib
+    header = open(os.path.join(ROOT, "include", "atomnas_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(?:int|const char\s*\*)\s+(atomnas_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, flags=re.S))
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_long: "long", ctypes.c_float: "float", ctypes.c_double: "double",
+             ctypes.c_ulonglong: "long", ctypes.c_char_p: "ptr"}
+
+    def kind_of(decl):
+        d = decl.strip()
+        if "*" in d:
+            return "ptr"
+        base = d.rsplit(None, 1)[0] if " " in d else d
+        base = base.replace("const", "").strip()
+        return {"int": "int", "long": "long", "unsigned long long": "long", "long long": "long", "float": "float", "double": "double"}[base]
+    table = dict(_lib.SIGNATURES)
+    table.update({k: v[1] for k, v in _lib.NO_STATUS.items()})
+    assert set(table) == set(protos), set(table) ^ set(protos)
+    for name, args in table.items():
+        decl = protos[name].strip()
+        want = [] if decl in ("", "void") else [kind_of(a) for a in decl.split(",")]
+        got = [kinds[a] for a in args]
+        assert got == want, (name, got, want)
