@@ -54,7 +54,8 @@ SIGNATURES = {
 }
 NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version": (i32, []),
              "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32]),
-             "atomnas_project_bwd_supported": (i32, [i32, i32, i32])}
+             "atomnas_project_bwd_supported": (i32, [i32, i32, i32]),
+             "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32])}
 
 ABI_VERSION = 2   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None

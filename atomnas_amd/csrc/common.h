@@ -197,6 +197,15 @@ static inline int resident_per_cu(KernelT kern, int threads, size_t lds) {
 int reduce_parts(const float* part, long part_stride, int parts, long n, float* out, int inner, long s_outer, long s_inner,
                  hipStream_t st);
 
+// dwconv_cw.hip: the stride-1 / slab-major instances of the depthwise entry points.  Return -1 when the case is not theirs
+// (the caller goes on with the tile kernels of dwconv.hip), otherwise the launch status.
+int dwconv_cw_fwd(const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y, long yss,
+                  float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int dtype, hipStream_t st);
+int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
+                  const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h, long hss,
+                  float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int dtype,
+                  hipStream_t st);
+
 #define ATOMNAS_REQUIRE(cond, ...)            \
   do {                                        \
     if (!(cond)) {                            \

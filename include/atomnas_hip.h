@@ -84,6 +84,11 @@ int atomnas_dwconv_bwd(const void* g, int ldg, long g_ss, const void* yraw, int 
                        const float* w, int ldw, void* h, int ldh, long h_ss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W,
                        int C, int k, int stride, int dtype, void* stream);
 
+/* 1 when the two entry points above run the stride-1 / slab-major "channel pair per wave" kernels (csrc/dwconv_cw.hip) for this
+ *   shape with slab-major tensors, 0 when they run the tile kernels (csrc/dwconv.hip); dir: 0 forward, 1 backward.  Same results
+ *   either way; a query for tests and launch-geometry tools. */
+int atomnas_dwconv_cw_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir);
+
 /* ---- pointwise (1x1) convolutions as MFMA GEMMs: models/mobilenet_base.py:316-320 (expand), :338 (project),
  *      models/mobilenet_supernet.py:148-153 (last conv), :160-163 (classifier); branches concatenated (:378).
  * C[M,N] = epilogue( prologue(A)[M,K] x Wp[N,K]^T )

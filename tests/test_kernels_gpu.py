@@ -230,6 +230,97 @@ def test_gemm_tn(gpu_lib, dtype, M, NU, NV, variant):
         assert_close("out", view(out), ref, rtol=2e-3 if dtype == torch.bfloat16 else 2e-4, atol=2e-3 * float(ref.abs().max()))
 
 
+# ---------------------------------------------------------------------------------------------- channel-pair-per-wave depthwise kernels
+# csrc/dwconv_cw.hip: stride 1, slab-major tensors, width a multiple of 7 -- the instances the hidden tensors of the expanding
+# blocks take.  Cases: several whole images per tile (7x7, 14x14; the last tile partly empty), one whole image per tile (30x14),
+# row-ring tiles (28x28, 56x56, a ragged last tile at 44x28), 3 strips per row (pitch rule for non-powers of two), channel
+# counts that leave the last slab / the last 8-channel group partly or wholly empty.
+CW_SHAPES = [(10, 16, 7, 7), (3, 48, 14, 14), (2, 24, 56, 56), (5, 40, 28, 28), (2, 13, 21, 21), (1, 70, 28, 28), (2, 32, 30, 14),
+             (2, 16, 44, 28), (3, 5, 14, 14)]
+
+
+def _cw_supported(N, H, W, C, k, dtype, direction):
+    from atomnas_amd import _lib
+    return bool(_lib.load().atomnas_dwconv_cw_supported(N, H, W, C, k, 1, 0 if dtype == torch.float32 else 1, direction))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [3, 5, 7])
+@pytest.mark.parametrize("N,C,H,W", CW_SHAPES)
+def test_dwconv_fwd_cw(gpu_lib, dtype, k, N, C, H, W):
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    assert _cw_supported(N, H, W, C, k, dtype, 0) or os.environ.get("ATOMNAS_DW_CW") is not None
+    g = torch.Generator().manual_seed(3000 * k + C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.3
+    for fuse in (False, True):
+        xr = rounded(x, dtype)
+        xa = torch.relu(xr * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)) if fuse else xr
+        yref = F.conv2d(xa, w.double(), None, 1, (k - 1) // 2, 1, C)
+        ys = Slab.from_plain(fresh(N * H * W, C, dtype), C)   # poisoned valid region: unwritten elements are caught
+        stats = poisoned_stats(48 if k == 5 else 64, C)
+        ops.dwconv_fwd(_slab(to_act(x, dtype), C), cvec(sc) if fuse else None, cvec(sh) if fuse else None, fuse, taps(w), ys, stats, C, N,
+                       H, W, C, k, 1)
+        torch.cuda.synchronize()
+        yp = ys.to_plain()
+        y = from_act(yp, N, H, W, C)
+        assert_close("y", y, yref, **tol(dtype))
+        assert float(yp[:, C:].float().abs().max() if yp.shape[1] > C else 0) == 0.0
+        stats = stats.sum(0)
+        assert_close("sum", stats[0], y.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+        assert_close("sumsq", stats[1], (y * y).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [3, 5, 7])
+@pytest.mark.parametrize("N,C,H,W", CW_SHAPES)
+def test_dwconv_bwd_cw(gpu_lib, dtype, k, N, C, H, W):
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    assert _cw_supported(N, H, W, C, k, dtype, 1) or os.environ.get("ATOMNAS_DW_CW") is not None
+    g = torch.Generator().manual_seed(4000 * k + C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.3
+    P = (k - 1) // 2
+    gup = torch.randn(N, C, H, W, generator=g)
+    yraw = torch.randn(N, C, H, W, generator=g)
+    c1 = torch.rand(C, generator=g) + 0.5
+    c2 = torch.randn(C, generator=g) * 0.1
+    c3 = torch.randn(C, generator=g) * 0.1
+    for fuse in (False, True):
+        v = lambda t: t.double().view(1, -1, 1, 1)
+        xr = rounded(x, dtype).requires_grad_(True)
+        pre = xr * v(sc) + v(sh) if fuse else xr
+        xa = torch.relu(pre) if fuse else pre
+        wd = w.double().requires_grad_(True)
+        y = F.conv2d(xa, wd, None, 1, P, 1, C)
+        dy = v(c1) * rounded(gup, dtype) + v(c2) * rounded(yraw, dtype) + v(c3) if fuse else rounded(gup, dtype)
+        xa.retain_grad()
+        (y * dy).sum().backward()
+        href = xa.grad * (pre > 0).double() if fuse else xa.grad
+        hs = Slab.from_plain(fresh(N * H * W, C, dtype), C)
+        dw = torch.zeros(C, k * k, dtype=torch.float32, device="cuda")
+        stats = poisoned_stats(48 if k == 5 else 64, C)
+        ops.dwconv_bwd(_slab(to_act(gup, dtype), C), _slab(to_act(yraw, dtype), C) if fuse else None, cvec(c1) if fuse else None,
+                       cvec(c2) if fuse else None, cvec(c3) if fuse else None, _slab(to_act(x, dtype), C), cvec(sc) if fuse else None,
+                       cvec(sh) if fuse else None, fuse, taps(w), hs, dw, stats, C, N, H, W, C, k, 1)
+        torch.cuda.synchronize()
+        hp = hs.to_plain()
+        h = from_act(hp, N, H, W, C)
+        t = tol(dtype)
+        assert_close("h", h, href, t["rtol"], t["atol"] * 4)
+        assert float(hp[:, C:].float().abs().max() if hp.shape[1] > C else 0) == 0.0
+        assert_close("dw", dw.reshape(C, 1, k, k), wd.grad, rtol=2e-3, atol=2e-3 * float(wd.grad.abs().max()))
+        stats = stats.sum(0)
+        assert_close("sum_h", stats[0], h.sum((0, 2, 3)), rtol=1e-4, atol=2e-3)
+        assert_close("sum_hx", stats[1], (h * rounded(x, dtype)).sum((0, 2, 3)), rtol=1e-4, atol=2e-3)
+
+
 def test_dwconv_long_tile_walks():
     """The depthwise kernels keep the halo rows of the tile above in their LDS ring when a workgroup walks down a column of
     tiles.  With the small tensors of the tests every workgroup normally gets a single tile, so the same cases are re-run
@@ -257,6 +348,8 @@ def test_dwconv_slab_layout_is_bit_identical_to_plain(gpu_lib, k, stride, N, C, 
     ops = _ops()
     from atomnas_amd.ops import Slab
     dtype = torch.bfloat16
+    if stride == 1 and _cw_supported(N, H, W, C, k, dtype, 0):
+        pytest.skip("slab-major stride-1 tensors of this shape run csrc/dwconv_cw.hip (other summation order): test_dwconv_*_cw")
     g = torch.Generator().manual_seed(k * 100 + C)
     P = (k - 1) // 2
     Ho, Wo = (H + 2 * P - k) // stride + 1, (W + 2 * P - k) // stride + 1
