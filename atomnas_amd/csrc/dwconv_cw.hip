@@ -10,7 +10,8 @@
 //     the pair are then wave-uniform and live in scalar registers (s_load), not in LDS: per tap row a lane reads only its
 //     7 + k - 1 operand pairs (13 ds_read_b64 for k = 7, where the tile kernels read 20 of which the compiler merged pairs into
 //     half-rate ds_read2_b64) for 98 packed FMAs, and no vector register holds a weight.
-//   * the 8 waves of a 512-thread workgroup are the 8 channel pairs of one 16-channel slab; a tile is TH rows of the FULL image
+//   * the waves of a workgroup are the channel pairs of one 16-channel slab (8 waves) or of its 8-channel half (4 waves, so that
+//     two to four workgroups per CU overlap each other's load / commit / compute phases); a tile is TH rows of the FULL image
 //     width (or several whole images of a small map), so there is no horizontal halo, and the operand window is a ring over
 //     rows, so there is no vertical halo either: every activation byte is read from HBM exactly once.
 //   * LDS operand planes are [channel pair][row][column] with a row pitch chosen per strips-per-row so that the 32 lanes of an
@@ -24,7 +25,25 @@
 #include "common.h"
 #include <cstdlib>
 
+#ifndef CW_TIMING
+#define CW_TIMING 0   // experiment builds (tools/variant.sh): s_memtime accounting of the phases of a tile in the backward kernel
+#endif
+
 namespace atomnas {
+
+#if CW_TIMING
+__device__ unsigned long long g_cw_timing[8];
+#define CWMARK(i)                                                    \
+  {                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    const unsigned long long tn_ = __builtin_readcyclecounter();     \
+    tacc[i] += tn_ - tlast;                                          \
+    tlast = tn_;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  }
+#else
+#define CWMARK(i)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -55,6 +74,7 @@ template <> struct Cw<bf16_t> {
     return __builtin_bit_cast(unsigned, t);
   }
   static __device__ __forceinline__ pair_t zero_pair() { return 0u; }
+  static __device__ __forceinline__ void touch(const piece_t& p) { asm volatile("" ::"v"(p.v)); }   // "the register is read here"
 };
 template <> struct Cw<float> {
   typedef f32x2 pair_t;
@@ -76,6 +96,7 @@ template <> struct Cw<float> {
   static __device__ __forceinline__ float hi(pair_t v) { return v[1]; }
   static __device__ __forceinline__ pair_t pack(float a, float b) { return f32x2{a, b}; }
   static __device__ __forceinline__ pair_t zero_pair() { return f32x2{0.f, 0.f}; }
+  static __device__ __forceinline__ void touch(const piece_t& p) { asm volatile("" ::"v"(p.a), "v"(p.b)); }
 };
 
 __device__ __forceinline__ float cw_act(float a, int in_relu, int AM) {
@@ -89,6 +110,22 @@ __device__ __forceinline__ float cw_act_bwd(float c, float a, int in_relu, int A
   return (in_relu && !(a > 0.f)) ? 0.f : c;
 }
 
+// Sum over the 64 lanes of a wave with DPP adds only (no LDS traffic): quad butterflies, half-row and row mirrors leave every
+// lane with the sum of its 16-lane row; row_bcast15 / row_bcast31 then carry the row sums upwards.  The total is valid in
+// lanes 48..63 (lane 63 is read); the order of the additions is fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float cw_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float cw_wave_sum63(float v) {
+  v += cw_dpp<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += cw_dpp<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += cw_dpp<0x141, 0xF>(v);   // row_half_mirror
+  v += cw_dpp<0x140, 0xF>(v);   // row_mirror
+  v += cw_dpp<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v += cw_dpp<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  return v;
+}
 // value of lane `l` (compile-time constant) as a wave-uniform scalar
 __device__ __forceinline__ float cw_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -108,8 +145,8 @@ __device__ __forceinline__ void cw_read_row(f32x2 (&v)[NR], unsigned addr) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// Tile-independent decode of the two staging slots of a thread: slot i of thread tid is 16-byte piece (tid + i * 512) of the tile,
-// pieces run over (image, row, column, channel group) with the channel group fastest (512 is even: cg = tid & 1 for both slots).
+// Tile-independent decode of the two staging slots of a thread: slot i of thread tid is 16-byte piece (tid + i * NT) of the tile;
+// pieces run over (image, row, column, channel group of the workgroup) with the channel group fastest.
 struct CwSlots {
   int pp[2];     // pixel index inside the tile (im, row, col) -> also the index into the pixel planes; -1: no such piece
   int rr[2];     // row inside the tile
@@ -117,11 +154,11 @@ struct CwSlots {
   int goff[2];   // element offset inside the slab relative to the tile's first pixel: ((im * H + rr) * W + col) * 16 + cg * 8
   int im[2];
 };
-template <int P>
-__device__ __forceinline__ void cw_decode(CwSlots& s, const CwGeom& g, int tid) {
+template <int P, int NT, int CGS>
+__device__ __forceinline__ void cw_decode(CwSlots& s, const CwGeom& g, int tid, int cg) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int pp = (tid + i * 512) >> 1;
+    const int pp = (tid + i * NT) / CGS;
     const bool ok = pp < g.TPIX;
     const int col = pp % g.W, t2 = pp / g.W;
     const int rr = t2 % g.TH, im = t2 / g.TH;
@@ -129,15 +166,31 @@ __device__ __forceinline__ void cw_decode(CwSlots& s, const CwGeom& g, int tid) 
     s.rr[i] = rr;
     s.im[i] = im;
     s.dyo[i] = im * g.LH * g.LWp + col + P;
-    s.goff[i] = ((im * g.H + rr) * g.W + col) * 16 + (tid & 1) * 8;
+    s.goff[i] = ((im * g.H + rr) * g.W + col) * 16 + cg * 8;
   }
+}
+
+// Workgroup -> (slab, worker, half).  NW = 8: the 8 waves are the 8 channel pairs of a slab.  NW = 4: a workgroup owns 8 of the 16
+// channels (the 16-byte half of every 32-byte pixel); blocks b and b + 8 -- the same XCD, i.e. the same L2, under the observed
+// round-robin placement -- are the two halves of one (slab, worker), so the shared 128-byte lines are fetched from HBM once.
+template <int NW>
+__device__ __forceinline__ bool cw_block(const CwGeom& g, int& slab, int& worker, int& half) {
+  if (NW == 8) {
+    slab = blockIdx.x % g.nslabs; worker = blockIdx.x / g.nslabs; half = 0;
+    return true;
+  }
+  const int q = blockIdx.x >> 3;
+  half = q & 1;
+  const int u = (q >> 1) * 8 + (blockIdx.x & 7);
+  slab = u % g.nslabs; worker = u / g.nslabs;
+  return worker < g.nworkers;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward
 //   dYraw = c1*g + c2*yraw + c3 (BN-backward of the BN behind the conv, on load; yraw == NULL: dYraw = g)
 //   h = dwconv^T(dYraw) * act'(x*in_scale+in_shift),  dW += corr(act(x*in_scale+in_shift), dYraw),  stats: sum h, sum h*x
-template <typename T, int K, int AM, int WPS>
-__global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, long gss, const T* __restrict__ yraw, long yrss,
+template <typename T, int K, int AM, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ gup, long gss, const T* __restrict__ yraw, long yrss,
                                                      const float* __restrict__ c1, const float* __restrict__ c2p,
                                                      const float* __restrict__ c3, const T* __restrict__ x, long xss,
                                                      const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -147,22 +200,24 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
   typedef Cw<T> X;
   typedef typename X::pair_t pair_t;
   typedef typename X::piece_t piece_t;
-  constexpr int P = (K - 1) / 2, KK = K * K, SW = 7, DWN = SW + K - 1;
+  constexpr int P = (K - 1) / 2, KK = K * K, SW = 7, DWN = SW + K - 1, NT = NW * 64, CGS = NW / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x2* s_dy = reinterpret_cast<f32x2*>(smem);                    // [8 pairs][plane]: dYraw window, fp32
-  pair_t* s_x = reinterpret_cast<pair_t*>(s_dy + 8 * g.plane);      // [8 pairs][TPIXp]: raw input pixels, replaced by h in place
-  float* s_cf = reinterpret_cast<float*>(s_x + 8 * g.TPIXp);        // [3][16] BN-backward coefficients of the slab
+  f32x2* s_dy = reinterpret_cast<f32x2*>(smem);                    // [NW pairs][plane]: dYraw window, fp32
+  pair_t* s_x = reinterpret_cast<pair_t*>(s_dy + NW * g.plane);     // [NW pairs][TPIXp]: raw input pixels, replaced by h in place
+  float* s_cf = reinterpret_cast<float*>(s_x + NW * g.TPIXp);       // [3][16] BN-backward coefficients of the slab
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);           // channel pair of this wave (wave-uniform)
-  const int slab = blockIdx.x % g.nslabs, worker = blockIdx.x / g.nslabs;
+  int slab, worker, half;
+  if (!cw_block<NW>(g, slab, worker, half)) return;   // surplus block of the padded half-slab grid (whole workgroup, before any barrier)
   const int c_base = slab * 16;
-  const int ch = c_base + 2 * wv;
+  const int ch = c_base + 2 * (wv + 4 * half);
   const int cpad = (g.C + 7) & ~7;
-  const int cg = tid & 1;
+  const int cgl = CGS == 2 ? (tid & 1) : 0;   // channel group inside the workgroup's planes
+  const int cg = cgl + half;                   // channel group inside the slab
   const bool cg_ok = c_base + cg * 8 < cpad;
 
-  for (int i = tid; i < 8 * g.plane; i += 512) s_dy[i] = f32x2{0.f, 0.f};   // halo columns / rows outside the image stay zero
+  for (int i = tid; i < NW * g.plane; i += NT) s_dy[i] = f32x2{0.f, 0.f};   // halo columns / rows outside the image stay zero
   if (tid < 48) {
     const int v = tid >> 4, c = c_base + (tid & 15);
     const float* src = (v == 0) ? c1 : (v == 1 ? c2p : c3);
@@ -182,7 +237,7 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
   }
 
   CwSlots sl;
-  cw_decode<P>(sl, g, tid);
+  cw_decode<P, NT, CGS>(sl, g, tid, cg);
 
   // work item of this lane: (image, row, strip) -- tile-independent
   const int ipi = g.TH * g.ns;
@@ -206,23 +261,24 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
   const long slab_g = (long)slab * gss, slab_y = (long)slab * yrss, slab_x = (long)slab * xss, slab_h = (long)slab * hss;
 
   // issue the HBM loads of a tile (n0 = first image, hi0 = first row): dY rows [ho_s, ho_s + TH), input rows [hi0, hi0 + TH)
+  // Branch-free: a piece that does not exist (image / row beyond the tensor, channel group beyond C) reads the first piece of the
+  // slab instead and is masked at the commit.  (With the loads under per-lane branches hipcc cannot prove at the loop back-edge
+  // that they were waited for, and puts an s_waitcnt vmcnt(0) in front of the next tile's loads: that wait also covers the h
+  // stores issued just before -- 20 to 30 % of the kernel in the first measurements.)
   auto issue = [&](int n0, int hi0) {
     const int ho_s = g.ring ? hi0 + P : 0;
     const long pg = ((long)n0 * g.H + ho_s) * g.W * 16, px = ((long)n0 * g.H + hi0) * g.W * 16;
     pfmask = 0; pxmask = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N) {
-        if (ho_s + sl.rr[i] < g.H) {
-          X::load(pfg[i], gup + slab_g + pg + sl.goff[i]);
-          if (yraw) X::load(pfy[i], yraw + slab_y + pg + sl.goff[i]);
-          pfmask |= 1u << i;
-        }
-        if (hi0 + sl.rr[i] < g.H) {
-          X::load(pfx[i], x + slab_x + px + sl.goff[i]);
-          pxmask |= 1u << i;
-        }
-      }
+      const bool in_n = sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N;
+      const bool okg = in_n && ho_s + sl.rr[i] < g.H, okx = in_n && hi0 + sl.rr[i] < g.H;
+      const long og = okg ? pg + sl.goff[i] : 0, ox = okx ? px + sl.goff[i] : 0;
+      X::load(pfg[i], gup + slab_g + og);
+      if (yraw) X::load(pfy[i], yraw + slab_y + og);
+      X::load(pfx[i], x + slab_x + ox);
+      pfmask |= okg ? 1u << i : 0u;
+      pxmask |= okx ? 1u << i : 0u;
     }
   };
   // dYraw of one piece -> the four pair planes of this thread's channel group
@@ -245,8 +301,8 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
       if (sl.pp[i] >= 0) {
         int slot = (g.ring ? 2 * P : P) + sl.rr[i] + base;
         if (slot >= g.LH) slot -= g.LH;
-        put_dy(pfg[i], pfy[i], (pfmask >> i) & 1u, s_dy + (cg * 4) * g.plane + sl.dyo[i] + slot * g.LWp);
-        pair_t* dx_ = s_x + (cg * 4) * g.TPIXp + sl.pp[i];
+        put_dy(pfg[i], pfy[i], (pfmask >> i) & 1u, s_dy + (cgl * 4) * g.plane + sl.dyo[i] + slot * g.LWp);
+        pair_t* dx_ = s_x + (cgl * 4) * g.TPIXp + sl.pp[i];
         const bool okx = (pxmask >> i) & 1u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) dx_[q * g.TPIXp] = okx ? X::pair(pfx[i], q) : X::zero_pair();
@@ -255,9 +311,9 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
   };
   // first tile of an image (or of this worker): the 2P window rows above the tile's own rows, loaded synchronously
   auto halo_sync = [&](int n0, int hi0) {
-    const int npc = 2 * P * g.W * 2;
-    for (int p = tid; p < npc; p += 512) {
-      const int col = (p >> 1) % g.W, wr = (p >> 1) / g.W;
+    const int npc = 2 * P * g.W * CGS;
+    for (int p = tid; p < npc; p += NT) {
+      const int col = (p / CGS) % g.W, wr = (p / CGS) / g.W;
       const int ho = hi0 - P + wr;
       piece_t a, b;
       X::zero(a); X::zero(b);
@@ -267,7 +323,7 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
         X::load(a, gup + slab_g + off);
         if (yraw) X::load(b, yraw + slab_y + off);
       }
-      put_dy(a, b, ok, s_dy + (cg * 4) * g.plane + wr * g.LWp + col + P);
+      put_dy(a, b, ok, s_dy + (cgl * 4) * g.plane + wr * g.LWp + col + P);
     }
   };
   auto store_h = [&](int n0, int hi0) {
@@ -276,7 +332,7 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
     for (int i = 0; i < 2; ++i) {
       if (sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N && hi0 + sl.rr[i] < g.H) {
         piece_t v;
-        const pair_t* sx_ = s_x + (cg * 4) * g.TPIXp + sl.pp[i];
+        const pair_t* sx_ = s_x + (cgl * 4) * g.TPIXp + sl.pp[i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) X::set_pair(v, q, sx_[q * g.TPIXp]);
         X::store(v, h + slab_h + px + sl.goff[i]);
@@ -289,18 +345,33 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
   if (tile < t_end) issue(nb * g.NI, ty * g.TH);
   int base = 0;
   int pn0 = -1, phi0 = 0;   // tile whose result waits in s_x
+#if CW_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
   for (; tile < t_end; ++tile) {
     const int n0 = nb * g.NI, hi0 = ty * g.TH;
     const bool fresh = g.ring && (tile == t_beg || ty == 0);
     if (fresh) base = 0;
+    CWMARK(6)
+    // opaque per tile: the 64-bit global addresses of the slots are formed where they are used.  (Hoisted out of the tile loop they
+    // are spilled, and every reload waits for vmcnt(0), i.e. for all loads and stores issued before it: the prefetch serialises.)
+    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]));
     __syncthreads();   // (A) previous tile consumed, its h complete in s_x (first pass: also orders the LDS initialisation)
+    CWMARK(0)
+    // every prefetched register is consumed here on every path: nothing is pending when the next tile's loads overwrite them
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { X::touch(pfg[i]); X::touch(pfy[i]); X::touch(pfx[i]); }
     if (pn0 >= 0) store_h(pn0, phi0);
     commit(base);
     if (fresh) halo_sync(n0, hi0);
+    CWMARK(1)
     __syncthreads();   // (B) window and pixel planes complete
+    CWMARK(2)
     int nnb = nb, nty = ty + 1;
     if (nty == g.tiles_y) { nty = 0; ++nnb; }
     if (tile + 1 < t_end) issue(nnb * g.NI, nty * g.TH);
+    CWMARK(3)
 
     // opaque per tile (in uniform control flow: every lane of the table stays defined): the 2 k^2 broadcasts stay in their tap rows
     // instead of being hoisted out of the tile loop, where they spill
@@ -317,6 +388,7 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
         dx[t] = f32x2{0.f, 0.f};
         asm volatile("" : "+v"(xa[t]));   // computed here, not sunk behind the tap rows (that keeps every operand row alive)
       }
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         int slot = it_r + (K - 1 - ky) + base;
@@ -339,6 +411,8 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
       }
       // epilogue: activation backward of the producer, rounding, statistics; h replaces x in its LDS slot
 #pragma unroll
+      for (int t = 0; t < SW; ++t) xq[t] = xp[t];   // read again: the raw pixels are not kept in registers across the tap rows
+#pragma unroll
       for (int t = 0; t < SW; ++t) {
         const float x0 = X::lo(xq[t]), x1 = X::hi(xq[t]);
         float v0 = cw_act_bwd(dx[t][0], x0 * sc0 + sh0, in_relu, AM);
@@ -352,66 +426,98 @@ __global__ __launch_bounds__(512, WPS) void k_dwb_cw(const T* __restrict__ gup, 
         xp[t] = o;
       }
     }
+    CWMARK(4)
     pn0 = n0; phi0 = hi0;
     nb = nnb; ty = nty;
     if (g.ring) { base += g.TH; if (base >= g.LH) base -= g.LH; }
   }
   __syncthreads();
   if (pn0 >= 0) store_h(pn0, phi0);
+  CWMARK(5)
 
-  // all 64 lanes of a wave hold the same channel pair: butterfly sums (fixed order), lane 0 owns row `worker` of the partial buffers
+  // Weight-gradient flush.  All 64 lanes of a wave hold partial sums of the SAME 2 k^2 values (tap t of channel e = value e k^2 + t,
+  // which is also its position in this wave's 2 k^2 consecutive floats of the partial row).  Cross-lane sums with 6 DPP steps per
+  // value are ~1300 instructions of straight-line code that run once -- measured 30-45 us per launch, mostly instruction-cache
+  // misses.  Instead: the wave transposes G = 14 values at a time through its own (now unused) operand plane -- lane l writes
+  // row l of a [64][G + 1] matrix -- and lane q * G + v adds quarter q (16 lanes, in lane order) of value v; the four quarters are
+  // added in order by lane v, which stores the total.  Fixed order, coalesced stores, a few hundred instructions.
+  {
+    constexpr int G = 14, NV = 2 * KK;
+    float* red = reinterpret_cast<float*>(s_dy + wv * g.plane);   // 64 * (G + 1) + 4 * G floats <= 2 * plane (cw_geometry)
+    float* red2 = red + 64 * (G + 1);
+    float* drow = dwp ? dwp + ((long)worker * g.C + ch) * KK : nullptr;
+    const int nvalid = ch1_ok ? NV : (ch0_ok ? KK : 0);
+    const int rq = lane / G, rv = lane - rq * G;   // quarter and value of this lane in the column sums (lanes 0 .. 4G-1)
 #pragma unroll
-  for (int t = 0; t < KK; ++t) { dwa[t][0] = wave_sum(dwa[t][0]); dwa[t][1] = wave_sum(dwa[t][1]); }
-  s0a = wave_sum(s0a); s0b = wave_sum(s0b); s1a = wave_sum(s1a); s1b = wave_sum(s1b);
-  if (lane == 0) {
+    for (int r0 = 0; r0 < NV; r0 += G) {
+#pragma unroll
+      for (int v = 0; v < G; ++v)
+        if (r0 + v < NV) red[lane * (G + 1) + v] = (r0 + v < KK) ? dwa[(r0 + v) % KK][0] : dwa[(r0 + v) % KK][1];
+      __builtin_amdgcn_wave_barrier();
+      float part = 0.f;
+      if (lane < 4 * G) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) part += red[(rq * 16 + i) * (G + 1) + rv];
+        red2[lane] = part;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < G && drow && r0 + lane < nvalid) drow[r0 + lane] = ((red2[lane] + red2[G + lane]) + red2[2 * G + lane]) + red2[3 * G + lane];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // BN-backward statistics of the pair: 4 values, DPP sums (fixed order), lane 63 owns row `worker` of the partial buffer
+  s0a = cw_wave_sum63(s0a); s0b = cw_wave_sum63(s0b); s1a = cw_wave_sum63(s1a); s1b = cw_wave_sum63(s1b);
+  if (lane == 63 && stats) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int c = ch + e;
       if (c < g.C) {
-        if (dwp) {
-          float* d = dwp + ((long)worker * g.C + c) * KK;
-#pragma unroll
-          for (int t = 0; t < KK; ++t) d[t] = dwa[t][e];
-        }
-        if (stats) {
-          const float v0 = e ? s0b : s0a, v1 = e ? s1b : s1a;
-          float* r = stats + (long)worker * 2 * stat_ld;
-          r[c] = v0;
-          r[stat_ld + c] = v1;
-          stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, c);
-          stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, (long)stat_ld + c);
-        }
+        const float v0 = e ? s0b : s0a, v1 = e ? s1b : s1a;
+        float* r = stats + (long)worker * 2 * stat_ld;
+        r[c] = v0;
+        r[stat_ld + c] = v1;
+        stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, c);
+        stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, (long)stat_ld + c);
       }
     }
   }
+#if CW_TIMING
+  CWMARK(7)
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_cw_timing[i], tacc[i]);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------- forward
 //   y = dwconv(act(x*in_scale+in_shift)),  stats: sum y, sum y^2 (of the stored values)
-template <typename T, int K, int AM, int WPS>
-__global__ __launch_bounds__(512, WPS) void k_dwf_cw(const T* __restrict__ x, long xss, const float* __restrict__ in_scale,
+template <typename T, int K, int AM, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void k_dwf_cw(const T* __restrict__ x, long xss, const float* __restrict__ in_scale,
                                                      const float* __restrict__ in_shift, int in_relu, const float* __restrict__ w,
                                                      int ldw, T* __restrict__ y, long yss, float* __restrict__ stats, int stat_ld,
                                                      int stat_rows, CwGeom g) {
   typedef Cw<T> X;
   typedef typename X::pair_t pair_t;
   typedef typename X::piece_t piece_t;
-  constexpr int P = (K - 1) / 2, SW = 7, IWN = SW + K - 1;
+  constexpr int P = (K - 1) / 2, SW = 7, IWN = SW + K - 1, NT = NW * 64, CGS = NW / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x2* s_in = reinterpret_cast<f32x2*>(smem);                     // [8 pairs][plane]: activated input window, fp32
-  pair_t* s_y = reinterpret_cast<pair_t*>(s_in + 8 * g.plane);       // [8 pairs][TPIXp]: the tile's output
-  float* s_cf = reinterpret_cast<float*>(s_y + 8 * g.TPIXp);         // [2][16] scale / shift of the slab
+  f32x2* s_in = reinterpret_cast<f32x2*>(smem);                     // [NW pairs][plane]: activated input window, fp32
+  pair_t* s_y = reinterpret_cast<pair_t*>(s_in + NW * g.plane);      // [NW pairs][TPIXp]: the tile's output
+  float* s_cf = reinterpret_cast<float*>(s_y + NW * g.TPIXp);        // [2][16] scale / shift of the slab
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slab = blockIdx.x % g.nslabs, worker = blockIdx.x / g.nslabs;
+  int slab, worker, half;
+  if (!cw_block<NW>(g, slab, worker, half)) return;   // surplus block of the padded half-slab grid (whole workgroup, before any barrier)
   const int c_base = slab * 16;
-  const int ch = c_base + 2 * wv;
+  const int ch = c_base + 2 * (wv + 4 * half);
   const int cpad = (g.C + 7) & ~7;
-  const int cg = tid & 1;
+  const int cgl = CGS == 2 ? (tid & 1) : 0;   // channel group inside the workgroup's planes
+  const int cg = cgl + half;                   // channel group inside the slab
   const bool cg_ok = c_base + cg * 8 < cpad;
 
-  for (int i = tid; i < 8 * g.plane; i += 512) s_in[i] = f32x2{0.f, 0.f};
+  for (int i = tid; i < NW * g.plane; i += NT) s_in[i] = f32x2{0.f, 0.f};
   if (tid < 32) {
     const int v = tid >> 4, c = c_base + (tid & 15);
     s_cf[tid] = (in_scale && c < cpad) ? (v == 0 ? in_scale[c] : in_shift[c]) : (v == 0 ? 1.f : 0.f);
@@ -425,7 +531,7 @@ __global__ __launch_bounds__(512, WPS) void k_dwf_cw(const T* __restrict__ x, lo
   }
 
   CwSlots sl;
-  cw_decode<P>(sl, g, tid);
+  cw_decode<P, NT, CGS>(sl, g, tid, cg);
   const int ipi = g.TH * g.ns;
   const int it_im = lane / ipi, it_rem = lane % ipi;
   const int it_r = it_rem / g.ns, it_j = it_rem % g.ns;
@@ -442,16 +548,15 @@ __global__ __launch_bounds__(512, WPS) void k_dwf_cw(const T* __restrict__ x, lo
   const int t_beg = (int)((long)worker * g.ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * g.ntiles / g.nworkers);
   const long slab_x = (long)slab * xss, slab_y = (long)slab * yss;
 
-  auto issue = [&](int n0, int ho0) {
+  auto issue = [&](int n0, int ho0) {   // branch-free, see k_dwb_cw
     const int hi_s = g.ring ? ho0 + P : 0;
     const long px = ((long)n0 * g.H + hi_s) * g.W * 16;
     pxmask = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N && hi_s + sl.rr[i] < g.H) {
-        X::load(pfx[i], x + slab_x + px + sl.goff[i]);
-        pxmask |= 1u << i;
-      }
+      const bool okx = sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N && hi_s + sl.rr[i] < g.H;
+      X::load(pfx[i], x + slab_x + (okx ? px + sl.goff[i] : 0));
+      pxmask |= okx ? 1u << i : 0u;
     }
   };
   auto put_in = [&](const piece_t& p, bool ok, f32x2* d) {
@@ -472,20 +577,20 @@ __global__ __launch_bounds__(512, WPS) void k_dwf_cw(const T* __restrict__ x, lo
       if (sl.pp[i] >= 0) {
         int slot = (g.ring ? 2 * P : P) + sl.rr[i] + base;
         if (slot >= g.LH) slot -= g.LH;
-        put_in(pfx[i], (pxmask >> i) & 1u, s_in + (cg * 4) * g.plane + sl.dyo[i] + slot * g.LWp);
+        put_in(pfx[i], (pxmask >> i) & 1u, s_in + (cgl * 4) * g.plane + sl.dyo[i] + slot * g.LWp);
       }
     }
   };
   auto halo_sync = [&](int n0, int ho0) {
-    const int npc = 2 * P * g.W * 2;
-    for (int p = tid; p < npc; p += 512) {
-      const int col = (p >> 1) % g.W, wr = (p >> 1) / g.W;
+    const int npc = 2 * P * g.W * CGS;
+    for (int p = tid; p < npc; p += NT) {
+      const int col = (p / CGS) % g.W, wr = (p / CGS) / g.W;
       const int hi = ho0 - P + wr;
       piece_t a;
       X::zero(a);
       const bool ok = cg_ok && hi >= 0 && hi < g.H && n0 < g.N;
       if (ok) X::load(a, x + slab_x + (((long)n0 * g.H + hi) * g.W + col) * 16 + cg * 8);
-      put_in(a, ok, s_in + (cg * 4) * g.plane + wr * g.LWp + col + P);
+      put_in(a, ok, s_in + (cgl * 4) * g.plane + wr * g.LWp + col + P);
     }
   };
   auto store_y = [&](int n0, int ho0) {
@@ -494,7 +599,7 @@ __global__ __launch_bounds__(512, WPS) void k_dwf_cw(const T* __restrict__ x, lo
     for (int i = 0; i < 2; ++i) {
       if (sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N && ho0 + sl.rr[i] < g.H) {
         piece_t v;
-        const pair_t* sy_ = s_y + (cg * 4) * g.TPIXp + sl.pp[i];
+        const pair_t* sy_ = s_y + (cgl * 4) * g.TPIXp + sl.pp[i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) X::set_pair(v, q, sy_[q * g.TPIXp]);
         X::store(v, y + slab_y + py + sl.goff[i]);
@@ -511,7 +616,9 @@ __global__ __launch_bounds__(512, WPS) void k_dwf_cw(const T* __restrict__ x, lo
     const int n0 = nb * g.NI, ho0 = ty * g.TH;
     const bool fresh = g.ring && (tile == t_beg || ty == 0);
     if (fresh) base = 0;
+    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]));   // see k_dwb_cw
     __syncthreads();   // (A) previous tile consumed, its output complete in s_y
+    X::touch(pfx[0]); X::touch(pfx[1]);   // see k_dwb_cw
     if (pn0 >= 0) store_y(pn0, pho0);
     commit(base);
     if (fresh) halo_sync(n0, ho0);
@@ -558,8 +665,8 @@ __global__ __launch_bounds__(512, WPS) void k_dwf_cw(const T* __restrict__ x, lo
   if (pn0 >= 0) store_y(pn0, pho0);
 
   if (stats) {
-    sa = wave_sum(sa); sb = wave_sum(sb); qa = wave_sum(qa); qb = wave_sum(qb);
-    if (lane == 0) {
+    sa = cw_wave_sum63(sa); sb = cw_wave_sum63(sb); qa = cw_wave_sum63(qa); qb = cw_wave_sum63(qb);
+    if (lane == 63) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int c = ch + e;
@@ -600,6 +707,7 @@ static bool cw_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
   if (pow2) { while (lwp % (2 * g.ns) != g.ns) ++lwp; } else if (lwp % 2 == 0) ++lwp;
   g.LWp = lwp;
   int plane = g.NI * g.LH * g.LWp;
+  if (plane < 512) plane = 512;      // the weight-gradient flush transposes 64 x 15 + 56 floats through a wave's own plane
   while (plane % 4 != 2) ++plane;     // staging writes of the two channel groups land in different bank halves
   g.plane = plane;
   g.TPIX = g.NI * g.TH * W;
@@ -611,9 +719,10 @@ static bool cw_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
   return true;
 }
 
-static void cw_workers(CwGeom& g, int per_cu, int max_rows) {
+static void cw_workers(CwGeom& g, int per_cu, int max_rows, int nw) {
   if (per_cu < 1) per_cu = 1;
-  long want = ((long)num_cus() * per_cu) / g.nslabs;
+  const int units = g.nslabs * (nw == 4 ? 2 : 1);   // workgroups per worker
+  long want = ((long)num_cus() * per_cu) / units;
   static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: long tile walks
   if (max_env > 0 && want > max_env) want = max_env;
   if (max_rows > 0 && want > max_rows) want = max_rows;   // every worker owns one partial row
@@ -621,10 +730,22 @@ static void cw_workers(CwGeom& g, int per_cu, int max_rows) {
   if (want < 1) want = 1;
   g.nworkers = (int)want;
 }
+static unsigned cw_grid(const CwGeom& g, int nw) {
+  const unsigned u = (unsigned)g.nworkers * g.nslabs;
+  return nw == 4 ? (u + 7) / 8 * 16 : u;   // half-slab workgroups: 8 (slab, worker) units -> 16 blocks, see cw_block
+}
 
 static int cw_mode() {
   static const int m = getenv("ATOMNAS_DW_CW") ? atoi(getenv("ATOMNAS_DW_CW")) : 3;   // bit 0: backward, bit 1: forward
   return m;
+}
+static int cw_nw() {
+  static const int m = getenv("ATOMNAS_DW_CW_NW") ? atoi(getenv("ATOMNAS_DW_CW_NW")) : 4;   // waves per workgroup: 8 (whole slab) or 4 (half)
+  return m == 8 ? 8 : 4;
+}
+template <typename T> static size_t cw_lds(const CwGeom& g, int nw) {
+  typedef typename Cw<T>::pair_t pair_t;
+  return (size_t)nw * g.plane * sizeof(f32x2) + (size_t)nw * g.TPIXp * sizeof(pair_t) + 48 * sizeof(float);
 }
 
 template <typename T, int K>
@@ -633,23 +754,22 @@ static int cw_launch_bwd(const void* gup, long gss, const void* yraw, long yrss,
                          float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, hipStream_t st) {
   CwGeom g;
   if (!cw_geometry(g, N, H, W, C, K)) return -1;
-  typedef typename Cw<T>::pair_t pair_t;
-  const size_t lds = (size_t)8 * g.plane * sizeof(f32x2) + (size_t)8 * g.TPIXp * sizeof(pair_t) + 48 * sizeof(float);
+  const int nw = cw_nw();
+  const size_t lds = cw_lds<T>(g, nw);
   if (lds > 160 * 1024) return -1;
-  static const int wps_env = getenv("ATOMNAS_DW_CW_WPS") ? atoi(getenv("ATOMNAS_DW_CW_WPS")) : 0;
-  // two workgroups per CU (128 registers) only where the 18 + ... accumulators of k = 3 fit and the LDS allows it
-  const bool two = wps_env ? wps_env == 4 : (K == 3 && 2 * lds + 2048 <= 160 * 1024);
-#define CW_BWD(AMV, WPSV)                                                                                                   \
+  // waves per SIMD the instances are compiled for: half-slab workgroups 3 (k = 3: 139 registers) or 2; whole-slab workgroups 2
+  constexpr int WPS4 = K == 3 ? 3 : 2;
+#define CW_BWD(AMV, NWV, WPSV)                                                                                              \
   {                                                                                                                         \
-    auto kern = k_dwb_cw<T, K, AMV, WPSV>;                                                                                  \
-    cw_workers(g, resident_per_cu(kern, 512, lds), (stats || dw) ? part_rows : 0);                                          \
-    hipLaunchKernelGGL(kern, dim3(g.nworkers * g.nslabs), dim3(512), lds, st, (const T*)gup, gss, (const T*)yraw, yrss, c1, c2, \
+    auto kern = k_dwb_cw<T, K, AMV, NWV, WPSV>;                                                                             \
+    cw_workers(g, resident_per_cu(kern, NWV * 64, lds), (stats || dw) ? part_rows : 0, NWV);                                \
+    hipLaunchKernelGGL(kern, dim3(cw_grid(g, NWV)), dim3(NWV * 64), lds, st, (const T*)gup, gss, (const T*)yraw, yrss, c1, c2, \
                        c3, (const T*)x, xss, sc, sh, relu, w, ldw, (T*)h, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g); \
   }
-  if (two) {
-    if (relu == ACT_RELU6) CW_BWD(ACT_RELU6, 4) else if (relu == ACT_SWISH) CW_BWD(ACT_SWISH, 4) else CW_BWD(0, 4)
+  if (nw == 4) {
+    if (relu == ACT_RELU6) CW_BWD(ACT_RELU6, 4, WPS4) else if (relu == ACT_SWISH) CW_BWD(ACT_SWISH, 4, WPS4) else CW_BWD(0, 4, WPS4)
   } else {
-    if (relu == ACT_RELU6) CW_BWD(ACT_RELU6, 2) else if (relu == ACT_SWISH) CW_BWD(ACT_SWISH, 2) else CW_BWD(0, 2)
+    if (relu == ACT_RELU6) CW_BWD(ACT_RELU6, 8, 2) else if (relu == ACT_SWISH) CW_BWD(ACT_SWISH, 8, 2) else CW_BWD(0, 8, 2)
   }
 #undef CW_BWD
   if (int rc = check_launch("dwconv_bwd(cw)")) return rc;
@@ -662,22 +782,20 @@ static int cw_launch_fwd(const void* x, long xss, const float* sc, const float* 
                          float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, hipStream_t st) {
   CwGeom g;
   if (!cw_geometry(g, N, H, W, C, K)) return -1;
-  typedef typename Cw<T>::pair_t pair_t;
-  const size_t lds = (size_t)8 * g.plane * sizeof(f32x2) + (size_t)8 * g.TPIXp * sizeof(pair_t) + 32 * sizeof(float);
+  const int nw = cw_nw();
+  const size_t lds = cw_lds<T>(g, nw);
   if (lds > 160 * 1024) return -1;
-  static const int wps_env = getenv("ATOMNAS_DW_CW_WPS_FWD") ? atoi(getenv("ATOMNAS_DW_CW_WPS_FWD")) : 0;
-  const bool two = wps_env ? wps_env == 4 : (2 * lds + 2048 <= 160 * 1024);
-#define CW_FWD(AMV, WPSV)                                                                                                   \
+#define CW_FWD(AMV, NWV)                                                                                                    \
   {                                                                                                                         \
-    auto kern = k_dwf_cw<T, K, AMV, WPSV>;                                                                                  \
-    cw_workers(g, resident_per_cu(kern, 512, lds), stats ? stat_rows : 0);                                                  \
-    hipLaunchKernelGGL(kern, dim3(g.nworkers * g.nslabs), dim3(512), lds, st, (const T*)x, xss, sc, sh, relu, w, ldw, (T*)y, yss, \
+    auto kern = k_dwf_cw<T, K, AMV, NWV, 4>;                                                                                \
+    cw_workers(g, resident_per_cu(kern, NWV * 64, lds), stats ? stat_rows : 0, NWV);                                        \
+    hipLaunchKernelGGL(kern, dim3(cw_grid(g, NWV)), dim3(NWV * 64), lds, st, (const T*)x, xss, sc, sh, relu, w, ldw, (T*)y, yss, \
                        stats, stat_ld, stat_rows, g);                                                                       \
   }
-  if (two) {
+  if (nw == 4) {
     if (relu == ACT_RELU6) CW_FWD(ACT_RELU6, 4) else if (relu == ACT_SWISH) CW_FWD(ACT_SWISH, 4) else CW_FWD(0, 4)
   } else {
-    if (relu == ACT_RELU6) CW_FWD(ACT_RELU6, 2) else if (relu == ACT_SWISH) CW_FWD(ACT_SWISH, 2) else CW_FWD(0, 2)
+    if (relu == ACT_RELU6) CW_FWD(ACT_RELU6, 8) else if (relu == ACT_SWISH) CW_FWD(ACT_SWISH, 8) else CW_FWD(0, 8)
   }
 #undef CW_FWD
   return check_launch("dwconv_fwd(cw)");
@@ -714,6 +832,16 @@ int dwconv_cw_fwd(const void* x, long xss, const float* sc, const float* sh, int
 
 }  // namespace atomnas
 
+#if CW_TIMING
+extern "C" int atomnas_debug_cw_timing(unsigned long long* out8, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(atomnas::g_cw_timing), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(atomnas::g_cw_timing), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
+
 // 1 when atomnas_dwconv_fwd (dir = 0) / atomnas_dwconv_bwd (dir = 1) take the channel-pair-per-wave kernels of this file for the
 // shape (slab-major tensors, stride 1), 0 when they take the tile kernels of dwconv.hip.  Tests and launch-geometry tools only.
 extern "C" int atomnas_dwconv_cw_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir) {
@@ -721,7 +849,6 @@ extern "C" int atomnas_dwconv_cw_supported(int N, int H, int W, int C, int k, in
   if (stride != 1 || !(k == 3 || k == 5 || k == 7) || !(cw_mode() & (dir ? 1 : 2))) return 0;
   CwGeom g;
   if (!cw_geometry(g, N, H, W, C, k)) return 0;
-  const size_t pair = dtype == DT_F32 ? sizeof(f32x2) : sizeof(unsigned);
-  const size_t lds = (size_t)8 * g.plane * sizeof(f32x2) + (size_t)8 * g.TPIXp * pair + 48 * sizeof(float);
+  const size_t lds = dtype == DT_F32 ? cw_lds<float>(g, cw_nw()) : cw_lds<bf16_t>(g, cw_nw());
   return lds <= 160 * 1024 ? 1 : 0;
 }
