@@ -23,6 +23,9 @@ from .utils import optim as aopt
 from .utils import prune as aprune
 
 
+HYP_SUMMED_RANKS = 4   # engine-owned slot of the per-step scalar vector (runtime.ArenaManager.hyper)
+
+
 class TrainStep:
 
     def __init__(self, model, optimizer, ema=None, prune_info=None, weight_decay=1e-5, wd_method='mnas', label_smoothing=0.1,
@@ -59,6 +62,7 @@ class TrainStep:
         self._version = -1
         self.global_step = 0
         self._seed_grad = None
+        self._agree = torch.ones(1, dtype=torch.float32, device=dev)   # capture outcome, MIN-reduced over the ranks
 
     # ---- pieces
     def _prune_weights(self):
@@ -85,7 +89,6 @@ class TrainStep:
         self._wd_chunk = wd.to(mgr.P.device)
         w, pen = self._prune_weights()
         self._l1 = mgr.reg_table([(p._atomnas_off, p.numel(), c) for p, c in zip(w, pen)]) if w else None
-        self._world = torch.full((1,), float(max(self.world_size, 1)), dtype=torch.float32, device=mgr.P.device)
         self._ws = torch.empty(4096 + 64 * max(len(w), 1), dtype=torch.float32, device=mgr.P.device)
         self._tables_version = mgr.version
 
@@ -168,7 +171,7 @@ class TrainStep:
         if self._l1 is not None:
             table, njobs = self._l1
             ops.reg_value(mgr.P, table, njobs, 1, rho_ptr, 1.0, self.loss[2:3], ws=self._ws[4096:])
-            ops.reg_grad(mgr.P, mgr.G, table, njobs, 1, rho_ptr, self._world)
+            ops.reg_grad(mgr.P, mgr.G, table, njobs, 1, rho_ptr, mgr.hyper[HYP_SUMMED_RANKS:HYP_SUMMED_RANKS + 1])
         ops.fused_rmsprop_ema(mgr.P, mgr.G, mgr.SQ, mgr.BUF if group['momentum'] > 0 else None,
                               mgr.EMA if self.ema is not None else None, self._wd_chunk, mgr.nP, mgr.hyper, group['alpha'],
                               group['eps'], group['eps_inside_sqrt'], group['momentum'], l2_value=self.loss[1:2], ws=self._ws)
@@ -176,7 +179,10 @@ class TrainStep:
             ops.ema_update(mgr.SEMA, mgr.S, mgr.nS, mgr.hyper)
         ops.add_i64(mgr.step_counter, 1)
 
-    def _capture(self):
+    def _capture(self, want_overlapped=False):
+        """Captures what is missing: the one-graph form with the in-graph collectives (want_overlapped, comm mode "graph") and / or
+        the forward-backward + optimizer pair that runs without a collective or around a blocking one.  Graphs that exist are kept:
+        a step(reduce=False) between reducing steps must not drop the overlapped graph."""
         mgr = self.mgr
         mgr.ensure()
         self._tables()
@@ -194,10 +200,16 @@ class TrainStep:
         mgr.CNT.copy_(keep_c)
         # thread_local: the RCCL watchdog thread of a process group polls events while we capture; in the default "global" mode
         # such a call from another thread invalidates the capture
-        self.g_all = None
-        if self.comm_mode == "graph":
+        if want_overlapped and self.comm_mode == "graph" and self.g_all is None:
             # one graph: kernels, bucketed RCCL all-reduces on the side stream, optimizer tail
+            ok = True
             try:
+                # one real collective on the side stream first: communicator set-up / lazy connections must not happen inside capture
+                self._comm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._comm):
+                    dist.all_reduce(self._agree, group=self.pg)
+                torch.cuda.current_stream().wait_stream(self._comm)
+                torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._fwd_bwd_overlapped()
@@ -207,8 +219,15 @@ class TrainStep:
                 import logging
                 logging.warning("capturing the gradient all-reduce failed (%s); using one blocking all-reduce between two graphs", e)
                 torch.cuda.synchronize()
+                ok = False
+            # The mode is a property of the JOB: a rank that replays N bucketed collectives next to a rank that issues one whole-arena
+            # collective hangs or corrupts gradients.  Every rank reports, and one failure switches all of them to the blocking form.
+            self._agree.fill_(1.0 if ok else 0.0)
+            dist.all_reduce(self._agree, op=dist.ReduceOp.MIN, group=self.pg)
+            if float(self._agree.item()) < 0.5:
                 self.comm_mode = "host"
-        if self.g_all is None:
+                self.g_all = None
+        if self.g_fwd_bwd is None and not (want_overlapped and self.g_all is not None):
             self.g_fwd_bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode="thread_local"):
                 self._fwd_bwd()
@@ -238,7 +257,9 @@ class TrainStep:
             self._buckets = []
         if do_reduce and self.comm_mode is None:
             backend = dist.get_backend(self.pg) if dist.is_initialized() else None
-            overlap_ok = backend == "nccl" and os.environ.get("ATOMNAS_OVERLAP_ALLREDUCE", "1") != "0"
+            # ATOMNAS_OVERLAP_ALLREDUCE: "0" never, "force" with any backend (tests drive the bucketed path eagerly with gloo ranks)
+            env = os.environ.get("ATOMNAS_OVERLAP_ALLREDUCE", "1")
+            overlap_ok = env == "force" or (backend == "nccl" and env != "0")
             self.comm_mode = "graph" if overlap_ok else "host"
         if do_reduce and self.comm_mode == "graph" and not self._buckets:
             self._comm = self._comm or torch.cuda.Stream()
@@ -247,7 +268,11 @@ class TrainStep:
         self._tables()
         h[ops.HYP_LR] = float(self.optimizer.param_groups[0]['lr'] if lr is None else lr)
         h[ops.HYP_RHO] = float(rho)
-        h[ops.HYP_GRAD_SCALE] = 1.0 / max(self.world_size, 1)
+        # the scales follow what THIS step does: a step without the collective (bench.py's single-rank profile pass) trains on its own
+        # gradients, not on gradients shrunk by 1 / world
+        eff_world = float(max(self.world_size, 1)) if do_reduce else 1.0
+        h[ops.HYP_GRAD_SCALE] = 1.0 / eff_world
+        h[HYP_SUMMED_RANKS] = eff_world
         if self.ema is not None:
             h[ops.HYP_EMA_DECAY] = float(self.ema.momentum_at(self.global_step + 1) if ema_decay is None else ema_decay)
         else:
@@ -255,16 +280,14 @@ class TrainStep:
         mgr.push_hyper()
         overlapped = do_reduce and self.comm_mode == "graph"
         if self.use_graph:
-            if self.g_fwd_bwd is None and self.g_all is None:
-                self._capture()
+            if overlapped and self.g_all is None:
+                self._capture(want_overlapped=True)   # may agree on "host" over the ranks
                 overlapped = do_reduce and self.comm_mode == "graph"
             if overlapped and self.g_all is not None:
                 self.g_all.replay()
             else:
-                if self.g_fwd_bwd is None:   # captured as one graph earlier, now asked to run without the collective
-                    was, self.comm_mode = self.comm_mode, "host"
+                if self.g_fwd_bwd is None:
                     self._capture()
-                    self.comm_mode = was
                 self.g_fwd_bwd.replay()
                 if do_reduce:
                     dist.all_reduce(mgr.G, group=self.pg)
@@ -281,6 +304,10 @@ class TrainStep:
                 if self.allreduce_bn:
                     self._reduce_bn()
             self._opt()
+        # optimizer / regulariser launches outside TrainStep (RMSprop.step(), cal_bn_l1_loss) read the same vector: leave the neutral
+        # scales behind (host copy only: the device vector is re-staged by whoever launches next)
+        h[ops.HYP_GRAD_SCALE] = 1.0
+        h[HYP_SUMMED_RANKS] = 1.0
         self.global_step += 1
         if self.ema is not None:   # bookkeeping the reference keeps per variable (utils/optim.py:62-63); checkpointed
             self.ema.note_updates(1, float(h[ops.HYP_EMA_DECAY]))

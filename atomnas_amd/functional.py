@@ -172,7 +172,9 @@ def _join_side():
 # situ: 1.30 ms against 1.19 ms for the two GEMMs (x is re-staged and Gx re-read per segment): off
 _FUSED_EXPAND_SEG = bool(int(os.environ.get("ATOMNAS_FUSED_EXPAND_SEG", "0")))
 _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
-_PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))   # experiment switch (same-box A/B of the two layouts)
+_PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
+TAIL_TAP = None   # set to a list by tests to receive the dropout keep mask of every tail forward
+_CHECK_LOSS_SEED = bool(int(os.environ.get("ATOMNAS_CHECK_LOSS_SEED", "0")))   # experiment switch (same-box A/B of the two layouts)
 
 
 def _hidden(pl, M, C, T, dev):
@@ -496,6 +498,8 @@ def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
     pooled = torch.empty(N, lp.cout, dtype=T, device=dev)
     p = float(drop_p) if training else 0.0
     keep = torch.empty(N, lp.cout, dtype=torch.uint8, device=dev) if p > 0 else None
+    if TAIL_TAP is not None:   # tests: the dropout keep mask this forward uses (and its backward re-uses)
+        TAIL_TAP.append(keep)
     ops.bn_act_pool(L, b.scale, b.shift, int(act), pooled, keep, p, seed, step_ptr, N, H * W, lp.cout)
     Kc = fp.cout
     logits = torch.empty(N, pad8(Kc), dtype=torch.float32, device=dev)
@@ -586,7 +590,12 @@ class TailLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         # contract: the caller differentiates the loss itself (d total / d loss = 1, as train.py:181 `loss.backward()` does);
-        # gout is therefore not multiplied in (that would be an elementwise launch per step for a factor of one)
+        # gout is therefore not multiplied in (that would be an elementwise launch per step for a factor of one).  A caller that
+        # scales the returned loss would silently get unscaled gradients: ATOMNAS_CHECK_LOSS_SEED=1 verifies the seed (one host
+        # synchronisation per step, so not in the default path and never under graph capture).
+        if _CHECK_LOSS_SEED and not torch.cuda.is_current_stream_capturing() and float(gout) != 1.0:
+            raise RuntimeError("TailLossFunction differentiates d(loss)/d(loss) = 1 only; got a seed of %r (scale the learning "
+                               "rate, or use CrossEntropyLabelSmooth for a loss that is combined with other terms)" % float(gout))
         lp, fp, sv = ctx.lp, ctx.fp, ctx.sv
         gx = tail_backward(lp, fp, sv, None, dl_padded=ctx.dl)
         ctx.sv = ctx.dl = None

@@ -454,11 +454,15 @@ class ArenaManager:
         for ema in self.emas:
             ema._on_materialize(self)
         self.anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
-        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)     # lr, rho, ema decay, grad scale (atomnas_hip.h)
+        # lr, rho, ema decay, grad scale (atomnas_hip.h: the kernels read slots 0..3); slot 4 is the engine's own: the number of
+        # ranks the gradients of this step were summed over (multiplier of the per-rank L1 sub-gradient, engine.TrainStep._opt)
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self.hyper[3] = 1.0
-        self.hyper_host = torch.zeros(4, dtype=torch.float32)
+        self.hyper[4] = 1.0
+        self.hyper_host = torch.zeros(8, dtype=torch.float32)
         self.hyper_host[3] = 1.0
-        self._hyper_ring = torch.zeros(64, 4, dtype=torch.float32).pin_memory()  # staging slots: the host may run ahead
+        self.hyper_host[4] = 1.0
+        self._hyper_ring = torch.zeros(64, 8, dtype=torch.float32).pin_memory()  # staging slots: the host may run ahead
         self._hyper_slot = 0
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=dev)  # decorrelates dropout masks across iterations
         self.bn_trained = False

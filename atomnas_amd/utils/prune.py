@@ -150,6 +150,18 @@ def alive_masks(weights, threshold, mode=0, with_index=False):
     mgr.ensure()
     if mode != 0 and mgr.EMA is None:
         raise RuntimeError('alive_masks(mode={}) needs the EMA attached to the model arenas'.format(mode))
+    if mode != 0:
+        # the shadows are read at the parameters' offsets of the EMA arena: a gamma without a registered shadow would read zeros
+        # and be pruned as dead, where the reference raises (utils/optim.py:71-76 `average`)
+        registered = set()
+        for e in getattr(mgr, 'emas', []):
+            registered.update(e.average_names())
+        if getattr(mgr, 'emas', None):
+            off2name = {slot[0]: n for n, slot in mgr.param_slots.items()}
+            for w in weights:
+                n = off2name.get(int(w._atomnas_off))
+                if n is None or not any(r == n or r.endswith('.' + n) or n.endswith('.' + r) for r in registered):
+                    raise RuntimeError('{} has not been registered'.format(n))
 
     class J(ctypes.Structure):
         _fields_ = [("off", ctypes.c_long), ("count", ctypes.c_int), ("out_off", ctypes.c_int)]

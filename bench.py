@@ -3,7 +3,11 @@
 backward, gradient all-reduce, RMSprop, EMA) at 224x224, per-GPU batch 256, bf16 activations, synthetic data.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            (N > 1 without a launcher environment: re-launches itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Other BASELINE configurations (one JSON line each, same fields): --model atomnas_a_supernet (config 2), --model atomnas_a_supernet
+--shrink 0.3 (config 3: a seeded 30 % of the atoms dead, shrink, steady state on the ragged network; shrink latency reported
+separately), --model atomnas_c_plus --batch 128 (config 5: searched network with SE / Swish / fused blocks).
 
 Rank 0 prints ONE JSON line (contract in the task statement): value = whole-job images/sec, plus
   roofline     -- the dominant kernel of the step (by summed time), its algorithmic bytes / measured time vs HBM peak,
@@ -26,7 +30,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+HBM_PEAK = 8.0e12    # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+MFMA_PEAK = 2.5e15   # flop/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
+GEMM_ENTRIES = ("atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn", "atomnas_expand_bwd", "atomnas_project_bwd")
 
 
 def build(model_name, dtype, batch, seed):
@@ -39,12 +45,17 @@ def build(model_name, dtype, batch, seed):
     from atomnas_amd.utils import rmsprop
     hp = configs.SEARCH_HPARAMS
     torch.manual_seed(seed)
-    model = ms.Model(**configs.model_kwparams(model_name), input_size=hp['image_size'])
+    searched = model_name in ("atomnas_c", "atomnas_c_plus")
+    if searched:   # retrain of a searched architecture (apps/searched/**): no prunable atoms, no L1 term
+        from atomnas_amd.models import searched_network as sn
+        model = sn.Model(**configs.searched_kwparams(model_name), input_size=hp['image_size'])
+    else:
+        model = ms.Model(**configs.model_kwparams(model_name), input_size=hp['image_size'])
     model.apply(mb.init_weights_mnas)
     model.set_compute_dtype(dtype)
     mp.model_profiling(model, hp['image_size'], hp['image_size'], verbose=False)
     model.cuda().train()
-    pinfo = aprune.get_bn_to_prune(model, hp['prune_params'], verbose=False)
+    pinfo = None if searched else aprune.get_bn_to_prune(model, hp['prune_params'], verbose=False)
     world = dist.get_world_size() if dist.is_initialized() else 1
     lr = hp['base_lr'] * (batch * world / hp['base_total_batch'])
     opt = rmsprop.RMSprop(model.parameters(), lr=lr, alpha=hp['alpha'], momentum=hp['momentum'], eps=hp['epsilon'],
@@ -59,7 +70,47 @@ def build(model_name, dtype, batch, seed):
     ts = engine.TrainStep(model, opt, ema, pinfo, weight_decay=hp['weight_decay'], wd_method=hp['weight_decay_method'],
                           label_smoothing=hp['label_smoothing'], batch_size=batch, image_size=hp['image_size'],
                           world_size=world)
-    return model, ts, hp
+    return model, ts, hp, opt, ema, pinfo
+
+
+def forced_shrink(model, ts, opt, ema, pinfo, frac, seed):
+    """SURVEY.md section 8(d) recipe of config 3: a seeded random `frac` of the atoms get gamma = gamma_EMA = 0 (the others are left
+    alone), then the reference's shrink_model (train.py:27-81).  Returns (shrink wall time in ms, MACs before, MACs after)."""
+    import train as T
+    from atomnas_amd.utils import config
+    g = torch.Generator().manual_seed(seed)
+    table = dict(model.named_parameters())
+    with torch.no_grad():
+        for name in pinfo.weight:
+            w = table[name]
+            dead = (torch.rand(w.numel(), generator=g) < frac).to(w.device)
+            w[dead] = 0.0
+            ema.average(name)[dead] = 0.0
+
+    class F(dict):
+        __getattr__ = dict.__getitem__
+    config.FLAGS.bind(F(image_size=224, use_distributed=False))
+    wrapper = torch.nn.Module()
+    wrapper.module = model
+    macs0 = int(model.n_macs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    T.shrink_model(wrapper, ema, opt, pinfo, 1e-3, ema_only=False)
+    ts.mgr.ensure()   # arenas rebuilt (parameters, optimizer state, EMA shadows gathered)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3, macs0, int(model.n_macs)
+
+
+def gemm_flops(tag_name, tag):
+    """flops of one GEMM-type launch from its shape tag (2 M N K per product; the fused backward entry points do two products)"""
+    f = {k: int(v) for k, v in re.findall(r"([A-Za-z]+)(\d+)", tag)}
+    if tag_name == "atomnas_pw_gemm_nt":
+        return 2 * f["M"] * f["N"] * f["K"]
+    if tag_name == "atomnas_pw_gemm_tn":
+        return 2 * f["M"] * f["NU"] * f["NV"]
+    if tag_name in ("atomnas_expand_bwd", "atomnas_project_bwd"):
+        return 4 * f["M"] * f["N"] * f["K"]
+    return 0
 
 
 def algorithmic_bytes(tag_name, tag, itemsize):
@@ -87,27 +138,30 @@ def algorithmic_bytes(tag_name, tag, itemsize):
     return 0
 
 
-def kernel_profile(ts, itemsize):
+def kernel_profile(ts, itemsize, lr, rho):
     """Eager pass of the same step with HIP events around every C-ABI launch (on the launch stream)."""
     from atomnas_amd import _lib
     was = ts.use_graph
     ts.use_graph = False
-    # rank 0 profiles alone while the other ranks wait at the barrier: reduce=False keeps every collective out of this pass
-    # (the 1/world gradient scale of the optimizer graph is harmless here)
-    ts.step(rho=1e-4, reduce=False)
+    # rank 0 profiles alone while the other ranks wait at the barrier: reduce=False keeps every collective out of this pass (the step
+    # then scales its own gradients by 1, not by 1 / world; the ranks have finished the timed region, so the divergence of rank 0's
+    # parameters is of no consequence for the numbers)
+    ts.step(lr=lr, rho=rho, reduce=False)
     torch.cuda.synchronize()
     _lib.PROFILE = []
-    ts.step(rho=1e-4, reduce=False)
+    ts.step(lr=lr, rho=rho, reduce=False)
     torch.cuda.synchronize()
     prof, _lib.PROFILE = _lib.PROFILE, None
     ts.use_graph = was
     agg = collections.OrderedDict()
     for name, tag, e0, e1 in prof:
-        a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+        a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0, flops=0))
         a["launches"] += 1
         a["ms"] += e0.elapsed_time(e1)
-        if tag and name in ("atomnas_dwconv_fwd", "atomnas_dwconv_bwd", "atomnas_pw_gemm_nt", "atomnas_pw_gemm_tn", "atomnas_expand_bwd", "atomnas_project_bwd"):
+        if tag and name in ("atomnas_dwconv_fwd", "atomnas_dwconv_bwd") + GEMM_ENTRIES:
             a["bytes"] += algorithmic_bytes(name, tag, itemsize)
+        if tag and name in GEMM_ENTRIES:
+            a["flops"] += gemm_flops(name, tag)
     return agg
 
 
@@ -196,13 +250,30 @@ def cpu_baseline(model_name, seconds_budget=20.0):
                 sample="oracle/atomnas_oracle.train_step (fp32 torch CPU restatement of train.py:165-236), %s, bs %d, %d timed steps after 1 warm-up, %d threads of %d host cores" % (model_name, bs, n, threads, cores))
 
 
+def relaunch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: one process per GPU under torch.distributed.run (the
+    command the driver uses), same arguments; the children's rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note("re-launching as: " + " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE metric: 256)")
-    ap.add_argument("--model", default="atomnas_c_supernet")
+    ap.add_argument("--model", default="atomnas_c_supernet",
+                    choices=["atomnas_c_supernet", "atomnas_a_supernet", "mobilenet_v2_1.0", "atomnas_c", "atomnas_c_plus"])
+    ap.add_argument("--shrink", type=float, default=0.0, help="config 3: fraction of atoms forced dead before a shrink; the timed steps "
+                    "then run on the ragged network")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -212,18 +283,24 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (validation of the multi-rank path only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path runs in libatomnas_hip.so only (no CPU fallback)")
     torch.cuda.set_device(0 if args.same_device else local)
     if world > 1 or os.environ.get("ATOMNAS_FORCE_ALLREDUCE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend)   # "nccl" is RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     note("building %s" % args.model)
-    model, ts, hp = build(args.model, dtype, args.batch, seed=1995)
+    model, ts, hp, opt, ema, pinfo = build(args.model, dtype, args.batch, seed=1995)
     ts.use_graph = not args.no_graph
     if world > 1:   # replicate rank 0's initialisation (reference: utils/distributed.py:183-190)
         dist.broadcast(ts.mgr.P, 0)
@@ -232,54 +309,90 @@ def main():
     x = torch.randn(args.batch, 3, hp['image_size'], hp['image_size'], device="cuda", generator=g)
     y = torch.randint(0, 1000, (args.batch,), device="cuda", generator=g)
     ts.set_batch(x, y)
+    # learning rate of the timed iterations: the schedule's value at iteration 0.  The reference warms up from base_lr to
+    # base_lr * batch / 256 over 5 epochs (utils/optim.py:252-306: lr(0) = 0.016 at every world size), so the first steps of a
+    # large-batch job run at base_lr, not at the scaled rate.
+    lr0 = hp['base_lr']
+    rho = 1e-4 if pinfo is not None else 0.0
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    shrink_info = None
+    if args.shrink > 0:
+        if pinfo is None:
+            raise SystemExit("bench.py: --shrink needs a supernet (prunable atoms)")
+        note("config 3: %d warm steps, then %.0f %% of the atoms dead and shrink" % (max(args.warmup, 1), 100 * args.shrink))
+        for _ in range(max(args.warmup, 1)):
+            ts.step(lr=lr0, rho=rho)
+        barrier()
+        ms_shrink, macs0, macs1 = forced_shrink(model, ts, opt, ema, pinfo, args.shrink, seed=11)   # same seed on every rank
+        shrink_info = dict(fraction=args.shrink, shrink_ms=round(ms_shrink, 1), macs_before=macs0, macs_after=macs1)
+        note("shrink: %.0f ms, MACs %d -> %d" % (ms_shrink, macs0, macs1))
+
     note("warm-up (graph capture)")
-    for _ in range(max(args.warmup, 1)):
-        ts.step(rho=1e-4)
+    first_loss = None
+    for i in range(max(args.warmup, 1)):
+        ts.step(lr=lr0, rho=rho)
+        if i == 0:
+            first_loss = float(ts.loss[0].item())
     barrier()
     note("timing %d steps" % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ts.step(rho=1e-4)
+        ts.step(lr=lr0, rho=rho)
     barrier()
     dt = time.perf_counter() - t0
     note("timed: %.2f ms/step" % (dt / args.steps * 1e3))
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = ts.loss.tolist()
     topk = ts.topk.tolist()
-    # the replayed graph must still be a training step: finite losses, hit counters within the batch (a step that trains on stale
-    # gradients or uncleared accumulators shows up here, not in the timing)
+    # the replayed graph must still be a training step: finite losses, hit counters within the batch, and a cross entropy below the
+    # one of the first step on this (fixed) batch -- a step that trains on stale gradients, uncleared accumulators or a broken
+    # kernel shows up here, not in the timing
     if not all(v == v and abs(v) < 1e6 for v in loss) or not all(0 <= t <= args.batch for t in topk):
         raise SystemExit("bench.py: the timed steps did not train (loss %s, top-k hits %s)" % (loss, topk))
+    if args.steps + args.warmup >= 4 and not loss[0] < first_loss:
+        raise SystemExit("bench.py: the cross entropy did not go down over %d steps on a fixed batch (%.4f -> %.4f)"
+                         % (args.steps + max(args.warmup, 1), first_loss, loss[0]))
 
     out = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
+        metric = ("images/sec (whole node) AtomNAS-C supernet 224x224 bs256/GPU" if args.model == "atomnas_c_supernet" and not args.shrink
+                  else "images/sec (whole node) %s%s 224x224 bs%d/GPU" % (args.model, " after shrink" if args.shrink else "", args.batch))
+        backend = dist.get_backend() if dist.is_initialized() else None
         out = collections.OrderedDict(
-            metric="images/sec (whole node) AtomNAS-C supernet 224x224 bs256/GPU",
+            metric=metric,
             value=round(args.batch * world * args.steps / dt, 1), unit="images/sec", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype="bf16" if dtype == torch.bfloat16 else "f32", data="synthetic",
             config=dict(workload="%s full training step (fwd + CE-smooth/L2/L1 + bwd + grad all-reduce + RMSprop + EMA), 224x224" % args.model,
                         per_gpu_batch=args.batch, global_batch=args.batch * world, parallelism="dp%d" % world,
-                        hip_graph=bool(ts.use_graph), final_loss=[round(v, 4) for v in loss]))
+                        hip_graph=bool(ts.use_graph), lr=lr0, first_loss=round(first_loss, 4), final_loss=[round(v, 4) for v in loss]),
+            rccl_ranks=(world if backend == "nccl" else 0), comm_backend=backend, comm_mode=ts.comm_mode,
+            rank_ms_per_step=[round(v, 3) for v in rank_ms])
+        if shrink_info:
+            out["shrink"] = shrink_info
     if not args.no_roofline and rank == 0:
         note("per-launch profile pass")
-        agg = kernel_profile(ts, 2 if dtype == torch.bfloat16 else 4)
+        agg = kernel_profile(ts, 2 if dtype == torch.bfloat16 else 4, lr0, rho)
         note("profile pass done")
         tot = sum(a["ms"] for a in agg.values())
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["bytes"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
         # the committed PMC pass was taken on the default workload (bf16, per-GPU batch 256): only valid for that
-        traffic, traffic_src = pmc_traffic(dom_name) if (args.batch == 256 and dtype == torch.bfloat16) else (None, None)
+        default_wl = args.batch == 256 and dtype == torch.bfloat16 and args.model == "atomnas_c_supernet" and not args.shrink
+        traffic, traffic_src = pmc_traffic(dom_name) if default_wl else (None, None)
         out["roofline"] = dict(kernel=dom_name, bound="hbm", achieved=round(ach / 1e9, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
                                frac=round(ach / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_src,
                                launches_per_step=dom["launches"],
@@ -287,12 +400,26 @@ def main():
                                avg_launch_us=round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
                                algorithmic_bytes_per_step=dom["bytes"], kernel_ms_per_step=round(dom["ms"], 3),
                                share_of_step=round(dom["ms"] / tot, 3))
+        # the pointwise (1x1) layers against BOTH of their rooflines -- all GEMM-type entries of the step
+        pw = [a for k, a in agg.items() if k in GEMM_ENTRIES]
+        pw_ms, pw_fl, pw_by = sum(a["ms"] for a in pw), sum(a["flops"] for a in pw), sum(a["bytes"] for a in pw)
+        if pw_ms > 0:
+            out["pointwise"] = dict(ms_per_step=round(pw_ms, 3), flops_per_step=pw_fl, algorithmic_bytes_per_step=pw_by,
+                                    tflops=round(pw_fl / (pw_ms * 1e-3) / 1e12, 1), mfma_peak_tflops=MFMA_PEAK / 1e12,
+                                    frac_mfma=round(pw_fl / (pw_ms * 1e-3) / MFMA_PEAK, 4),
+                                    GBps=round(pw_by / (pw_ms * 1e-3) / 1e9, 1), frac_hbm=round(pw_by / (pw_ms * 1e-3) / HBM_PEAK, 4))
+        dwk = [a for k, a in agg.items() if k.startswith("atomnas_dwconv")]
+        dw_ms, dw_by = sum(a["ms"] for a in dwk), sum(a["bytes"] for a in dwk)
+        if dw_ms > 0:
+            out["depthwise"] = dict(ms_per_step=round(dw_ms, 3), algorithmic_bytes_per_step=dw_by,
+                                    GBps=round(dw_by / (dw_ms * 1e-3) / 1e9, 1), frac_hbm=round(dw_by / (dw_ms * 1e-3) / HBM_PEAK, 4))
         out["kernels"] = {k[8:]: dict(n=a["launches"], ms=round(a["ms"], 3), GBps=(round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["bytes"] else None))
                           for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_guarded(args.model)
+        out["cpu_baseline"] = cpu_baseline_guarded(args.model if args.model in ("atomnas_c_supernet", "atomnas_a_supernet", "mobilenet_v2_1.0")
+                                                    else "atomnas_c_supernet")
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():

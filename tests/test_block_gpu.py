@@ -172,39 +172,36 @@ def test_model_forward_backward(gpu_lib, dtype):
     ref_logits = orc.model_forward(xin, work, spec, True, {}, q=orc.NoQuant if dtype == torch.float32 else orc.Bf16Storage)
     ref_loss = orc.ce_label_smooth(ref_logits, y, 0.1).mean()
     ref_loss.backward()
+    # Bounds from tools/parity_diag.py on this very network (profiles/r03_parity_diag.txt; the kernels are bit-reproducible, so the
+    # numbers do not move from run to run).  fp32 storage: logits relative L2 2.2e-6, worst gradient tensor 4.1e-6, no outliers.
+    # bf16 storage against Bf16Storage: logits 1.4e-2; gradients per significant tensor cosine >= 0.950, norm ratio 0.79..1.07,
+    # aggregate cosine 0.980 -- a 1-ulp forward difference flips bf16 roundings and ReLU masks, so whole-network bf16 gradients are
+    # pinned in direction and scale here and element-wise per block (test_block_forward_backward, tests/test_parity_gpu.py).
     if dtype == torch.float32:
-        ta, tg = dict(rtol=2e-3, atol=2e-4), dict(rtol=1e-2, atol=3e-3)  # fp32: atomics / accumulation order only
+        ta = dict(rtol=1e-4, atol=1e-5)
     else:
-        ta, tg = dict(rtol=3e-2, atol=3e-2), None
+        ta = dict(rtol=3e-2, atol=3e-2)
     assert_close("logits", logits, ref_logits, **ta)
-    assert abs(float(loss.detach()) - float(ref_loss.detach())) < (1e-4 if dtype == torch.float32 else 1e-2)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < (1e-5 if dtype == torch.float32 else 5e-3)
     gnorm = max(float(work[n].grad.norm()) for n, _ in model.named_parameters())
     for name, p in model.named_parameters():
         r = work[name].grad
         if dtype == torch.float32:
-            s = max(1e-2, float(r.abs().max()))
-            # fp32 sums differ run to run in the last bits (atomic order); a ReLU pre-activation within that distance of zero
-            # then flips its mask against the fp64 oracle and moves a few gradient elements by a whole contribution
-            # (observed: 1 of 432 elements, identical value whenever it happens) -> bounded outliers, tight relative L2
-            assert_close("grad " + name, p.grad, r, tg["rtol"], tg["atol"] * s, outlier_frac=0.02, rel_l2=3e-2)
+            if float(r.norm()) > 1e-6 * gnorm:
+                s = max(1e-2, float(r.abs().max()))
+                assert_close("grad " + name, p.grad, r, 1e-3, 1e-4 * s, outlier_frac=0.0, rel_l2=1e-4)
+            else:   # a bias in front of another BatchNorm: the true gradient is zero, both sides hold rounding noise
+                assert float(p.grad.abs().max()) < 1e-5 * gnorm, (name, float(p.grad.abs().max()), gnorm)
         elif float(r.norm()) > 1e-2 * gnorm:
-            # Whole-network bf16 gradients cannot be compared element-wise with ANY other implementation: 1-ulp forward
-            # differences (fp32 accumulation order) grow ~2x per block through the batch statistics, flip a percent of the
-            # ReLU masks in late layers, and each flip changes a gradient contribution completely (measured here: forward
-            # relative L2 error 1.8e-2 at the last block -> ~0.2 in the gradients, identical for every layer).  Component
-            # level bf16 parity is exact-to-rounding (test_block_forward_backward, tools/dbg_tail.py); here we pin the
-            # direction and scale of every significant gradient tensor.
             gg = p.grad.double().cpu().flatten()
             cos = float(torch.dot(gg, r.flatten()) / (gg.norm() * r.norm()))
             ratio = float(gg.norm() / r.norm())
-            # per tensor only a sanity bound (which masks flip varies from run to run with the order of the fp32 atomics);
-            # the aggregate over all parameters below is the stable statement
-            assert cos > 0.5 and 0.5 < ratio < 2.0, "grad %s: cosine %.3f norm ratio %.3f" % (name, cos, ratio)
+            assert cos > 0.9 and 0.7 < ratio < 1.3, "grad %s: cosine %.3f norm ratio %.3f" % (name, cos, ratio)
     if dtype != torch.float32:
         ga = torch.cat([p.grad.double().cpu().flatten() for _, p in model.named_parameters()])
         ra = torch.cat([work[n].grad.flatten() for n, _ in model.named_parameters()])
         cos = float(torch.dot(ga, ra) / (ga.norm() * ra.norm()))
-        assert cos > 0.9 and 0.8 < float(ga.norm() / ra.norm()) < 1.25, "all gradients: cosine %.3f norm ratio %.3f" % (cos, float(ga.norm() / ra.norm()))
+        assert cos > 0.95 and 0.9 < float(ga.norm() / ra.norm()) < 1.1, "all gradients: cosine %.3f norm ratio %.3f" % (cos, float(ga.norm() / ra.norm()))
 
 
 @pytest.mark.parametrize("act", ["nn.ReLU", "nn.ReLU6"])

@@ -169,3 +169,99 @@ def test_rccl_allreduce_is_captured_in_the_step_graph(gpu_lib):
     if p.is_alive():
         p.terminate()
     assert p.exitcode == 0 and out.get("ok") == 1
+
+
+def _bucket_worker(rank, world, port, out):
+    """Two gloo ranks on one device drive the BUCKETED all-reduce of engine.TrainStep eagerly (ATOMNAS_OVERLAP_ALLREDUCE=force lifts
+    the backend gate; gloo collectives cannot be captured, so use_graph is off): the collectives are issued from inside backward,
+    bucket by bucket on the side stream.  Against one blocking all-reduce of the whole arena over the same per-rank gradients the
+    result must be bit-identical, the buckets must tile the arena, and every bucket must have fired."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      ATOMNAS_OVERLAP_ALLREDUCE="force")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from trainstep_diag import setup
+        model, sd, spec, pinfo, opt, ema, engine = setup(torch.bfloat16, 64)   # same seed -> same initialisation on both ranks
+        ts = engine.TrainStep(model, opt, ema, pinfo, weight_decay=1e-3, batch_size=8, image_size=64, use_graph=False, world_size=world)
+        g = torch.Generator().manual_seed(300 + rank)
+        ts.set_batch(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 10, (8,), generator=g).cuda())
+        # reference: the per-rank gradients of this state, summed by ONE all-reduce of the whole arena
+        ts._fwd_bwd()
+        torch.cuda.synchronize()
+        ref = ts.mgr.G.detach().clone()
+        dist.all_reduce(ref)
+        # the bucketed form on the same state (BN statistics are per rank and do not enter the gradients of a train-mode step)
+        ts.step(lr=0.0, rho=0.0)   # lr 0: parameters stay where they are; comm mode is decided here
+        assert ts.comm_mode == "graph", ts.comm_mode
+        assert len(ts._buckets) >= 1 and ts._fired == len(ts._buckets)
+        lo = sorted(b[1] for b in ts._buckets)
+        assert lo[0] == 0 and sum(b[2] - b[1] for b in ts._buckets) == ts.mgr.nP
+        edges = sorted((b[1], b[2]) for b in ts._buckets)
+        assert all(edges[i][1] == edges[i + 1][0] for i in range(len(edges) - 1)), edges   # no gap, no overlap
+        ts._fwd_bwd_overlapped()
+        torch.cuda.synchronize()
+        assert ts._fired == len(ts._buckets)
+        assert torch.equal(ts.mgr.G, ref), float((ts.mgr.G - ref).abs().max())
+        # small buckets: several collectives per backward, same result
+        ts._build_buckets(target_floats=1 << 12)
+        assert len(ts._buckets) > 2
+        ts._fwd_bwd_overlapped()
+        torch.cuda.synchronize()
+        assert ts._fired == len(ts._buckets)
+        assert torch.equal(ts.mgr.G, ref), float((ts.mgr.G - ref).abs().max())
+        # a step without the collective between reducing steps scales its own gradient by 1, not by 1 / world
+        from atomnas_amd import ops
+        p0 = ts.mgr.P.clone()
+        ts.step(lr=0.001, rho=0.0, reduce=False)
+        torch.cuda.synchronize()
+        assert float(ts.mgr.hyper[ops.HYP_GRAD_SCALE]) == 1.0 and float(ts.mgr.hyper[4]) == 1.0
+        assert float((ts.mgr.P - p0).abs().max()) > 0
+        ts.step(lr=0.001, rho=0.0)
+        torch.cuda.synchronize()
+        assert float(ts.mgr.hyper[ops.HYP_GRAD_SCALE]) == 0.5 and float(ts.mgr.hyper[4]) == 2.0
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_two_ranks_matches_one_shot(gpu_lib):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(out.keys()) == list(range(world))
+
+
+def test_bench_gpus_2_launches_itself(gpu_lib):
+    """`python bench.py --gpus 2` without a launcher environment re-launches itself under torch.distributed.run, runs the full-size
+    supernet step on two ranks (both on cuda:0, gloo: the box has one GPU), the rank-0 profile pass included, and prints ONE JSON
+    line whose rank count matches --gpus."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--batch", "8",
+                        "--steps", "2", "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["config"]["parallelism"] == "dp2"
+    assert len(j["rank_ms_per_step"]) == 2 and j["comm_backend"] == "gloo" and j["comm_mode"] == "host" and j["rccl_ranks"] == 0
+    assert j["value"] > 0 and "roofline" in j and "pointwise" in j and j["pointwise"]["frac_mfma"] > 0
+    # a launcher / flag mismatch is an error, not a mislabelled 1-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "8", "--steps", "1"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "must agree" in (bad.stdout + bad.stderr)

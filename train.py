@@ -119,6 +119,9 @@ def load_checkpoint(ckpt, model_wrapper, optimizer, ema):
     names = ckpt.get('optimizer_param_names')
     if names:
         table = dict(model_wrapper.named_parameters())
+        if not any(n in table for n in names):   # written under the other wrapper form: same normalisation as the model keys
+            names = ([n[len('module.'):] for n in names] if all(n.startswith('module.') for n in names)
+                     else ['module.' + n for n in names])
         optimizer.param_groups[0]['params'] = [table[n] for n in names]
     optimizer.load_state_dict(ckpt['optimizer'])
     if ema:
@@ -192,7 +195,8 @@ def train_val_test():
             state = {'model': {k: v.detach().clone() for k, v in model_wrapper.state_dict().items()}, 'optimizer': optimizer.state_dict(),
                      'optimizer_param_names': [pname[id(p)] for p in optimizer.param_groups[0]['params']],
                      'ema': ema.state_dict() if ema else None, 'last_epoch': epoch, 'best_val': min(best_val, results['top1_error']),
-                     'meters': None}
+                     # the reference's resume unpacks `train_meters, val_meters = checkpoint['meters']` (train.py:313): a pair
+                     'meters': (None, None)}
             torch.save(state, os.path.join(FLAGS.log_dir, 'latest_checkpoint.pt'))
             with open(os.path.join(FLAGS.log_dir, 'latest_checkpoint.yml'), 'w') as f:
                 f.write(str(kw))
