@@ -51,6 +51,7 @@ struct CwGeom {
   int N, H, W, C;
   int TH, NI, tiles_y, ns;   // tile: NI images x TH rows x W columns; ns = W / 7 strips per row
   int LH, LWp, plane;        // operand window: rows per image, row pitch, elements (f32x2) per channel-pair plane
+  int RH;                    // rows of the window ring per image (= LH)
   int TPIX, TPIXp;           // pixels per tile; pitch of the pixel planes
   int nworkers, nslabs, ntiles;
   int ring;                  // 1: several tiles per image, the window rows are a ring
@@ -133,14 +134,21 @@ __device__ __forceinline__ float cw_bcast(float v, int l) {
 __device__ __forceinline__ unsigned cw_lds_addr(const void* p) {
   return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
 }
-// One operand row of a lane: NR consecutive channel pairs (8 bytes each) from LDS byte address `addr`.  Inline asm on purpose:
-// hipcc's load/store optimizer merges neighbouring ds_read_b64 into ds_read2_b64, which moves the same bytes in twice the LDS
-// cycles (MI355X_MICROARCH.md, LDS table).  The reads are invisible to the compiler's wait counters: the wait and the scheduling
-// fence below make every result valid before its first use (cdna_hip_programming.md 5.7 form iii).
-template <int NR>
-__device__ __forceinline__ void cw_read_row(f32x2 (&v)[NR], unsigned addr) {
+// The operands of one tap row, all asynchronous: the K tap pairs of the wave's channel pair as scalar loads (s_load_dwordx2 from
+// the tap-major table: wave-uniform, so they cost no vector instruction and no vector register -- v_readlane broadcasts were
+// measured at 9 cycles each, 14 per row next to 98 FMAs of ~4, tools/probe/vpk.hip) and the lane's NR consecutive operand pairs
+// from LDS.  Inline asm on purpose: hipcc's load/store optimizer merges neighbouring ds_read_b64 into ds_read2_b64, which moves
+// the same bytes in twice the LDS cycles (MI355X_MICROARCH.md, LDS table), and it cannot keep SMEM results in flight across
+// its own waits.  The loads are invisible to the compiler's wait counters: cw_row_wait() makes every result valid before its first
+// use (s_waitcnt + scheduling fence; cdna_hip_programming.md 5.7 form iii).
+template <int K, int NR>
+__device__ __forceinline__ void cw_row_issue(f32x2 (&wr)[K], f32x2 (&v)[NR], const float* wp, unsigned tap_off, unsigned ld4, unsigned addr) {
+#pragma unroll
+  for (int kx = 0; kx < K; ++kx) asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(wr[kx]) : "s"(wp), "s"(tap_off + (unsigned)kx * ld4));
 #pragma unroll
   for (int i = 0; i < NR; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[i]) : "v"(addr), "i"(i * 8));
+}
+__device__ __forceinline__ void cw_row_wait() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -165,7 +173,7 @@ __device__ __forceinline__ void cw_decode(CwSlots& s, const CwGeom& g, int tid, 
     s.pp[i] = ok ? pp : -1;
     s.rr[i] = rr;
     s.im[i] = im;
-    s.dyo[i] = im * g.LH * g.LWp + col + P;
+    s.dyo[i] = im * g.RH * g.LWp + col + P;
     s.goff[i] = ((im * g.H + rr) * g.W + col) * 16 + cg * 8;
   }
 }
@@ -189,7 +197,7 @@ __device__ __forceinline__ bool cw_block(const CwGeom& g, int& slab, int& worker
 // ---------------------------------------------------------------------------------------------------------------- backward
 //   dYraw = c1*g + c2*yraw + c3 (BN-backward of the BN behind the conv, on load; yraw == NULL: dYraw = g)
 //   h = dwconv^T(dYraw) * act'(x*in_scale+in_shift),  dW += corr(act(x*in_scale+in_shift), dYraw),  stats: sum h, sum h*x
-template <typename T, int K, int AM, int NW, int WPS>
+template <typename T, int K, int AM, int NW, int WPS, bool PF>
 __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ gup, long gss, const T* __restrict__ yraw, long yrss,
                                                      const float* __restrict__ c1, const float* __restrict__ c2p,
                                                      const float* __restrict__ c3, const T* __restrict__ x, long xss,
@@ -228,13 +236,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
   float sc0 = 1.f, sc1 = 1.f, sh0 = 0.f, sh1 = 0.f;
   if (in_scale && ch < cpad) { sc0 = in_scale[ch]; sc1 = in_scale[ch + 1]; sh0 = in_shift[ch]; sh1 = in_shift[ch + 1]; }
   const bool ch0_ok = ch < g.C, ch1_ok = ch + 1 < g.C;
-  // tap table of the pair: lane t (< k*k) holds tap t of both channels; the tap loop broadcasts them with v_readlane (constant lane)
-  // into scalar registers -- two vector registers and one instruction per scalar instead of k*k LDS reads or k*k loads per row
-  float wl0 = 0.f, wl1 = 0.f;
-  if (lane < KK) {
-    if (ch0_ok) wl0 = w[(long)lane * ldw + ch];
-    if (ch1_ok) wl1 = w[(long)lane * ldw + ch + 1];
-  }
+  // taps of the pair: w[t * ldw + ch], w[t * ldw + ch + 1] (ldw >= C rounded up to 8: the host side checks), read per tap row
+  // as wave-uniform scalars.  Taps of channels beyond C are whatever the table holds there: their results are forced to zero.
+  const float* wp = w + ch;
+  unsigned ld4 = (unsigned)ldw * 4u;
 
   CwSlots sl;
   cw_decode<P, NT, CGS>(sl, g, tid, cg);
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
   const int it_r = it_rem / g.ns, it_j = it_rem % g.ns;
   const bool it_ok = lane < g.NI * ipi;
   const int pix0 = (it_im * g.TH + it_r) * g.W + SW * it_j;
-  const unsigned dy_addr0 = cw_lds_addr(s_dy + wv * g.plane + it_im * g.LH * g.LWp + SW * it_j);   // + slot * LWp * 8
+  const unsigned dy_addr0 = cw_lds_addr(s_dy + wv * g.plane + it_im * g.RH * g.LWp + SW * it_j);   // + slot * LWp * 8
 
   f32x2 dwa[KK];
 #pragma unroll
@@ -373,9 +378,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
     if (tile + 1 < t_end) issue(nnb * g.NI, nty * g.TH);
     CWMARK(3)
 
-    // opaque per tile (in uniform control flow: every lane of the table stays defined): the 2 k^2 broadcasts stay in their tap rows
-    // instead of being hoisted out of the tile loop, where they spill
-    asm volatile("" : "+v"(wl0), "+v"(wl1));
+    // opaque per tile: the k^2 tap offsets are formed in their tap rows instead of being hoisted out of the tile loop (they spill)
+    asm volatile("" : "+s"(ld4));
     if (it_ok && n0 + it_im < g.N && hi0 + it_r < g.H && ch < cpad) {
       pair_t* xp = s_x + wv * g.TPIXp + pix0;
       pair_t xq[SW];
@@ -389,25 +393,37 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
         asm volatile("" : "+v"(xa[t]));   // computed here, not sunk behind the tap rows (that keeps every operand row alive)
       }
       asm volatile("" ::: "memory");
-#pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
+      // tap rows.  PF (k = 7, where the registers allow two waves per SIMD anyway): the operands of row ky + 1 are in flight while
+      // row ky is multiplied -- two operand buffers, static indices after unrolling.
+      f32x2 dyb[PF ? 2 : 1][DWN], wb[PF ? 2 : 1][K];
+      auto row_addr = [&](int ky) {
         int slot = it_r + (K - 1 - ky) + base;
         if (slot >= g.LH) slot -= g.LH;
-        f32x2 dy[DWN];
-        cw_read_row<DWN>(dy, dy_addr0 + (unsigned)(slot * g.LWp) * 8u);
+        return dy_addr0 + (unsigned)(slot * g.LWp) * 8u;
+      };
+      if (PF) cw_row_issue<K, DWN>(wb[0], dyb[0], wp, 0u, ld4, row_addr(0));
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        constexpr int dummy = 0; (void)dummy;
+        const int cur = PF ? (ky & 1) : 0;
+        if (!PF) cw_row_issue<K, DWN>(wb[0], dyb[0], wp, (unsigned)(ky * K) * ld4, ld4, row_addr(ky));
+        cw_row_wait();
+        if (PF && ky + 1 < K) {
+          cw_row_issue<K, DWN>(wb[cur ^ 1], dyb[cur ^ 1], wp, (unsigned)((ky + 1) * K) * ld4, ld4, row_addr(ky + 1));
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-          const f32x2 wv2 = f32x2{cw_bcast(wl0, ky * K + kx), cw_bcast(wl1, ky * K + kx)};
 #pragma unroll
           for (int t = 0; t < SW; ++t) {
-            dx[t] += dy[t + (K - 1 - kx)] * wv2;
-            dwa[ky * K + kx] += xa[t] * dy[t + (K - 1 - kx)];
+            dx[t] += dyb[cur][t + (K - 1 - kx)] * wb[cur][kx];
+            dwa[ky * K + kx] += xa[t] * dyb[cur][t + (K - 1 - kx)];
           }
-          asm volatile("" : "+v"(dwa[ky * K + kx]));   // this row's FMAs are done before the next row's reads are issued
+          asm volatile("" : "+v"(dwa[ky * K + kx]));   // this row's FMAs are done before the next row's operands are touched
         }
 #pragma unroll
         for (int t = 0; t < SW; ++t) asm volatile("" : "+v"(dx[t]));
-        __builtin_amdgcn_sched_barrier(0);   // one operand row live at a time (the tap loop is unrolled for static dwa indices)
+        __builtin_amdgcn_sched_barrier(0);   // one / two operand rows live at a time (the tap loop is unrolled for static dwa indices)
       }
       // epilogue: activation backward of the producer, rounding, statistics; h replaces x in its LDS slot
 #pragma unroll
@@ -523,12 +539,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwf_cw(const T* __restrict__ x
     s_cf[tid] = (in_scale && c < cpad) ? (v == 0 ? in_scale[c] : in_shift[c]) : (v == 0 ? 1.f : 0.f);
   }
   const bool ch0_ok = ch < g.C, ch1_ok = ch + 1 < g.C;
-  constexpr int KK = K * K;
-  float wl0 = 0.f, wl1 = 0.f;   // tap table of the pair, see k_dwb_cw
-  if (lane < KK) {
-    if (ch0_ok) wl0 = w[(long)lane * ldw + ch];
-    if (ch1_ok) wl1 = w[(long)lane * ldw + ch + 1];
-  }
+  const float* wp = w + ch;   // taps of the pair as wave-uniform scalars, see k_dwb_cw
+  unsigned ld4 = (unsigned)ldw * 4u;
 
   CwSlots sl;
   cw_decode<P, NT, CGS>(sl, g, tid, cg);
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwf_cw(const T* __restrict__ x
   const int it_r = it_rem / g.ns, it_j = it_rem % g.ns;
   const bool it_ok = lane < g.NI * ipi;
   const int pix0 = (it_im * g.TH + it_r) * g.W + SW * it_j;
-  const unsigned in_addr0 = cw_lds_addr(s_in + wv * g.plane + it_im * g.LH * g.LWp + SW * it_j);
+  const unsigned in_addr0 = cw_lds_addr(s_in + wv * g.plane + it_im * g.RH * g.LWp + SW * it_j);
 
   float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
   piece_t pfx[2];
@@ -627,26 +639,34 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwf_cw(const T* __restrict__ x
     if (nty == g.tiles_y) { nty = 0; ++nnb; }
     if (tile + 1 < t_end) issue(nnb * g.NI, nty * g.TH);
 
-    asm volatile("" : "+v"(wl0), "+v"(wl1));   // see k_dwb_cw
+    asm volatile("" : "+s"(ld4));   // see k_dwb_cw
     if (it_ok && n0 + it_im < g.N && ho0 + it_r < g.H && ch < cpad) {
       f32x2 acc[SW];
 #pragma unroll
       for (int t = 0; t < SW; ++t) acc[t] = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
+      f32x2 inb[2][IWN], wb[2][K];   // two operand buffers: row ky + 1 is in flight while row ky is multiplied
+      auto row_addr = [&](int ky) {
         int slot = it_r + ky + base;
         if (slot >= g.LH) slot -= g.LH;
-        f32x2 in[IWN];
-        cw_read_row<IWN>(in, in_addr0 + (unsigned)(slot * g.LWp) * 8u);
+        return in_addr0 + (unsigned)(slot * g.LWp) * 8u;
+      };
+      cw_row_issue<K, IWN>(wb[0], inb[0], wp, 0u, ld4, row_addr(0));
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const f32x2 wv2 = f32x2{cw_bcast(wl0, ky * K + kx), cw_bcast(wl1, ky * K + kx)};
-#pragma unroll
-          for (int t = 0; t < SW; ++t) acc[t] += in[t + kx] * wv2;
+      for (int ky = 0; ky < K; ++ky) {
+        const int cur = ky & 1;
+        cw_row_wait();
+        if (ky + 1 < K) {
+          cw_row_issue<K, IWN>(wb[cur ^ 1], inb[cur ^ 1], wp, (unsigned)((ky + 1) * K) * ld4, ld4, row_addr(ky + 1));
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int t = 0; t < SW; ++t) asm volatile("" : "+v"(acc[t]));   // this row's FMAs are done before the next row's reads
-        __builtin_amdgcn_sched_barrier(0);   // one operand row live at a time
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+          for (int t = 0; t < SW; ++t) acc[t] += inb[cur][t + kx] * wb[cur][kx];
+        }
+#pragma unroll
+        for (int t = 0; t < SW; ++t) asm volatile("" : "+v"(acc[t]));   // this row's FMAs are done before the next row's operands
+        __builtin_amdgcn_sched_barrier(0);
       }
       pair_t* yp = s_y + wv * g.TPIXp + pix0;
 #pragma unroll
@@ -706,7 +726,8 @@ static bool cw_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
   int lwp = lw;
   if (pow2) { while (lwp % (2 * g.ns) != g.ns) ++lwp; } else if (lwp % 2 == 0) ++lwp;
   g.LWp = lwp;
-  int plane = g.NI * g.LH * g.LWp;
+  g.RH = g.LH;
+  int plane = g.NI * g.RH * g.LWp;
   if (plane < 512) plane = 512;      // the weight-gradient flush transposes 64 x 15 + 56 floats through a wave's own plane
   while (plane % 4 != 2) ++plane;     // staging writes of the two channel groups land in different bank halves
   g.plane = plane;
@@ -759,17 +780,17 @@ static int cw_launch_bwd(const void* gup, long gss, const void* yraw, long yrss,
   if (lds > 160 * 1024) return -1;
   // waves per SIMD the instances are compiled for: half-slab workgroups 3 (k = 3: 139 registers) or 2; whole-slab workgroups 2
   constexpr int WPS4 = K == 3 ? 3 : 2;
-#define CW_BWD(AMV, NWV, WPSV)                                                                                              \
+#define CW_BWD(KERN, AMV, NWV, WPSV)                                                                                        \
   {                                                                                                                         \
-    auto kern = k_dwb_cw<T, K, AMV, NWV, WPSV>;                                                                             \
+    auto kern = KERN<T, K, AMV, NWV, WPSV, (K == 7)>;                                                                                 \
     cw_workers(g, resident_per_cu(kern, NWV * 64, lds), (stats || dw) ? part_rows : 0, NWV);                                \
     hipLaunchKernelGGL(kern, dim3(cw_grid(g, NWV)), dim3(NWV * 64), lds, st, (const T*)gup, gss, (const T*)yraw, yrss, c1, c2, \
                        c3, (const T*)x, xss, sc, sh, relu, w, ldw, (T*)h, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g); \
   }
   if (nw == 4) {
-    if (relu == ACT_RELU6) CW_BWD(ACT_RELU6, 4, WPS4) else if (relu == ACT_SWISH) CW_BWD(ACT_SWISH, 4, WPS4) else CW_BWD(0, 4, WPS4)
+    if (relu == ACT_RELU6) CW_BWD(k_dwb_cw, ACT_RELU6, 4, WPS4) else if (relu == ACT_SWISH) CW_BWD(k_dwb_cw, ACT_SWISH, 4, WPS4) else CW_BWD(k_dwb_cw, 0, 4, WPS4)
   } else {
-    if (relu == ACT_RELU6) CW_BWD(ACT_RELU6, 8, 2) else if (relu == ACT_SWISH) CW_BWD(ACT_SWISH, 8, 2) else CW_BWD(0, 8, 2)
+    if (relu == ACT_RELU6) CW_BWD(k_dwb_cw, ACT_RELU6, 8, 2) else if (relu == ACT_SWISH) CW_BWD(k_dwb_cw, ACT_SWISH, 8, 2) else CW_BWD(k_dwb_cw, 0, 8, 2)
   }
 #undef CW_BWD
   if (int rc = check_launch("dwconv_bwd(cw)")) return rc;
@@ -806,7 +827,7 @@ int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
                   const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h, long hss,
                   float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int dtype,
                   hipStream_t st) {
-  if (!(cw_mode() & 1) || gss == 0 || xss == 0 || hss == 0 || (yraw && yrss == 0)) return -1;
+  if (!(cw_mode() & 1) || gss == 0 || xss == 0 || hss == 0 || (yraw && yrss == 0) || ldw < ((C + 7) & ~7)) return -1;
 #define CW_B(TT, KV) return cw_launch_bwd<TT, KV>(gup, gss, yraw, yrss, c1, c2, c3, x, xss, sc, sh, relu, w, ldw, h, hss, dw, stats, stat_ld, part_rows, dw_ws, N, H, W, C, st)
   if (dtype == DT_F32) {
     if (k == 3) CW_B(float, 3); if (k == 5) CW_B(float, 5); if (k == 7) CW_B(float, 7);
@@ -819,7 +840,7 @@ int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
 
 int dwconv_cw_fwd(const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y, long yss,
                   float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int dtype, hipStream_t st) {
-  if (!(cw_mode() & 2) || xss == 0 || yss == 0) return -1;
+  if (!(cw_mode() & 2) || xss == 0 || yss == 0 || ldw < ((C + 7) & ~7)) return -1;
 #define CW_F(TT, KV) return cw_launch_fwd<TT, KV>(x, xss, sc, sh, relu, w, ldw, y, yss, stats, stat_ld, stat_rows, N, H, W, C, st)
   if (dtype == DT_F32) {
     if (k == 3) CW_F(float, 3); if (k == 5) CW_F(float, 5); if (k == 7) CW_F(float, 7);
