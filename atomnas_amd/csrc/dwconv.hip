@@ -89,6 +89,9 @@ template <> struct Raw8<float> {
   __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e] : b[e - 4]; }
 };
 
+__device__ __forceinline__ void dw_touch(const Raw8<bf16_t>& r) { asm volatile("" ::"v"(r.v)); }   // "the register is read here"
+__device__ __forceinline__ void dw_touch(const Raw8<float>& r) { asm volatile("" ::"v"(r.a), "v"(r.b)); }
+
 // one channel pair of one pixel, raw
 template <typename T> struct Raw2;
 template <> struct Raw2<bf16_t> {
@@ -211,15 +214,14 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   auto issue = [&](int n, int ty, int tx, int rowmin) {
     const int hi0 = ty * g.TH * S - P, wi0 = tx * g.TW * S - P;
     const long xps = pix_stride(ldx, xss);
-    const T* xn = x + (long)n * g.H * g.W * xps + chan_base(c_base + cg * 8, xss);
+    const T* xn = x + (long)n * g.H * g.W * xps + chan_base(cg_ok ? c_base + cg * 8 : 0, xss);
     pfmask = 0;
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
+    for (int i = 0; i < PF; ++i) {   // branch-free: see k_dwconv_bwd
       const int hi = hi0 + p_iy[i], wi = wi0 + p_ix[i];
-      if (cg_ok && p_iy[i] >= rowmin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
-        pf[i].load(xn + ((long)hi * g.W + wi) * xps);
-        pfmask |= 1u << i;
-      }
+      const bool ok = cg_ok && p_iy[i] >= rowmin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+      pf[i].load(xn + (ok ? ((long)hi * g.W + wi) * xps : 0));
+      pfmask |= ok ? 1u << i : 0u;
     }
   };
   auto commit = [&](int rowmin, int base) {
@@ -297,6 +299,8 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
   for (; tile < t_end; ++tile) {
     const int ho0 = ty * g.TH, wo0 = tx * g.TW;
     __syncthreads();  // previous tile fully consumed, its output complete in s_y (also orders the s_w initialisation)
+#pragma unroll
+    for (int i = 0; i < PF; ++i) dw_touch(pf[i]);   // every prefetched register is read here on every path
     if (DW_FWD_STAGE && sn >= 0) store_y(sn, sty, stx);
     if (DW_EXP != 3) commit(rowmin, base);
     __syncthreads();
@@ -324,8 +328,13 @@ __global__ __launch_bounds__(256) void k_dwconv_fwd(const T* __restrict__ x, int
         if (slot >= g.LH) slot -= g.LH;
         const float* row = s_in + slot * g.RP + (j * SW * S) * CB + 2 * c2;
         f32x2 in[IWS];
+        {   // single ds_read_b64 each, see k_dwconv_bwd
+          const unsigned ra = lds_addr(row);
 #pragma unroll
-        for (int i = 0; i < IWS; ++i) in[i] = *reinterpret_cast<const f32x2*>(row + i * CB);
+          for (int i = 0; i < IWS; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(in[i]) : "v"(ra), "i"(i * CB * 4));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
           const f32x2 wv = *reinterpret_cast<const f32x2*>(s_w + (ky * K + kx) * CB + 2 * c2);
@@ -411,6 +420,7 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
   constexpr int LMAXB = fdiv(TM - 1 + P, S) - cdiv(P - (K - 1), S) + 1;  // dY window of a TM-pixel input tile
   constexpr int PF = (LMAXB * (fdiv(TM - 1 + P, S) - fdiv(-P, S) + 1) * (CB / 8) + 255) / 256;
   static_assert(PF <= 32, "prefetch mask is 32 bits");
+  static_assert((TM * TM * (CB / 8) + 255) / 256 <= 32, "x prefetch mask is 32 bits");
   constexpr bool DMA = DW_DMA && sizeof(T) == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // raw staging of the next tile's dY / yraw pieces (lane-linear: piece i of thread t at (i*256 + t) * 16 bytes); first in LDS
@@ -475,23 +485,30 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
   auto issue = [&](int n, int ty, int tx, int rowmin) {
     const int hob = cdiv(ty * g.TH + P - (K - 1), S), wob = (tx * g.TW) / S + RELMIN;
     const long gps = pix_stride(ldg, gss), yps = pix_stride(ldyr, yrss);
-    const T* gn = gup + (long)n * g.Ho * g.Wo * gps + chan_base(c_base + cg * 8, gss);
-    const T* yn = yraw ? yraw + (long)n * g.Ho * g.Wo * yps + chan_base(c_base + cg * 8, yrss) : nullptr;
+    const int cgc = cg_ok ? c_base + cg * 8 : 0;   // a channel group beyond C reads group 0 (masked), never beyond the tensor
+    const T* gn = gup + (long)n * g.Ho * g.Wo * gps + chan_base(cgc, gss);
+    const T* yn = yraw ? yraw + (long)n * g.Ho * g.Wo * yps + chan_base(cgc, yrss) : nullptr;
     pfmask = 0;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int ho = hob + p_iy[i], wo = wob + p_ix[i];
-      if (DW_EXP != 8 && DW_EXP != 11 && cg_ok && p_iy[i] >= rowmin && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
-        const long off = (long)ho * g.Wo + wo;
-        if constexpr (DMA) {
+      const bool ok = DW_EXP != 8 && DW_EXP != 11 && cg_ok && p_iy[i] >= rowmin && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo;
+      if constexpr (DMA) {
+        if (ok) {
+          const long off = (long)ho * g.Wo + wo;
           lds_dma16(gn + off * gps, rawg_base + (unsigned)i * 256u * 16u);
           if (yn && DW_EXP != 9) lds_dma16(yn + off * yps, rawy_base + (unsigned)i * 256u * 16u);
-        } else {
-          pfg[i].load(gn + off * gps);
-          if (yn && DW_EXP != 9) pfy[i].load(yn + off * yps);
         }
-        pfmask |= 1u << i;
+      } else {
+        // Branch-free (round 3): a piece outside the image / the channel range reads the first piece of the image instead and is
+        // masked at the commit.  With the loads under per-lane branches hipcc cannot prove at the loop back-edge that they were
+        // waited for and puts an s_waitcnt vmcnt(0) in front of the next tile's loads, which also waits for the h stores issued
+        // just before (csrc/dwconv_cw.hip, same finding: 20-30 % of the kernel).
+        const long off = ok ? (long)ho * g.Wo + wo : 0;
+        pfg[i].load(gn + off * gps);
+        if (yn && DW_EXP != 9) pfy[i].load(yn + off * yps);
       }
+      pfmask |= ok ? 1u << i : 0u;
     }
   };
   auto commit = [&](int rowmin, int base) {
@@ -551,19 +568,26 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
     xp_c[p] = pix % g.TW;
   }
   Raw8<T> xr[XP];
-  auto issue_x = [&](int an, int aty, int atx) {
+  unsigned xmask = 0;
+  auto issue_x = [&](int an, int aty, int atx) {   // branch-free, see issue()
+    xmask = 0;
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       const int hi = aty * g.TH + xp_r[p], wi = atx * g.TW + xp_c[p];
-      xr[p].zero();
-      if (DW_EXP != 7 && DW_EXP != 11 && cg_ok && hi >= 0 && hi < g.H && wi < g.W)
-        xr[p].load(x + (((long)an * g.H + hi) * g.W + wi) * pix_stride(ldx, xss) + chan_base(c_base + cg * 8, xss));
+      const bool ok = DW_EXP != 7 && DW_EXP != 11 && cg_ok && hi >= 0 && hi < g.H && wi < g.W;
+      const long pix = ok ? ((long)an * g.H + hi) * g.W + wi : (long)an * g.H * g.W;
+      xr[p].load(x + pix * pix_stride(ldx, xss) + chan_base(cg_ok ? c_base + cg * 8 : 0, xss));
+      xmask |= ok ? 1u << p : 0u;
     }
   };
   auto commit_x = [&]() {
 #pragma unroll
     for (int p = 0; p < XP; ++p)
-      if (xp_r[p] >= 0) xr[p].store(s_x + (xp_r[p] * g.TW + xp_c[p]) * CB + cg * 8);
+      if (xp_r[p] >= 0) {
+        Raw8<T> v = xr[p];
+        if (!((xmask >> p) & 1u)) v.zero();
+        v.store(s_x + (xp_r[p] * g.TW + xp_c[p]) * CB + cg * 8);
+      }
   };
   auto store_h = [&](int an, int aty, int atx) {
 #pragma unroll
@@ -604,6 +628,12 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
     if (!XPRE) issue_x(n, ty, tx);
     __syncthreads();   // previous tile fully consumed, its result complete in s_h
     TMARK(0)
+    if constexpr (!DMA) {   // every prefetched register is read here on every path: nothing is pending at the next issue
+#pragma unroll
+      for (int i = 0; i < PF; ++i) { dw_touch(pfg[i]); dw_touch(pfy[i]); }
+#pragma unroll
+      for (int p = 0; p < XP; ++p) dw_touch(xr[p]);
+    }
     if (hn >= 0) store_h(hn, hty, htx);
     commit(rowmin, base);
     commit_x();
@@ -644,7 +674,9 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
           else if constexpr (AM == ACT_SWISH) xa[t] = f32x2{swish_f(a0), swish_f(a1)};
           else xa[t] = in_relu ? f32x2{fmaxf(a0, 0.f), fmaxf(a1, 0.f)} : f32x2{a0, a1};
         }
+        asm volatile("" : "+v"(xa[t]));   // computed here, before the tap rows
       }
+      asm volatile("" ::: "memory");
       f32x2 dx[SW];
 #pragma unroll
       for (int t = 0; t < SW; ++t) dx[t] = f32x2{0.f, 0.f};
@@ -659,8 +691,15 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
         if (slot >= g.LH) slot -= g.LH;
         const float* row = s_dy + slot * g.RP + ((wis - wi0) / S) * CB + 2 * cc2;
         f32x2 dy[DWN];
+        {
+          // single ds_read_b64 each (inline asm): hipcc merges neighbours into ds_read2_b64, which moves the same bytes in twice
+          // the LDS cycles (MI355X_MICROARCH.md, LDS table); the wait and the fence make the results valid before their use
+          const unsigned ra = lds_addr(row);
 #pragma unroll
-        for (int i = 0; i < DWN; ++i) dy[i] = *reinterpret_cast<const f32x2*>(row + i * CB);
+          for (int i = 0; i < DWN; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dy[i]) : "v"(ra), "i"(i * CB * 4));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
           const f32x2 wv = *reinterpret_cast<const f32x2*>(s_w + (ky * K + kx) * CB + 2 * cc2);
@@ -677,7 +716,10 @@ __global__ __launch_bounds__(256, (K <= 5 ? DW_BWD_MINB5 : 2)) void k_dwconv_bwd
       }
 
       TMARK(4)
-      // epilogue: ReLU mask of the producer, rounding, statistics; the result goes to LDS and leaves with the next tile
+      // epilogue: ReLU mask of the producer, rounding, statistics; the result goes to LDS and leaves with the next tile.  The raw
+      // pixels are read again from LDS rather than kept in registers across the tap rows (k = 7 spilled: round 3).
+#pragma unroll
+      for (int t = 0; t < SW; ++t) xq[q][t].load(s_x + (pix0 + t) * CB + 2 * cc2);
 #pragma unroll
       for (int t = 0; t < SW; ++t) {
         const int wi = wis + t;
