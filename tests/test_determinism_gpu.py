@@ -106,7 +106,7 @@ def _run_full_size(use_graph, steps=3):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, ROOT)
     import bench
-    model, ts, hp = bench.build("atomnas_c_supernet", torch.bfloat16, 4, seed=11)
+    model, ts, hp = bench.build("atomnas_c_supernet", torch.bfloat16, 4, seed=11)[:3]
     ts.use_graph = use_graph
     g = torch.Generator().manual_seed(6)
     for step in range(steps):

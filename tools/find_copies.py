@@ -3,7 +3,7 @@ import sys, torch, collections
 sys.path.insert(0, "/root/repo")
 import bench
 from torch.profiler import profile, ProfilerActivity
-model, ts, hp = bench.build("atomnas_c_supernet", torch.bfloat16, 32, 1995)
+model, ts, hp = bench.build("atomnas_c_supernet", torch.bfloat16, 32, 1995)[:3]
 ts.use_graph = False
 ts.set_batch(torch.randn(32, 3, 224, 224, device="cuda"), torch.randint(0, 1000, (32,), device="cuda"))
 for _ in range(2): ts.step(rho=1e-4)
