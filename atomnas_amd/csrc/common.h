@@ -203,8 +203,8 @@ int dwconv_cw_fwd(const void* x, long xss, const float* sc, const float* sh, int
                   float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int dtype, hipStream_t st);
 int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
                   const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h, long hss,
-                  float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int dtype,
-                  hipStream_t st);
+                  float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride,
+                  int dtype, hipStream_t st);
 
 #define ATOMNAS_REQUIRE(cond, ...)            \
   do {                                        \

@@ -55,6 +55,9 @@ struct CwGeom {
   int TPIX, TPIXp;           // pixels per tile; pitch of the pixel planes
   int nworkers, nslabs, ntiles;
   int ring;                  // 1: several tiles per image, the window rows are a ring
+  // stride-2 kernels (k_dwb_cw2 / k_dwf_cw2): the lanes live on the dY / output grid (Ho x Wo), the window holds that grid
+  int Ho, Wo, THd;           // output rows / columns, output rows per tile (TH = 2 THd input rows)
+  int TPIXD;                 // output pixels per tile
 };
 
 // storage-type plumbing: `piece` = 8 channels of one pixel (16-byte global accesses), `pair` = one channel pair of one pixel
@@ -506,6 +509,327 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------- backward, stride 2
+// Stride-2 depthwise backward in the same form.  The lanes live on the dY grid (Ho x Wo = H/2 x W/2): a lane owns 7 dY columns of
+// one dY row, i.e. a 2 x 14 block of input pixels, and walks its two input rows one after the other.  Which taps meet which input
+// pixel is a matter of row / column parity, and with whole 2 x 14 blocks per lane every parity test is a compile-time constant:
+// no lane is masked (the tile kernels lose half of the lanes of every tap row of a stride-2 layer).  The window holds dYraw exactly as
+// in k_dwb_cw (ring over dY rows, HL kept rows); the input tile is 4x the dY tile (2 THd x W pixels, contiguous in HBM because the
+// tile spans the full width), staged through 7 register slots per thread that need no per-slot state.
+constexpr __host__ __device__ int cw_fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+template <typename T, int K, int AM, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw2(const T* __restrict__ gup, long gss, const T* __restrict__ yraw, long yrss,
+                                                          const float* __restrict__ c1, const float* __restrict__ c2p,
+                                                          const float* __restrict__ c3, const T* __restrict__ x, long xss,
+                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                          int in_relu, const float* __restrict__ w, int ldw, T* __restrict__ h, long hss,
+                                                          float* __restrict__ dwp, float* __restrict__ stats, int stat_ld,
+                                                          int stat_rows, CwGeom g) {
+  typedef Cw<T> X;
+  typedef typename X::pair_t pair_t;
+  typedef typename X::piece_t piece_t;
+  constexpr int P = (K - 1) / 2, KK = K * K, SW = 14, NT = NW * 64, CGS = NW / 4;
+  constexpr int RELMIN = cw_fdiv(-P, 2), RELMAX = cw_fdiv(SW - 1 + P, 2), DWN = RELMAX - RELMIN + 1, CL = -RELMIN;
+  constexpr int RT = P / 2;                              // dY rows above the first row pair of a tile that its taps reach
+  constexpr int HL = RT + cw_fdiv(P - 1, 2) + 1;         // window rows shared with the tile above (LH = THd + HL)
+  constexpr int XS = (448 * 4 * CGS + NT - 1) / NT;      // staging slots of the input tile (<= 64 lanes x 28 pixels)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x2* s_dy = reinterpret_cast<f32x2*>(smem);                    // [NW pairs][plane]
+  pair_t* s_x = reinterpret_cast<pair_t*>(s_dy + NW * g.plane);     // [NW pairs][TPIXp]: raw input pixels, replaced by h in place
+  float* s_cf = reinterpret_cast<float*>(s_x + NW * g.TPIXp);       // [3][16]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int slab, worker, half;
+  if (!cw_block<NW>(g, slab, worker, half)) return;
+  const int c_base = slab * 16;
+  const int ch = c_base + 2 * (wv + 4 * half);
+  const int cpad = (g.C + 7) & ~7;
+  const int cgl = CGS == 2 ? (tid & 1) : 0;
+  const int cg = cgl + half;
+  const bool cg_ok = c_base + cg * 8 < cpad;
+
+  for (int i = tid; i < NW * g.plane; i += NT) s_dy[i] = f32x2{0.f, 0.f};
+  if (tid < 48) {
+    const int v = tid >> 4, c = c_base + (tid & 15);
+    const float* src = (v == 0) ? c1 : (v == 1 ? c2p : c3);
+    s_cf[tid] = (c1 && src && (v == 0 || yraw) && c < cpad) ? src[c] : (v == 0 ? 1.f : 0.f);
+  }
+  float sc0 = 1.f, sc1 = 1.f, sh0 = 0.f, sh1 = 0.f;
+  if (in_scale && ch < cpad) { sc0 = in_scale[ch]; sc1 = in_scale[ch + 1]; sh0 = in_shift[ch]; sh1 = in_shift[ch + 1]; }
+  const bool ch0_ok = ch < g.C, ch1_ok = ch + 1 < g.C;
+  const float* wp = w + ch;   // taps of the pair as wave-uniform scalars, see k_dwb_cw
+  unsigned ld4 = (unsigned)ldw * 4u;
+
+  // dY staging slots (two per thread): piece (tid + i NT) of the tile's dY rows, (image, row, column, channel group)
+  int d_pp[2], d_rr[2], d_dyo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pp = (tid + i * NT) / CGS;
+    d_pp[i] = pp < g.TPIXD ? pp : -1;
+    const int col = pp % g.Wo, t2 = pp / g.Wo;
+    d_rr[i] = t2 % g.THd;
+    d_dyo[i] = (t2 / g.THd) * g.RH * g.LWp + col + CL;
+  }
+  int cgoff = cg * 8;   // channel-group offset inside a 16-channel pixel (opaque per tile, see k_dwb_cw)
+  int tq = tid;         // thread id as the staging slots see it: opaque per tile, so that the 7 x 4 plane addresses and the 7 global
+                        // offsets of the input slots are formed where they are used instead of living in registers across the tap rows
+
+  // work item of this lane: (image, dY row, strip of 7 dY columns) = input rows 2 m, 2 m + 1, input columns 14 j .. 14 j + 13
+  const int ipi = g.THd * g.ns;
+  const int it_im = lane / ipi, it_rem = lane % ipi;
+  const int it_m = it_rem / g.ns, it_j = it_rem % g.ns;
+  const bool it_ok = lane < g.NI * ipi;
+  const int pix00 = (it_im * g.TH + 2 * it_m) * g.W + SW * it_j;   // first pixel of the lane's upper input row inside the tile
+  const unsigned dy_addr0 = cw_lds_addr(s_dy + wv * g.plane + it_im * g.RH * g.LWp + 7 * it_j);
+
+  f32x2 dwa[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) dwa[t] = f32x2{0.f, 0.f};
+  float s0a = 0.f, s0b = 0.f, s1a = 0.f, s1b = 0.f;
+
+  piece_t pfg[2], pfy[2], pfx[XS];
+  int pmaxd = 0, pmaxx = 0;   // valid dY pieces / input pixels of the prefetched tile (contiguous: everything below is valid)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { X::zero(pfg[i]); X::zero(pfy[i]); }
+#pragma unroll
+  for (int i = 0; i < XS; ++i) X::zero(pfx[i]);
+
+  const int t_beg = (int)((long)worker * g.ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * g.ntiles / g.nworkers);
+  const long slab_g = (long)slab * gss, slab_y = (long)slab * yrss, slab_x = (long)slab * xss, slab_h = (long)slab * hss;
+
+  // n0: first image, hd0: first dY row of the tile (input rows 2 hd0 ...).  Full-width tiles are contiguous in HBM: piece p of the
+  // tile is at base + 16 p, and "valid" is p < a per-tile bound.
+  auto issue = [&](int n0, int hd0) {
+    const int ho_s = g.ring ? hd0 - RT + HL : 0;     // first dY row of the steady slots (window row HL, or RT for whole images)
+    const long pg = ((long)n0 * g.Ho + ho_s) * g.Wo * 16, px = ((long)n0 * g.H + 2 * hd0) * g.W * 16;
+    int vr = g.ring ? g.Ho - ho_s : g.Ho * (g.N - n0 < g.NI ? g.N - n0 : g.NI);   // valid dY rows from ho_s on
+    if (g.ring && vr > g.THd) vr = g.THd;
+    if (vr < 0) vr = 0;
+    pmaxd = cg_ok ? vr * g.Wo : 0;
+    int vx = g.ring ? g.H - 2 * hd0 : g.H * (g.N - n0 < g.NI ? g.N - n0 : g.NI);
+    if (g.ring && vx > g.TH) vx = g.TH;
+    pmaxx = cg_ok ? vx * g.W : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = d_pp[i] >= 0 && d_pp[i] < pmaxd;
+      const long og = ok ? pg + (long)d_pp[i] * 16 + cgoff : 0;
+      X::load(pfg[i], gup + slab_g + og);
+      if (yraw) X::load(pfy[i], yraw + slab_y + og);
+    }
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int pp = (tq + i * NT) / CGS;
+      X::load(pfx[i], x + slab_x + (pp < pmaxx ? px + (long)pp * 16 + cgoff : 0));
+    }
+  };
+  auto put_dy = [&](const piece_t& pg_, const piece_t& py_, bool ok, f32x2* d) {
+    float q1[8], q2[8], q3[8];
+    VecIO<float, 8>::load(s_cf + cg * 8, q1);
+    VecIO<float, 8>::load(s_cf + 16 + cg * 8, q2);
+    VecIO<float, 8>::load(s_cf + 32 + cg * 8, q3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const pair_t gq = X::pair(pg_, q), yq = X::pair(py_, q);
+      const float a0 = q1[2 * q] * X::lo(gq) + (q2[2 * q] * X::lo(yq) + q3[2 * q]);
+      const float a1 = q1[2 * q + 1] * X::hi(gq) + (q2[2 * q + 1] * X::hi(yq) + q3[2 * q + 1]);
+      d[q * g.plane] = ok ? f32x2{a0, a1} : f32x2{0.f, 0.f};
+    }
+  };
+  auto commit = [&](int base) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (d_pp[i] >= 0) {
+        int slot = (g.ring ? HL : RT) + d_rr[i] + base;
+        if (slot >= g.LH) slot -= g.LH;
+        put_dy(pfg[i], pfy[i], d_pp[i] < pmaxd, s_dy + (cgl * 4) * g.plane + d_dyo[i] + slot * g.LWp);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int pp = (tq + i * NT) / CGS;
+      if (pp < g.TPIX) {
+        pair_t* dx_ = s_x + (cgl * 4) * g.TPIXp + pp;
+        const bool okx = pp < pmaxx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dx_[q * g.TPIXp] = okx ? X::pair(pfx[i], q) : X::zero_pair();
+      }
+    }
+  };
+  auto halo_sync = [&](int n0, int hd0) {   // first tile of an image / of this worker: the HL window rows above the tile's own rows
+    const int npc = HL * g.Wo * CGS;
+    for (int p = tid; p < npc; p += NT) {
+      const int col = (p / CGS) % g.Wo, wr = (p / CGS) / g.Wo;
+      const int ho = hd0 - RT + wr;
+      piece_t a, b;
+      X::zero(a); X::zero(b);
+      const bool ok = cg_ok && ho >= 0 && ho < g.Ho && n0 < g.N;
+      if (ok) {
+        const long off = (((long)n0 * g.Ho + ho) * g.Wo + col) * 16 + cg * 8;
+        X::load(a, gup + slab_g + off);
+        if (yraw) X::load(b, yraw + slab_y + off);
+      }
+      put_dy(a, b, ok, s_dy + (cgl * 4) * g.plane + wr * g.LWp + col + CL);
+    }
+  };
+  auto store_h = [&](int n0, int hd0, int pmax) {
+    const long px = ((long)n0 * g.H + 2 * hd0) * g.W * 16;
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int pp = (tq + i * NT) / CGS;
+      if (pp < pmax) {
+        piece_t v;
+        const pair_t* sx_ = s_x + (cgl * 4) * g.TPIXp + pp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X::set_pair(v, q, sx_[q * g.TPIXp]);
+        X::store(v, h + slab_h + px + (long)pp * 16 + cgoff);
+      }
+    }
+  };
+
+  int tile = t_beg;
+  int nb = tile / g.tiles_y, ty = tile % g.tiles_y;
+  if (tile < t_end) issue(nb * g.NI, ty * g.THd);
+  int base = 0;
+  int pn0 = -1, phd0 = 0, ppmax = 0;   // tile whose result waits in s_x, and its valid pixel count
+  for (; tile < t_end; ++tile) {
+    const int n0 = nb * g.NI, hd0 = ty * g.THd;
+    const bool fresh = g.ring && (tile == t_beg || ty == 0);
+    if (fresh) base = 0;
+    asm volatile("" : "+v"(cgoff), "+v"(tq));
+    __syncthreads();   // (A) previous tile consumed, its h complete in s_x
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { X::touch(pfg[i]); X::touch(pfy[i]); }
+#pragma unroll
+    for (int i = 0; i < XS; ++i) X::touch(pfx[i]);
+    if (pn0 >= 0) store_h(pn0, phd0, ppmax);
+    commit(base);
+    const int cur_pmaxx = pmaxx;
+    if (fresh) halo_sync(n0, hd0);
+    __syncthreads();   // (B) window and pixel planes complete
+    int nnb = nb, nty = ty + 1;
+    if (nty == g.tiles_y) { nty = 0; ++nnb; }
+    asm volatile("" : "+v"(tq));
+    if (tile + 1 < t_end) issue(nnb * g.NI, nty * g.THd);
+
+    asm volatile("" : "+s"(ld4));
+    if (it_ok && n0 + it_im < g.N && hd0 + it_m < g.Ho && ch < cpad) {
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp) {     // the lane's two input rows ...
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {   // ... each in two halves of 7 pixels: half the live operands (k = 7 spilled on whole strips)
+          constexpr int HW7 = 7;
+          // dY columns the half strip reaches: jj = (t + P - kx) / 2 - RELMIN over its pixels t and the taps of matching parity
+          const int t0 = HW7 * sh;
+          const int emin = t0 + P - (K - 1), emax = t0 + HW7 - 1 + P;
+          const int jlo = cw_fdiv(emin + 1, 2) - RELMIN;                  // smallest even number >= emin, halved
+          const int jhi = cw_fdiv(emax, 2) - RELMIN;                      // largest even number <= emax, halved
+          constexpr int JN = (HW7 - 1 + K - 1) / 2 + 2;                   // enough for either half
+          pair_t* xp = s_x + wv * g.TPIXp + pix00 + rp * g.W + t0;
+          pair_t xq[HW7];
+          f32x2 xa[HW7], dx[HW7];
+#pragma unroll
+          for (int t = 0; t < HW7; ++t) xq[t] = xp[t];
+#pragma unroll
+          for (int t = 0; t < HW7; ++t) {
+            xa[t] = f32x2{cw_act(X::lo(xq[t]) * sc0 + sh0, in_relu, AM), cw_act(X::hi(xq[t]) * sc1 + sh1, in_relu, AM)};
+            dx[t] = f32x2{0.f, 0.f};
+            asm volatile("" : "+v"(xa[t]));
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            if ((rp + P - ky) & 1) continue;                  // this tap row meets rows of the other parity
+            const int d = (rp + P - ky) / 2;                  // dY row relative to the lane's own: hd = m + d
+            int slot = it_m + d + RT + base;
+            if (slot >= g.LH) slot -= g.LH;
+            f32x2 dy[JN], wr_[K];
+            cw_row_issue<K, JN>(wr_, dy, wp, (unsigned)(ky * K) * ld4, ld4, dy_addr0 + (unsigned)(slot * g.LWp + jlo) * 8u);
+            cw_row_wait();
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+              for (int t = 0; t < HW7; ++t) {
+                if ((t0 + t + P - kx) & 1) continue;            // column parity
+                const int jj = (t0 + t + P - kx) / 2 - RELMIN - jlo;
+                dx[t] += dy[jj] * wr_[kx];
+                dwa[ky * K + kx] += xa[t] * dy[jj];
+              }
+              asm volatile("" : "+v"(dwa[ky * K + kx]));
+            }
+#pragma unroll
+            for (int t = 0; t < HW7; ++t) asm volatile("" : "+v"(dx[t]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          (void)jhi;
+#pragma unroll
+          for (int t = 0; t < HW7; ++t) xq[t] = xp[t];
+#pragma unroll
+          for (int t = 0; t < HW7; ++t) {
+            const float x0 = X::lo(xq[t]), x1 = X::hi(xq[t]);
+            float v0 = cw_act_bwd(dx[t][0], x0 * sc0 + sh0, in_relu, AM);
+            float v1 = cw_act_bwd(dx[t][1], x1 * sc1 + sh1, in_relu, AM);
+            v0 = ch0_ok ? v0 : 0.f;
+            v1 = ch1_ok ? v1 : 0.f;
+            const pair_t o = X::pack(v0, v1);
+            v0 = X::lo(o); v1 = X::hi(o);
+            s0a += v0; s0b += v1;
+            s1a += v0 * x0; s1b += v1 * x1;
+            xp[t] = o;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    pn0 = n0; phd0 = hd0; ppmax = cur_pmaxx;
+    nb = nnb; ty = nty;
+    if (g.ring) { base += g.THd; if (base >= g.LH) base -= g.LH; }
+  }
+  __syncthreads();
+  if (pn0 >= 0) store_h(pn0, phd0, ppmax);
+
+  {   // weight-gradient flush through this wave's own plane, see k_dwb_cw
+    constexpr int G = 14, NV = 2 * KK;
+    float* red = reinterpret_cast<float*>(s_dy + wv * g.plane);
+    float* red2 = red + 64 * (G + 1);
+    float* drow = dwp ? dwp + ((long)worker * g.C + ch) * KK : nullptr;
+    const int nvalid = ch1_ok ? NV : (ch0_ok ? KK : 0);
+    const int rq = lane / G, rv = lane - rq * G;
+#pragma unroll
+    for (int r0 = 0; r0 < NV; r0 += G) {
+#pragma unroll
+      for (int v = 0; v < G; ++v)
+        if (r0 + v < NV) red[lane * (G + 1) + v] = (r0 + v < KK) ? dwa[(r0 + v) % KK][0] : dwa[(r0 + v) % KK][1];
+      __builtin_amdgcn_wave_barrier();
+      float part = 0.f;
+      if (lane < 4 * G) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) part += red[(rq * 16 + i) * (G + 1) + rv];
+        red2[lane] = part;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < G && drow && r0 + lane < nvalid) drow[r0 + lane] = ((red2[lane] + red2[G + lane]) + red2[2 * G + lane]) + red2[3 * G + lane];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  s0a = cw_wave_sum63(s0a); s0b = cw_wave_sum63(s0b); s1a = cw_wave_sum63(s1a); s1b = cw_wave_sum63(s1b);
+  if (lane == 63 && stats) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = ch + e;
+      if (c < g.C) {
+        const float v0 = e ? s0b : s0a, v1 = e ? s1b : s1a;
+        float* r = stats + (long)worker * 2 * stat_ld;
+        r[c] = v0;
+        r[stat_ld + c] = v1;
+        stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, c);
+        stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, (long)stat_ld + c);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- forward
 //   y = dwconv(act(x*in_scale+in_shift)),  stats: sum y, sum y^2 (of the stored values)
 template <typename T, int K, int AM, int NW, int WPS>
@@ -740,6 +1064,48 @@ static bool cw_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
   return true;
 }
 
+// stride 2: the lane grid is the output grid; K decides the halo rows / columns of the window
+static bool cw2_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
+  if (H % 2 || W % 14 != 0 || W < 14) return false;
+  const int P = (K - 1) / 2;
+  const int RELMIN = cw_fdiv(-P, 2), RELMAX = cw_fdiv(13 + P, 2), CL = -RELMIN, CR = RELMAX - 6;
+  const int HL = P / 2 + cw_fdiv(P - 1, 2) + 1;
+  g.N = N; g.H = H; g.W = W; g.C = C;
+  g.Ho = H / 2; g.Wo = W / 2;
+  g.ns = g.Wo / 7;
+  if (g.ns > 16) return false;
+  if (g.Ho * g.ns <= 64) {   // whole images
+    g.THd = g.Ho; g.tiles_y = 1; g.NI = 64 / (g.Ho * g.ns); g.ring = 0;
+    if (g.NI > N) g.NI = N;
+  } else {
+    const int cap = 64 / g.ns;
+    const int nty = (g.Ho + cap - 1) / cap;
+    g.THd = (g.Ho + nty - 1) / nty;
+    g.tiles_y = (g.Ho + g.THd - 1) / g.THd;
+    g.NI = 1; g.ring = 1;
+  }
+  g.TH = 2 * g.THd;
+  g.LH = g.THd + HL;
+  const int lw = g.Wo + CL + CR;
+  const bool pow2 = (g.ns & (g.ns - 1)) == 0;
+  int lwp = lw;
+  if (pow2) { while (lwp % (2 * g.ns) != g.ns) ++lwp; } else if (lwp % 2 == 0) ++lwp;
+  g.LWp = lwp;
+  g.RH = g.LH;
+  int plane = g.NI * g.RH * g.LWp + 4;   // + slack: a half strip reads a fixed number of operand pairs, up to 2 past its last one
+  if (plane < 512) plane = 512;
+  while (plane % 4 != 2) ++plane;
+  g.plane = plane;
+  g.TPIX = g.NI * g.TH * W;
+  g.TPIXD = g.NI * g.THd * g.Wo;
+  int tp = g.TPIX;
+  while (tp % 8 != 4) ++tp;
+  g.TPIXp = tp;
+  g.ntiles = ((N + g.NI - 1) / g.NI) * g.tiles_y;
+  g.nslabs = (C + 15) / 16;
+  return true;
+}
+
 static void cw_workers(CwGeom& g, int per_cu, int max_rows, int nw) {
   if (per_cu < 1) per_cu = 1;
   const int units = g.nslabs * (nw == 4 ? 2 : 1);   // workgroups per worker
@@ -757,7 +1123,8 @@ static unsigned cw_grid(const CwGeom& g, int nw) {
 }
 
 static int cw_mode() {
-  static const int m = getenv("ATOMNAS_DW_CW") ? atoi(getenv("ATOMNAS_DW_CW")) : 3;   // bit 0: backward, bit 1: forward
+  // bit 0: backward, bit 1: forward (stride 1); bit 2: backward stride 2, bit 3: forward stride 2
+  static const int m = getenv("ATOMNAS_DW_CW") ? atoi(getenv("ATOMNAS_DW_CW")) : 7;
   return m;
 }
 static int cw_nw() {
@@ -822,12 +1189,46 @@ static int cw_launch_fwd(const void* x, long xss, const float* sc, const float* 
   return check_launch("dwconv_fwd(cw)");
 }
 
+template <typename T, int K>
+static int cw2_launch_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
+                          const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h, long hss,
+                          float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, hipStream_t st) {
+  CwGeom g;
+  if (!cw2_geometry(g, N, H, W, C, K)) return -1;
+  const size_t lds = cw_lds<T>(g, 4);
+  if (lds > 160 * 1024) return -1;
+#define CW2_BWD(AMV)                                                                                                        \
+  {                                                                                                                         \
+    auto kern = k_dwb_cw2<T, K, AMV, 4, 2>;                                                                                 \
+    cw_workers(g, resident_per_cu(kern, 256, lds), (stats || dw) ? part_rows : 0, 4);                                       \
+    hipLaunchKernelGGL(kern, dim3(cw_grid(g, 4)), dim3(256), lds, st, (const T*)gup, gss, (const T*)yraw, yrss, c1, c2,     \
+                       c3, (const T*)x, xss, sc, sh, relu, w, ldw, (T*)h, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g); \
+  }
+  if (relu == ACT_RELU6) CW2_BWD(ACT_RELU6) else if (relu == ACT_SWISH) CW2_BWD(ACT_SWISH) else CW2_BWD(0)
+#undef CW2_BWD
+  if (int rc = check_launch("dwconv_bwd(cw2)")) return rc;
+  if (dw) return reduce_parts(dw_ws, (long)C * K * K, g.nworkers, (long)C * K * K, dw, C * K * K, 0, 1, st);
+  return 0;
+}
+
 // -1: not one of this file's cases (the caller continues with the tile kernels of dwconv.hip); otherwise the launch status
 int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
                   const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h, long hss,
-                  float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int dtype,
-                  hipStream_t st) {
+                  float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride,
+                  int dtype, hipStream_t st) {
   if (!(cw_mode() & 1) || gss == 0 || xss == 0 || hss == 0 || (yraw && yrss == 0) || ldw < ((C + 7) & ~7)) return -1;
+  if (stride == 2) {
+    if (!(cw_mode() & 4)) return -1;
+#define CW_B2(TT, KV) return cw2_launch_bwd<TT, KV>(gup, gss, yraw, yrss, c1, c2, c3, x, xss, sc, sh, relu, w, ldw, h, hss, dw, stats, stat_ld, part_rows, dw_ws, N, H, W, C, st)
+    if (dtype == DT_F32) {
+      if (k == 3) CW_B2(float, 3); if (k == 5) CW_B2(float, 5); if (k == 7) CW_B2(float, 7);
+    } else {
+      if (k == 3) CW_B2(bf16_t, 3); if (k == 5) CW_B2(bf16_t, 5); if (k == 7) CW_B2(bf16_t, 7);
+    }
+#undef CW_B2
+    return -1;
+  }
+  if (stride != 1) return -1;
 #define CW_B(TT, KV) return cw_launch_bwd<TT, KV>(gup, gss, yraw, yrss, c1, c2, c3, x, xss, sc, sh, relu, w, ldw, h, hss, dw, stats, stat_ld, part_rows, dw_ws, N, H, W, C, st)
   if (dtype == DT_F32) {
     if (k == 3) CW_B(float, 3); if (k == 5) CW_B(float, 5); if (k == 7) CW_B(float, 7);
@@ -867,8 +1268,15 @@ extern "C" int atomnas_debug_cw_timing(unsigned long long* out8, int reset) {
 // shape (slab-major tensors, stride 1), 0 when they take the tile kernels of dwconv.hip.  Tests and launch-geometry tools only.
 extern "C" int atomnas_dwconv_cw_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir) {
   using namespace atomnas;
-  if (stride != 1 || !(k == 3 || k == 5 || k == 7) || !(cw_mode() & (dir ? 1 : 2))) return 0;
+  if (!(k == 3 || k == 5 || k == 7)) return 0;
   CwGeom g;
+  if (stride == 2) {
+    if (!(cw_mode() & (dir ? 4 : 8)) || dir == 0) return 0;   // stride 2: backward only so far
+    if (!cw2_geometry(g, N, H, W, C, k)) return 0;
+    const size_t lds = dtype == DT_F32 ? cw_lds<float>(g, 4) : cw_lds<bf16_t>(g, 4);
+    return lds <= 160 * 1024 ? 1 : 0;
+  }
+  if (stride != 1 || !(cw_mode() & (dir ? 1 : 2))) return 0;
   if (!cw_geometry(g, N, H, W, C, k)) return 0;
   const size_t lds = dtype == DT_F32 ? cw_lds<float>(g, cw_nw()) : cw_lds<bf16_t>(g, cw_nw());
   return lds <= 160 * 1024 ? 1 : 0;

@@ -239,9 +239,15 @@ CW_SHAPES = [(10, 16, 7, 7), (3, 48, 14, 14), (2, 24, 56, 56), (5, 40, 28, 28), 
              (2, 16, 44, 28), (3, 5, 14, 14)]
 
 
-def _cw_supported(N, H, W, C, k, dtype, direction):
+def _cw_supported(N, H, W, C, k, dtype, direction, stride=1):
     from atomnas_amd import _lib
-    return bool(_lib.load().atomnas_dwconv_cw_supported(N, H, W, C, k, 1, 0 if dtype == torch.float32 else 1, direction))
+    return bool(_lib.load().atomnas_dwconv_cw_supported(N, H, W, C, k, stride, 0 if dtype == torch.float32 else 1, direction))
+
+
+# stride 2 (csrc/dwconv_cw.hip k_dwb_cw2): lanes on the output grid -- whole output images per tile (14x14 -> 7x7, 28x28 -> 14x14),
+# row-ring tiles (112, 56, a ragged last tile at 88x56), 3 strips per row, ragged channel counts
+CW2_SHAPES = [(10, 16, 14, 14), (3, 48, 28, 28), (2, 24, 112, 112), (5, 40, 56, 56), (2, 13, 42, 42), (1, 70, 56, 56), (2, 16, 88, 56),
+              (3, 5, 28, 28)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -276,19 +282,20 @@ def test_dwconv_fwd_cw(gpu_lib, dtype, k, N, C, H, W):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", [3, 5, 7])
-@pytest.mark.parametrize("N,C,H,W", CW_SHAPES)
-def test_dwconv_bwd_cw(gpu_lib, dtype, k, N, C, H, W):
+@pytest.mark.parametrize("stride,N,C,H,W", [(1,) + s for s in CW_SHAPES] + [(2,) + s for s in CW2_SHAPES])
+def test_dwconv_bwd_cw(gpu_lib, dtype, k, stride, N, C, H, W):
     ops = _ops()
     from atomnas_amd.ops import Slab
-    assert _cw_supported(N, H, W, C, k, dtype, 1) or os.environ.get("ATOMNAS_DW_CW") is not None
+    assert _cw_supported(N, H, W, C, k, dtype, 1, stride) or os.environ.get("ATOMNAS_DW_CW") is not None
     g = torch.Generator().manual_seed(4000 * k + C + H)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(C, 1, k, k, generator=g) * 0.3
     sc = torch.rand(C, generator=g) + 0.5
     sh = torch.randn(C, generator=g) * 0.3
     P = (k - 1) // 2
-    gup = torch.randn(N, C, H, W, generator=g)
-    yraw = torch.randn(N, C, H, W, generator=g)
+    Ho, Wo = (H + 2 * P - k) // stride + 1, (W + 2 * P - k) // stride + 1
+    gup = torch.randn(N, C, Ho, Wo, generator=g)
+    yraw = torch.randn(N, C, Ho, Wo, generator=g)
     c1 = torch.rand(C, generator=g) + 0.5
     c2 = torch.randn(C, generator=g) * 0.1
     c3 = torch.randn(C, generator=g) * 0.1
@@ -298,7 +305,7 @@ def test_dwconv_bwd_cw(gpu_lib, dtype, k, N, C, H, W):
         pre = xr * v(sc) + v(sh) if fuse else xr
         xa = torch.relu(pre) if fuse else pre
         wd = w.double().requires_grad_(True)
-        y = F.conv2d(xa, wd, None, 1, P, 1, C)
+        y = F.conv2d(xa, wd, None, stride, P, 1, C)
         dy = v(c1) * rounded(gup, dtype) + v(c2) * rounded(yraw, dtype) + v(c3) if fuse else rounded(gup, dtype)
         xa.retain_grad()
         (y * dy).sum().backward()
@@ -308,7 +315,7 @@ def test_dwconv_bwd_cw(gpu_lib, dtype, k, N, C, H, W):
         stats = poisoned_stats(48 if k == 5 else 64, C)
         ops.dwconv_bwd(_slab(to_act(gup, dtype), C), _slab(to_act(yraw, dtype), C) if fuse else None, cvec(c1) if fuse else None,
                        cvec(c2) if fuse else None, cvec(c3) if fuse else None, _slab(to_act(x, dtype), C), cvec(sc) if fuse else None,
-                       cvec(sh) if fuse else None, fuse, taps(w), hs, dw, stats, C, N, H, W, C, k, 1)
+                       cvec(sh) if fuse else None, fuse, taps(w), hs, dw, stats, C, N, H, W, C, k, stride)
         torch.cuda.synchronize()
         hp = hs.to_plain()
         h = from_act(hp, N, H, W, C)
