@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
     CWMARK(6)
     // opaque per tile: the 64-bit global addresses of the slots are formed where they are used.  (Hoisted out of the tile loop they
     // are spilled, and every reload waits for vmcnt(0), i.e. for all loads and stores issued before it: the prefetch serialises.)
-    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]));
+    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]), "+v"(sl.pp[0]), "+v"(sl.pp[1]), "+v"(sl.dyo[0]), "+v"(sl.dyo[1]));
     __syncthreads();   // (A) previous tile consumed, its h complete in s_x (first pass: also orders the LDS initialisation)
     CWMARK(0)
     // every prefetched register is consumed here on every path: nothing is pending when the next tile's loads overwrite them
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwf_cw(const T* __restrict__ x
     const int n0 = nb * g.NI, ho0 = ty * g.TH;
     const bool fresh = g.ring && (tile == t_beg || ty == 0);
     if (fresh) base = 0;
-    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]));   // see k_dwb_cw
+    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]), "+v"(sl.pp[0]), "+v"(sl.pp[1]), "+v"(sl.dyo[0]), "+v"(sl.dyo[1]));   // see k_dwb_cw
     __syncthreads();   // (A) previous tile consumed, its output complete in s_y
     X::touch(pfx[0]); X::touch(pfx[1]);   // see k_dwb_cw
     if (pn0 >= 0) store_y(pn0, pho0);
