@@ -1876,7 +1876,7 @@ extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void*
 
 // 1 when atomnas_project_bwd has an instance for this shape (bf16 storage, oup <= 48, hid >= 96 and >= 2 * oup)
 extern "C" int atomnas_project_bwd_supported(int oup, int hid, int dtype) {
-  return dtype == DT_BF16 && oup >= 1 && oup <= 48 && hid >= 96 && hid >= 2 * oup && hid <= NT_MAX_STAT;
+  return dtype == DT_BF16 && oup >= 1 && oup <= 96 && hid >= 96 && hid >= 2 * oup && hid <= NT_MAX_STAT;
 }
 
 // Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) in ONE pass over the raw depthwise output:
@@ -1905,6 +1905,10 @@ extern "C" int atomnas_project_bwd(const void* g, int ldg, const void* p, int ld
     if (ut == 1) return launch_project_bwd_cfg<1, 1>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
     return launch_project_bwd_cfg<1, 2>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
   }
-  return launch_project_bwd_cfg<2, 3>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  if (oup <= 48) return launch_project_bwd_cfg<2, 3>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  // round 3: the 14x14 stages (oup 80 / 96): three k-steps of the input gradient, 5 / 6 accumulator tiles of the weight gradient
+  if (oup <= 64) return launch_project_bwd_cfg<2, 4>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  if (oup <= 80) return launch_project_bwd_cfg<3, 5>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  return launch_project_bwd_cfg<3, 6>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
 }
 

@@ -140,6 +140,9 @@ def bn_backward_coeffs(bn, st, stats2, count, dev):
 
 # ---------------------------------------------------------------------------------------------- atomic block
 _FUSED_PROJECT_BWD = bool(int(os.environ.get("ATOMNAS_FUSED_PROJECT_BWD", "1")))   # experiment switch (A/B against the two-GEMM form)
+# widest block output that takes the fused kernel.  The library covers oup <= 96, but the 80/96-wide instances hold 223 VGPR + 96 AGPR
+# (one wave per SIMD) and measured slower than the two-GEMM form on the 14x14 stages: 36.53 vs 36.30 ms/step (r03, bs256 bf16).
+_FUSED_PROJECT_BWD_MAXOUP = int(os.environ.get("ATOMNAS_FUSED_PROJECT_BWD_MAXOUP", "48"))
 # experiment switch: the separate weight-gradient GEMMs of a block run on a side stream next to the input-gradient chain (they only
 # write the gradient arena); joined before the block's backward returns.
 _SIDE_WGRAD = bool(int(os.environ.get("ATOMNAS_SIDE_WGRAD", "0")))
@@ -260,7 +263,8 @@ def block_backward(pl, sv, G):
     wp_jobs = ([(sg, h, pl.Wp_grad[stt:], pl.total) for sg, stt, h in zip(pl.seg, pl.start, pl.hid)] if pl.fused
                else [(0, HT, pl.Wp_grad, HT)])
     # early stages (oup <= 48, no SE): the weight gradient rides in the input-gradient kernel below (one pass over D)
-    fused_pb = (_FUSED_PROJECT_BWD and se is None and not pl.fused and pl.expand and ops.project_bwd_supported(pl.oup, HT, T))
+    fused_pb = (_FUSED_PROJECT_BWD and se is None and not pl.fused and pl.expand and pl.oup <= _FUSED_PROJECT_BWD_MAXOUP
+                and ops.project_bwd_supported(pl.oup, HT, T))
     with _Side():
         for sg, nv, out, si in ([] if fused_pb else wp_jobs):
             if se is not None:

@@ -462,7 +462,8 @@ def test_expand_bwd_fused_matches_the_two_gemm_form(gpu_lib, M, inp, hid, res, s
 # ---------------------------------------------------------------------------------------------- fused project backward
 @pytest.mark.parametrize("slab", [True, False])
 @pytest.mark.parametrize("act", [1, 2, 3])
-@pytest.mark.parametrize("M,oup,hid", [(5000, 24, 432), (1500, 16, 288), (4100, 40, 720), (1031, 8, 96), (3000, 48, 203 + 5), (20000, 32, 336)])
+@pytest.mark.parametrize("M,oup,hid", [(5000, 24, 432), (1500, 16, 288), (4100, 40, 720), (1031, 8, 96), (3000, 48, 203 + 5), (20000, 32, 336),
+                                       (4000, 80, 1440), (3100, 96, 1728), (2500, 56, 300), (2048, 72, 720)])
 def test_project_bwd_fused_matches_the_two_gemm_form(gpu_lib, M, oup, hid, act, slab):
     """atomnas_project_bwd = atomnas_pw_gemm_nt(BNBWD prologue, activation mask, STAT_Z) + atomnas_pw_gemm_tn of the projection's backward
     (models/mobilenet_base.py:338) with the raw depthwise output read once.  Same MFMA sequence for the input gradient; the weight
