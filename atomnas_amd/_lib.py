@@ -27,6 +27,7 @@ SIGNATURES = {
     "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     "atomnas_bn_finalize_bwd": [vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "atomnas_bn_apply": [vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
+    "atomnas_bnbwd_apply": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i64, i32, i32, vp],
     "atomnas_bn_act_pool": [vp, i32, vp, vp, i32, vp, i32, vp, f32, u64, vp, i32, i32, i32, i32, vp],
     "atomnas_pool_act_bwd": [vp, i32, vp, f32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "atomnas_act_bwd_stats": [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
@@ -57,7 +58,7 @@ NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version":
              "atomnas_project_bwd_supported": (i32, [i32, i32, i32]),
              "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32])}
 
-ABI_VERSION = 2   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
+ABI_VERSION = 3   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None
 
 

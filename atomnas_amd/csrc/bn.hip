@@ -155,6 +155,31 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, int l
   }
 }
 
+// dP = c1*g + c2*x + c3 per channel, rounded to the storage type: the differentiated BatchNorm output as a tensor.  The GEMM
+// prologue PRO_BNBWD computes exactly this (same expression, same rounding) per consumer tile; for the 14x14 / 7x7 stages the
+// projection's input-gradient GEMM has 23..54 consumers (64-channel chunks) of every row, so it is cheaper to materialise the
+// narrow tensor once (10 MB) and run the streaming GEMM (k_gemm_nt_st) without a prologue.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bnbwd_apply(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx,
+                                                     const float* __restrict__ c1, const float* __restrict__ c2,
+                                                     const float* __restrict__ c3, T* __restrict__ y, int ldy, long M, int C) {
+  const int cg = (C + 7) / 8;
+  const long total = M * cg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / cg;
+    const int c0 = (int)(i % cg) * 8;
+    float v[8], xx[8], a1[8], a2[8], a3[8];
+    VecIO<T, 8>::load(g + m * ldg + c0, v);
+    VecIO<T, 8>::load(x + m * ldx + c0, xx);
+    VecIO<float, 8>::load(c1 + c0, a1);
+    VecIO<float, 8>::load(c2 + c0, a2);
+    VecIO<float, 8>::load(c3 + c0, a3);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? a1[e] * v[e] + a2[e] * xx[e] + a3[e] : 0.f;
+    VecIO<T, 8>::store(y + m * ldy + c0, v);
+  }
+}
+
 __device__ __forceinline__ unsigned hash32(unsigned long long key) {
   // splitmix64 finaliser; counter-based so that backward can regenerate nothing: the keep mask is stored
   key += 0x9E3779B97F4A7C15ull;
@@ -381,6 +406,23 @@ extern "C" int atomnas_bn_apply(const void* x, int ldx, const float* scale, cons
     hipLaunchKernelGGL(k_bn_apply<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, scale, shift, relu,
                        (const bf16_t*)res, ldres, (bf16_t*)y, ldy, M, C);
   return check_launch("bn_apply");
+}
+
+extern "C" int atomnas_bnbwd_apply(const void* g, int ldg, const void* x, int ldx, const float* c1, const float* c2, const float* c3,
+                                   void* y, int ldy, long M, int C, int dtype, void* stream) {
+  ATOMNAS_REQUIRE(g && x && y && c1 && c2 && c3 && M > 0 && C > 0, "bnbwd_apply: bad arguments");
+  ATOMNAS_REQUIRE(ldg % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldg >= C && ldx >= C && ldy >= C, "bnbwd_apply: bad pitch");
+  const long total = M * ((C + 7) / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(k_bnbwd_apply<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)g, ldg, (const float*)x, ldx, c1, c2,
+                       c3, (float*)y, ldy, M, C);
+  else
+    hipLaunchKernelGGL(k_bnbwd_apply<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)g, ldg, (const bf16_t*)x, ldx, c1,
+                       c2, c3, (bf16_t*)y, ldy, M, C);
+  return check_launch("bnbwd_apply");
 }
 
 extern "C" int atomnas_bn_act_pool(const void* x, int ldx, const float* scale, const float* shift, int relu, void* pooled, int ldp,

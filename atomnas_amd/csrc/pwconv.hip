@@ -666,6 +666,329 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_nt, column-stationary, streaming
+// Round 3.  k_gemm_nt_cs above spends its time waiting, not moving bytes (3.3 TB/s on the 56x56 expand forward, where a bare write
+// stream of the same shape and order reaches 5.3 TB/s, tools/probe/stpat.hip): s_waitcnt vmcnt counts loads AND stores in issue
+// order, and every load or store that sits behind a branch (row / channel validity, the optional epilogue streams) makes the number
+// of operations issued after a load unknown to the compiler, which then waits with vmcnt(0) -- i.e. for the PREVIOUS tile's stores
+// to be acknowledged -- before it touches the operand of the current one.  Here every memory operation of the loop is unconditional:
+//   * buffer loads / stores with a per-wave resource; an invalid lane (row >= M, k >= K, channel half outside the tensor) gets an
+//     offset past num_records, so the hardware returns zeros / drops the store: no branch, and the zeros are exactly the padding the
+//     MFMA and the statistics need;
+//   * the operands of tile t+1 are issued before the arithmetic of tile t, the two stores of tile t after it: the wait for tile
+//     t+1's operands is vmcnt(2), with the stores of tile t still in flight.
+// The epilogue is fixed at compile time (EPK) instead of six run-time branches with their registers:
+//   ST_FWD  : C = A * W^T, optional sum c / sum c^2 statistics               (the expand forward, mobilenet_base.py:316-320)
+//   ST_MASK : C = mask_z(A * W^T), optional sum c / sum c*z statistics        (the input gradient of the projection through the
+//             activation of the depthwise BatchNorm; A is the already differentiated BatchNorm output, see atomnas_bnbwd_apply)
+// A is plain bf16 without a prologue, K a multiple of 8; weights as for k_gemm_nt_cs (rows >= N and columns >= K of Wp are zero).
+enum { ST_FWD = 1, ST_MASK = 2 };
+// per k-steps: burst tiles of the narrow operand (0: per-tile ring), ring depth (of z, and of the operand when there is no
+// burst), waves per SIMD the registers are allocated for
+#ifndef ST_BT1
+#define ST_BT1 16
+#endif
+#ifndef ST_BT2
+#define ST_BT2 8
+#endif
+#ifndef ST_BT3
+#define ST_BT3 4
+#endif
+#ifndef ST_WPE1
+#define ST_WPE1 1
+#endif
+#ifndef ST_WPE2
+#define ST_WPE2 1
+#endif
+#ifndef ST_WPE3
+#define ST_WPE3 1
+#endif
+template <int KSTEPS, int EPK> struct StCfg {
+  static constexpr int BT = KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : 0;
+  static constexpr int PD = BT > 0 ? (BT >= 2 ? 2 : 1) : 2;
+  static constexpr int WPE = EPK != ST_FWD ? 1 : KSTEPS == 1 ? ST_WPE1 : KSTEPS == 2 ? ST_WPE2 : KSTEPS == 3 ? ST_WPE3 : 1;
+};
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr unsigned ST_OOB = 0x80000000u;   // >= num_records of every resource below
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)ST_OOB, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 st_as_bf16(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int KSTEPS, int EPK, int PD, int BT, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_gemm_nt_st(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K,
+                                                    int nchunks, int tiles_per_item) {
+  using MM = Mma<bf16_t>;
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4, j = lane & 15;
+  const int wrow = 16 * (j >> 2) + (j & 3);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long item = (long)blockIdx.x * 4 + wave;
+  const long mtiles = (M + 15) / 16;
+  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
+  if (item >= nranges * nchunks) return;
+  const int chunk = (int)(item % nchunks);
+  const long range = item / nchunks;
+  const int nc = chunk * 64;
+  const int nb = nc + 16 * q;
+  const bool do_stats = ep.stats != nullptr;
+
+  typename MM::frag wf[KSTEPS][4];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[ks][t] = MM::raw(Wp + (long)(nc + wrow + 4 * t) * ldw + ks * 32 + 8 * q);
+
+  const long mt_beg = range * tiles_per_item;
+  const long mt_end = mt_beg + tiles_per_item < mtiles ? mt_beg + tiles_per_item : mtiles;
+  const int ntiles = (int)(mt_end - mt_beg);
+  const long row0 = mt_beg * 16;
+  const int rows_item = (int)((M - row0) < (long)ntiles * 16 ? (M - row0) : (long)ntiles * 16);
+
+  // per-wave resources (base = first row of the range, first channel of the chunk) and per-lane byte offsets inside them
+  const bf16_t* ap = reinterpret_cast<const bf16_t*>(A.p1) + (A.ss1 ? row0 * 16 : row0 * A.ld1);
+  const __amdgpu_buffer_rsrc_t ra = st_rsrc(ap);
+  const unsigned a_tile = A.ss1 ? 512u : 32u * (unsigned)A.ld1;
+  unsigned a_lane[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int k = ks * 32 + 8 * q;
+    const long e = A.ss1 ? (long)(k >> 4) * A.ss1 + j * 16 + (k & 15) : (long)j * A.ld1 + k;
+    a_lane[ks] = k < K ? (unsigned)(2 * e) : ST_OOB;
+  }
+  bf16_t* cp = reinterpret_cast<bf16_t*>(ep.c) + (ep.css ? (long)(nc >> 4) * ep.css + row0 * 16 : row0 * ep.ldc + nc);
+  const __amdgpu_buffer_rsrc_t rc = st_rsrc(cp);
+  const unsigned c_tile = ep.css ? 512u : 32u * (unsigned)ep.ldc;
+  const int nalloc = ep.css ? (N + 15) / 16 * 16 : N;
+  unsigned c_lane[2], z_lane[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const long e = ep.css ? (long)q * ep.css + j * 16 + 8 * h : (long)j * ep.ldc + 16 * q + 8 * h;
+    c_lane[h] = nb + 8 * h < nalloc ? (unsigned)(2 * e) : ST_OOB;
+  }
+  __amdgpu_buffer_rsrc_t rz = rc;
+  unsigned z_tile = 0;
+  float zs[16], zh[16];
+  if constexpr (EPK == ST_MASK) {
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(ep.z) + (ep.zss ? (long)(nc >> 4) * ep.zss + row0 * 16 : row0 * ep.ldz + nc);
+    rz = st_rsrc(zp);
+    z_tile = ep.zss ? 512u : 32u * (unsigned)ep.ldz;
+    const int zalloc = ep.zss ? (N + 15) / 16 * 16 : N;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long e = ep.zss ? (long)q * ep.zss + j * 16 + 8 * h : (long)j * ep.ldz + 16 * q + 8 * h;
+      z_lane[h] = nb + 8 * h < zalloc ? (unsigned)(2 * e) : ST_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {   // per-channel vectors are readable up to N rounded up to 8; beyond that the lane never uses them
+      const bool ok = nb + i < (N + 7) / 8 * 8;
+      zs[i] = ok ? ep.zscale[nb + i] : 0.f;
+      zh[i] = ok ? ep.zshift[nb + i] : 0.f;
+    }
+  }
+  const Act am = act_of(ep.mask);
+
+  float s1[16], s2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+
+  // ---- epilogue of one tile: accumulators -> (mask) -> bf16 -> store, statistics of the stored values
+  auto finish = [&](int t, const f32x4 (&acc)[4], const u32x4 (&zc)[2]) {
+    float c[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[4 * u + r] = acc[u][r];
+    float zv[16];
+    if constexpr (EPK == ST_MASK) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bf16x8 zb = st_as_bf16(zc[h]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zv[8 * h + i] = (float)zb[i];
+      }
+      float a16[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a16[i] = zv[i] * zs[i] + zh[i];
+      if (__builtin_expect(am.swish, 0)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = nb + i < N ? c[i] * swish_grad(a16[i]) : 0.f;   // the padding of z may hold anything
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = act_pass(a16[i], am) ? c[i] : 0.f;
+      }
+    }
+    const bool rv = j < rows_item - 16 * t;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 ob;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ob[i] = (bf16_t)c[8 * h + i];
+      // The tile offset rides in soffset (one scalar for all unrolled tiles instead of a vector induction variable per access and
+      // tile).  HAZARD: with an SGPR soffset LLVM does not keep the next VALU instructions off the store's data registers (its rule
+      // exempts that form), but on gfx950 data overwritten in the two instructions after the store IS what gets written (r03: 0.17 %
+      // wrong elements in test_gemm_nt[20000-1440-80]).  The asm below uses `ob` after the statistics: its registers stay intact.
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rc, rv ? c_lane[h] : ST_OOB, (unsigned)t * c_tile, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float o = (float)ob[i];   // statistics see the stored value
+        s1[8 * h + i] += o;
+        s2[8 * h + i] += EPK == ST_FWD ? o * o : o * zv[8 * h + i];
+        // the accumulation happens HERE: left to itself, instruction selection collects the statistics updates of all unrolled tiles at
+        // the end of the loop body, with the 16 stored values of every tile live until then (about 20 registers per unrolled tile)
+        asm volatile("" : "+v"(s1[8 * h + i]), "+v"(s2[8 * h + i]));
+      }
+      asm volatile("" ::"v"(__builtin_bit_cast(u32x4, ob)));
+    }
+  };
+  auto load_a = [&](int t, int ks) {
+    const bool rv = j < rows_item - 16 * t;
+    return __builtin_amdgcn_raw_buffer_load_b128(ra, rv ? a_lane[ks] : ST_OOB, (unsigned)t * a_tile, 0);
+  };
+  auto load_z = [&](int t, int h) {
+    const bool rv = j < rows_item - 16 * t;
+    return __builtin_amdgcn_raw_buffer_load_b128(rz, rv ? z_lane[h] : ST_OOB, (unsigned)t * z_tile, 0);
+  };
+  // Two ways to feed the narrow operand.  In both, tiles past the range (the loops run to a multiple of the unroll) and their
+  // operands are all out of range: zeros in, nothing out.  A load still pending at the loop entry would put an s_waitcnt vmcnt(0)
+  // into the loop header (the entry edge and the back edge share it), i.e. a wait for the previous tiles' stores in every iteration:
+  // the first operands are waited for before the loop (the pins).  Pins also keep each tile's arithmetic behind the previous tile's
+  // sched_barrier: instruction selection orders pure operations (the MFMAs) by data dependence only and had hoisted all unrolled
+  // tiles' MFMAs to the top of the body (one set of accumulators and temporaries per tile).
+  u32x4 zn[PD][2];
+  if constexpr (BT > 0) {
+    // (a) bursts through LDS.  HBM reads trickling into a saturated write stream are what this kernel pays for (r03 knock-outs on
+    // the 56x56 expand, 694 MB out / 38 MB in: 215 us; narrow operand from an L2-resident window 157 us; one request burst per
+    // 4 / 8 tiles 198 / 171 us): the operand is fetched BT tiles (several KB, contiguous) at a time.  The burst lands in registers,
+    // is parked in a lane-private LDS slot (each lane reads back exactly what it wrote: no barrier), and the same registers take the
+    // next burst, which has the whole BT-tile period to arrive.
+    extern __shared__ u32x4 st_stage[];
+    u32x4* my = st_stage + (long)wave * (BT * KSTEPS * 64) + lane;
+    u32x4 bn[BT][KSTEPS];
+#pragma unroll
+    for (int u = 0; u < BT; ++u)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) bn[u][ks] = load_a(u, ks);
+    if constexpr (EPK == ST_MASK) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) { zn[u][0] = load_z(u, 0); zn[u][1] = load_z(u, 1); }
+#pragma unroll
+      for (int u = 0; u < PD; ++u) { asm volatile("" : "+v"(zn[u][0])); asm volatile("" : "+v"(zn[u][1])); }
+    }
+#pragma unroll
+    for (int u = 0; u < BT; ++u)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(bn[u][ks]));
+    for (int t0 = 0; t0 < ntiles; t0 += BT) {
+      int tb = t0 + BT;
+      asm volatile("" : "+s"(tb));
+#pragma unroll
+      for (int u = 0; u < BT; ++u)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          asm volatile("" : "+v"(bn[u][ks]));
+          my[(u * KSTEPS + ks) * 64] = bn[u][ks];
+        }
+#pragma unroll
+      for (int u = 0; u < BT; ++u)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) bn[u][ks] = load_a(tb + u, ks);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < BT; ++u) {
+        int t = t0 + u;
+        asm volatile("" : "+s"(t));   // opaque per tile: validity masks and offsets of all unrolled tiles are otherwise computed up front
+        u32x4 ac[KSTEPS], zc[2];
+        unsigned eo = (unsigned)(u * KSTEPS * 64);
+        asm volatile("" : "+v"(eo));   // the LDS reads of all unrolled tiles would otherwise be hoisted to the top of the body
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          ac[ks] = my[eo + ks * 64];
+          asm volatile("" : "+v"(ac[ks]));
+        }
+        if constexpr (EPK == ST_MASK) {
+          asm volatile("" : "+v"(zn[u % PD][0]));
+          zc[0] = zn[u % PD][0]; zc[1] = zn[u % PD][1];
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const bf16x8 af = st_as_bf16(ac[ks]);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] = MM::mma(wf[ks][v], af, acc[v]);
+        }
+        finish(t, acc, zc);
+        if constexpr (EPK == ST_MASK) { zn[u % PD][0] = load_z(t + PD, 0); zn[u % PD][1] = load_z(t + PD, 1); }
+        __builtin_amdgcn_sched_barrier(0);   // one tile at a time
+      }
+    }
+  } else {
+    // (b) a ring of PD register sets, one tile refilled per tile (the wide-K instances: one tile is already a 6 KB request).  The
+    // wait for tile t+1's operands leaves the stores of the PD-1 tiles before it in flight.  The pin is on the ring registers
+    // themselves, and the refill of a slot is issued after the MFMAs that read it: with a pinned COPY the refill went to other
+    // registers and the ring was rotated with moves behind a wait for every load.
+    u32x4 an[PD][KSTEPS];
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) an[u][ks] = load_a(u, ks);
+      if constexpr (EPK == ST_MASK) { zn[u][0] = load_z(u, 0); zn[u][1] = load_z(u, 1); }
+    }
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(an[u][ks]));
+      if constexpr (EPK == ST_MASK) { asm volatile("" : "+v"(zn[u][0])); asm volatile("" : "+v"(zn[u][1])); }
+    }
+    for (int t0 = 0; t0 < ntiles; t0 += PD) {
+#pragma unroll
+      for (int slot = 0; slot < PD; ++slot) {
+        int t = t0 + slot;
+        asm volatile("" : "+s"(t));
+        u32x4 zc[2];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(an[slot][ks]));
+        if constexpr (EPK == ST_MASK) { zc[0] = zn[slot][0]; zc[1] = zn[slot][1]; }
+        f32x4 acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const bf16x8 af = st_as_bf16(an[slot][ks]);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] = MM::mma(wf[ks][v], af, acc[v]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) an[slot][ks] = load_a(t + PD, ks);
+        if constexpr (EPK == ST_MASK) { zn[slot][0] = load_z(t + PD, 0); zn[slot][1] = load_z(t + PD, 1); }
+        finish(t, acc, zc);
+        __builtin_amdgcn_sched_barrier(0);   // one tile at a time
+      }
+    }
+  }
+
+  if (do_stats) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float a = s1[i], b = s2[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (j == 0 && nb + i < N) {   // this wave is the only writer of (row `range`, channel nb + i): plain stores
+        ep.stats[(long)range * 2 * N + nb + i] = a;
+        ep.stats[(long)range * 2 * N + N + nb + i] = b;
+        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, nb + i);
+        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, (long)N + nb + i);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ fused project backward
 // Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) for the early stages (oup <= 48): the
 // column-stationary input-gradient GEMM  g = mask(dP * Wp)  already holds, per 16-row tile, dP (as its MFMA operand) and the raw
@@ -1478,6 +1801,47 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// The streaming instances take the cases they are written for (see k_gemm_nt_st); everything else stays with k_gemm_nt_cs.
+static int nt_st_kind(int mode, const Operand& A, const Epilogue& ep, long M, int N, int K) {
+  static const int on = getenv("ATOMNAS_NT_ST") ? atoi(getenv("ATOMNAS_NT_ST")) : 1;
+  if (!on || mode != PRO_NONE || (K & 7) || ep.bias || ep.add || ep.out_f32) return 0;
+  const bool stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+  if (ep.stats != nullptr && ep.stat_mode == STAT_NONE) return 0;
+  // 32-bit byte offsets below 2^31 inside the per-wave resources: the whole A tensor, four slabs (one chunk) of C and z
+  const long a_bytes = A.ss1 ? ((long)((K + 15) / 16 - 1) * A.ss1 + M * 16) * 2 : M * (long)A.ld1 * 2;
+  if (a_bytes >= (1L << 31)) return 0;
+  if (ep.css ? (3 * ep.css + M * 16) * 2 >= (1L << 31) : ((N & 7) || (long)ep.ldc * 2 * 16 * 4096 >= (1L << 31))) return 0;
+  if (!ep.z) return (!stats || ep.stat_mode == STAT_SQ) ? ST_FWD : 0;
+  if (!ep.mask || (stats && ep.stat_mode != STAT_Z)) return 0;
+  if (ep.zss ? (3 * ep.zss + M * 16) * 2 >= (1L << 31) : ((N & 7) || (long)ep.ldz * 2 * 16 * 4096 >= (1L << 31))) return 0;
+  return ST_MASK;
+}
+
+template <int KSTEPS>
+static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
+  const int nchunks = (N + 63) / 64;
+  const long mtiles = (M + 15) / 16;
+  const bf16_t* W = (const bf16_t*)Wp;
+  const long min_tpi = ep.stats ? (mtiles + ep.stat_rows - 1) / ep.stat_rows : 1;   // every row range owns one partial row
+#define ST_CASE(EPKV)                                                                                                   \
+  {                                                                                                                     \
+    using Cfg = StCfg<KSTEPS, EPKV>;                                                                                    \
+    auto kern = k_gemm_nt_st<KSTEPS, EPKV, Cfg::PD, Cfg::BT, Cfg::WPE>;                                                 \
+    const size_t lds = (size_t)4 * Cfg::BT * KSTEPS * 1024;   /* the burst staging, one lane-private slot per wave */   \
+    const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;                                           \
+    long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;                                                       \
+    if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
+    if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;                                                             \
+    const long max_ranges = waves / nchunks > 0 ? waves / nchunks : 1;   /* one round of workgroups, as for k_gemm_nt_cs */ \
+    if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges; \
+    if (tiles_per_item > 4096) tiles_per_item = 4096;   /* keeps t * tile bytes in 32 bits (nt_st_kind) */              \
+    const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;                                      \
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item); \
+  }
+  if (kind == ST_FWD) ST_CASE(ST_FWD) else ST_CASE(ST_MASK)
+#undef ST_CASE
+}
+
 template <int KSTEPS>
 static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
   const int nchunks = (N + 63) / 64;
@@ -1552,6 +1916,13 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
     static const int cs_maxk_pro = getenv("ATOMNAS_NT_CS_MAXK_PRO") ? atoi(getenv("ATOMNAS_NT_CS_MAXK_PRO")) : 96;
     if (K <= (mode == PRO_BNBWD ? cs_maxk_pro : cs_maxk) && K <= 192 && N >= 2 * K && N >= 96 && M >= 1024) {
       const int ksteps = (K + 31) / 32;
+      if (const int kind = nt_st_kind(mode, A, ep, M, N, K)) {
+        if (ksteps == 1) launch_nt_st<1>(kind, A, Wp, ldw, ep, M, N, K, st);
+        else if (ksteps == 2) launch_nt_st<2>(kind, A, Wp, ldw, ep, M, N, K, st);
+        else if (ksteps == 3) launch_nt_st<3>(kind, A, Wp, ldw, ep, M, N, K, st);
+        else launch_nt_st<6>(kind, A, Wp, ldw, ep, M, N, K, st);
+        return check_launch("gemm_nt_st");
+      }
       if (ksteps == 1) launch_nt_cs<1>(mode, A, Wp, ldw, ep, M, N, K, st);
       else if (ksteps == 2) launch_nt_cs<2>(mode, A, Wp, ldw, ep, M, N, K, st);
       else if (ksteps == 3) launch_nt_cs<3>(mode, A, Wp, ldw, ep, M, N, K, st);
@@ -1650,6 +2021,7 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
   else if (umode == PRO_BNBWD && vmode == PRO_BNRELU) TN2_CASE(PRO_BNBWD, PRO_BNRELU)
   else if (umode == PRO_BNRELU && vmode == PRO_BNBWD) TN2_CASE(PRO_BNRELU, PRO_BNBWD)
   else if (umode == PRO_BNBWD && vmode == PRO_NONE) TN2_CASE(PRO_BNBWD, PRO_NONE)
+  else if (umode == PRO_NONE && vmode == PRO_BNRELU) TN2_CASE(PRO_NONE, PRO_BNRELU)   /* U = atomnas_bnbwd_apply's output */
   else { set_error("gemm_tn: unsupported prologue pair (%d,%d)", umode, vmode); return 1; }
 #undef TN2_CASE
   if (int rc = check_launch("gemm_tn2")) return rc;
@@ -1708,6 +2080,7 @@ static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Opera
   else if (umode == PRO_BNBWD && vmode == PRO_BNRELU) TN_CASE(PRO_BNBWD, PRO_BNRELU);
   else if (umode == PRO_BNRELU && vmode == PRO_BNBWD) TN_CASE(PRO_BNRELU, PRO_BNBWD);
   else if (umode == PRO_BNBWD && vmode == PRO_NONE) TN_CASE(PRO_BNBWD, PRO_NONE);
+  else if (umode == PRO_NONE && vmode == PRO_BNRELU) TN_CASE(PRO_NONE, PRO_BNRELU);
   else { set_error("gemm_tn: unsupported prologue pair (%d,%d)", umode, vmode); return 1; }
 #undef TN_CASE
   if (int rc = check_launch("gemm_tn")) return rc;

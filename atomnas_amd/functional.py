@@ -176,6 +176,7 @@ def _join_side():
 _FUSED_EXPAND_SEG = bool(int(os.environ.get("ATOMNAS_FUSED_EXPAND_SEG", "0")))
 _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
+_DP_TENSOR = bool(int(os.environ.get("ATOMNAS_DP_TENSOR", "1")))   # experiment switch: 0 = the BatchNorm-backward prologue in every GEMM tile
 TAIL_TAP = None   # set to a list by tests to receive the dropout keep mask of every tail forward
 _CHECK_LOSS_SEED = bool(int(os.environ.get("ATOMNAS_CHECK_LOSS_SEED", "0")))   # experiment switch (same-box A/B of the two layouts)
 
@@ -265,10 +266,20 @@ def block_backward(pl, sv, G):
     # early stages (oup <= 48, no SE): the weight gradient rides in the input-gradient kernel below (one pass over D)
     fused_pb = (_FUSED_PROJECT_BWD and se is None and not pl.fused and pl.expand and pl.oup <= _FUSED_PROJECT_BWD_MAXOUP
                 and ops.project_bwd_supported(pl.oup, HT, T))
-    with _Side():
+    # late stages (oup >= 80: every row of dP feeds 23..54 GEMM tiles): the differentiated pw_bn output dP = p1*G + p2*P + p3 is
+    # materialised once (a few MB) and the GEMMs below read it without a prologue -- the input-gradient GEMM then takes the streaming
+    # kernel (k_gemm_nt_st), measured 84 / 102 / 74 us against 158 / 198 / 208 us with the prologue (14x14 80 / 96 wide, 7x7)
+    dP = None
+    if _DP_TENSOR and not fused_pb and se is None and T == torch.bfloat16 and pl.oup % 8 == 0:
+        dP = torch.empty(M2, pl.oup, dtype=T, device=dev)
+        ops.bnbwd_apply(G, Pr, p1, p2, p3, dP, M2, pl.oup)
+    with _Side():   # entered after dP is on the main stream: the side stream waits for it
         for sg, nv, out, si in ([] if fused_pb else wp_jobs):
             if se is not None:
                 ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
+            elif dP is not None:
+                ops.gemm_tn(dP, pl.oup, _seg(D, sg), nv, out, si, 1, M2, v_mode=PRO_BNRELU, vc1=bD.scale[sg:], vc2=bD.shift[sg:],
+                            v_relu=int(act))
             else:
                 ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
                             vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
@@ -290,8 +301,12 @@ def block_backward(pl, sv, G):
                         stat_rows=st2D.rows)
     else:
         # projection input gradient, masked by the depthwise activation, with the depthwise-BN backward statistics
-        ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
-                    zshift=bD.shift, mask=int(act), stats=st2D.t, stat_mode=STAT_Z, stat_rows=st2D.rows)
+        if dP is not None:
+            ops.gemm_nt(dP, pl.WpT_pack, g, M2, HT, pl.oup, z=D, zscale=bD.scale, zshift=bD.shift, mask=int(act), stats=st2D.t,
+                        stat_mode=STAT_Z, stat_rows=st2D.rows)
+        else:
+            ops.gemm_nt(G, pl.WpT_pack, g, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3, z=D, zscale=bD.scale,
+                        zshift=bD.shift, mask=int(act), stats=st2D.t, stat_mode=STAT_Z, stat_rows=st2D.rows)
     d1, d2, d3 = bn_backward_coeffs(pl.bnd, bD, st2D, M2, dev)
     # depthwise backward per branch
     if pl.expand:

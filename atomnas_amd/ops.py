@@ -249,6 +249,12 @@ def bn_apply(x, scale, shift, relu, res, y, M, C):
          _ld(y), M, C, dt_code(x.dtype), _stream())
 
 
+def bnbwd_apply(g, x, c1, c2, c3, y, M, C):
+    """y = c1*g + c2*x + c3 (plain [M, C] tensors): the differentiated BatchNorm output, materialised once"""
+    _chk_cuda(g, x, y)
+    call("atomnas_bnbwd_apply", _p(g), _ld(g), _p(x), _ld(x), _p(c1), _p(c2), _p(c3), _p(y), _ld(y), M, C, dt_code(g.dtype), _stream())
+
+
 def bn_act_pool(x, scale, shift, relu, pooled, keep, drop_p, seed, step_ptr, N, HW, C):
     call("atomnas_bn_act_pool", _p(x), _ld(x), _p(scale), _p(shift), int(relu), _p(pooled), _ld(pooled), _p(keep), float(drop_p),
          int(seed) & 0xFFFFFFFFFFFFFFFF, _p(step_ptr), N, HW, C, dt_code(x.dtype), _stream())

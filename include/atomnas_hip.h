@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 2   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points */
+#define ATOMNAS_ABI_VERSION 3   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -154,6 +154,11 @@ int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, int stat_ld, dou
 /* y = act(x*scale+shift) (+ res): the shared pw_bn + residual of a block, models/mobilenet_base.py:379-381 */
 int atomnas_bn_apply(const void* x, int ldx, const float* scale, const float* shift, int relu, const void* res, int ldres, void* y,
                      int ldy, long M, int C, int dtype, void* stream);
+/* y = c1*g + c2*x + c3 per channel (plain layouts): the gradient through a training-mode BatchNorm as a tensor, i.e. what the
+ *   PRO_BNBWD prologue of the GEMMs computes per tile (torch.nn.BatchNorm2d backward behind models/mobilenet_base.py:338-339).
+ *   Used where one narrow gradient feeds many GEMM tiles (ABI 3). */
+int atomnas_bnbwd_apply(const void* g, int ldg, const void* x, int ldx, const float* c1, const float* c2, const float* c3, void* y,
+                        int ldy, long M, int C, int dtype, void* stream);
 /* pooled[n][c] = dropout(mean_hw act(x*scale+shift)): last ConvBNReLU activation + AvgPool2d + Dropout,
  *   models/mobilenet_supernet.py:148-163 (keep mask written for backward; step_ptr decorrelates iterations) */
 int atomnas_bn_act_pool(const void* x, int ldx, const float* scale, const float* shift, int relu, void* pooled, int ldp,

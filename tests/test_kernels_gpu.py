@@ -139,7 +139,7 @@ GEMM_SHAPES = [(100, 24, 16), (1000, 432, 24), (333, 40, 139), (64, 16, 432), (2
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("variant", ["plain_stats", "bnrelu_stats", "bnbwd_mask_statz", "bnbwd_add_statz", "bias_f32"])
+@pytest.mark.parametrize("variant", ["plain_stats", "bnrelu_stats", "bnbwd_mask_statz", "bnbwd_add_statz", "bias_f32", "plain_mask_statz"])
 def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
     ops = _ops()
     g = torch.Generator().manual_seed(M + 7 * N + 13 * K)
@@ -160,6 +160,9 @@ def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
     elif variant == "bnrelu_stats":
         Aeff = torch.relu(rd(A) * c1.double() + c2.double())
         kw = dict(a_mode=ops.PRO_BNRELU, ac1=cvec(c1), ac2=cvec(c2), a_relu=True, stat_mode=ops.STAT_SQ)
+    elif variant == "plain_mask_statz":   # the streaming kernel's masked form: no prologue (the operand is atomnas_bnbwd_apply's output)
+        Aeff = rd(A)
+        kw = dict(stat_mode=ops.STAT_Z)
     else:
         Aeff = rd(A) if variant == "bias_f32" else c1.double() * rd(A) + c2.double() * rd(A2) + c3.double()
         if variant != "bias_f32":
@@ -167,7 +170,7 @@ def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
     if dtype == torch.bfloat16:
         Aeff = Aeff.to(torch.bfloat16).double()  # the prologue result is rounded to bf16 before the MFMA
     Cref = Aeff @ Wd.t()
-    if variant == "bnbwd_mask_statz":
+    if variant in ("bnbwd_mask_statz", "plain_mask_statz"):
         Cref = Cref * ((rd(Z) * zs.double() + zh.double()) > 0)
         kw.update(z=act2d(Z, N), zscale=cvec(zs), zshift=cvec(zh), mask=True)
     elif variant == "bnbwd_add_statz":
@@ -199,7 +202,7 @@ def test_gemm_nt(gpu_lib, dtype, M, N, K, variant):
 @pytest.mark.parametrize("M,NU,NV", [(100, 24, 16), (1000, 24, 432), (3000, 40, 139), (700, 320, 1152), (257, 700, 40), (50, 3, 7),
                                      # 128-column V tiles: 4 / 6 accumulator tiles on 64-row slabs, two U tiles of 160 on 128-row slabs
                                      (2000, 96, 1728), (1500, 40, 720), (3100, 80, 300)])
-@pytest.mark.parametrize("variant", ["none_none", "none_bnbwd", "bnbwd_bnrelu"])
+@pytest.mark.parametrize("variant", ["none_none", "none_bnbwd", "bnbwd_bnrelu", "none_bnrelu"])
 def test_gemm_tn(gpu_lib, dtype, M, NU, NV, variant):
     ops = _ops()
     g = torch.Generator().manual_seed(M + 7 * NU + 13 * NV)
@@ -219,6 +222,9 @@ def test_gemm_tn(gpu_lib, dtype, M, NU, NV, variant):
         Ve = torch.relu(rd(V) * vc[0].double() + vc[1].double())
         kw = dict(u_mode=ops.PRO_BNBWD, u2=act2d(U2, NU), uc1=cvec(uc[0]), uc2=cvec(uc[1]), uc3=cvec(uc[2]),
                   v_mode=ops.PRO_BNRELU, vc1=cvec(vc[0]), vc2=cvec(vc[1]), v_relu=True)
+    elif variant == "none_bnrelu":   # U = atomnas_bnbwd_apply's output
+        Ve = torch.relu(rd(V) * vc[0].double() + vc[1].double())
+        kw = dict(v_mode=ops.PRO_BNRELU, vc1=cvec(vc[0]), vc2=cvec(vc[1]), v_relu=True)
     if dtype == torch.bfloat16:
         Ue, Ve = Ue.to(torch.bfloat16).double(), Ve.to(torch.bfloat16).double()
     ref = Ue.t() @ Ve  # [NU, NV]
@@ -414,6 +420,76 @@ def test_gemm_slab_layout_is_bit_identical_to_plain(gpu_lib, M, N, K):
         res.append((C.to_plain()[:, :N] if slab else C[:, :N], st, out, out2))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("act", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(2000, 432, 24), (1500, 288, 16), (4111, 720, 40), (3000, 203, 80), (2500, 1440, 96), (1029, 400, 192),
+                                   (30000, 432, 24)])
+def test_gemm_nt_streaming_kernel(gpu_lib, M, N, K, act):
+    """k_gemm_nt_st (bf16, no prologue, K % 8 == 0): expand-forward form and masked input-gradient form, slab-major and plain
+    outputs, ragged M / N, all three activations; against fp64 and the two layouts against each other (bit-identical)."""
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K + act)
+    r = lambda *s: torch.randn(*s, generator=g)
+    A, Z, W = r(M, K), r(M, N), r(N, K) / K ** 0.5
+    zs, zh = torch.rand(N, generator=g) + 0.5, r(N) * 0.3
+    rd = lambda t: t.to(dtype).double()
+    act2d = lambda t, c: torch.cat([t.to(dtype), torch.zeros(t.shape[0], pad8(c) - c, dtype=dtype)], 1).cuda()
+    Ad, Zd, Wp = act2d(A, K), act2d(Z, N), pack_w(W, dtype)
+    Cref = rd(A) @ rd(W).t()
+    pre = rd(Z) * zs.double() + zh.double()
+    if act == 3:
+        sg = torch.sigmoid(pre)
+        Mref = Cref * (sg * (1 + pre * (1 - sg)))
+    else:
+        Mref = Cref * ((pre > 0) & (pre < (6.0 if act == 2 else float("inf")))).double()
+    scale = float(Cref.abs().max())
+    outs = {}
+    for slab in ([False, True] if N % 8 == 0 else [True]):
+        for form in ("fwd", "mask"):
+            C = Slab(M, N, dtype, "cuda", zero=True) if slab else fresh(M, N, dtype)
+            st = poisoned_stats(64, N)
+            if form == "fwd":
+                ops.gemm_nt(Ad, Wp, C, M, N, K, stats=st, stat_mode=ops.STAT_SQ)
+            else:
+                ops.gemm_nt(Ad, Wp, C, M, N, K, z=_slab(Zd, N) if slab else Zd, zscale=cvec(zs), zshift=cvec(zh), mask=act, stats=st,
+                            stat_mode=ops.STAT_Z)
+            torch.cuda.synchronize()
+            Cp = C.to_plain() if slab else C
+            Cg = Cp[:, :N].double().cpu()
+            ref = Cref if form == "fwd" else Mref
+            assert_close("C " + form, Cg, ref, tol(dtype)["rtol"], tol(dtype)["atol"] * max(1.0, scale), outlier_frac=1e-4 if form == "mask" else 0.0)
+            assert float(Cp[:, N:].float().abs().max()) == 0.0 if Cp.shape[1] > N else True
+            s = st.sum(0)
+            assert_close("s1 " + form, s[0], Cg.sum(0), rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale))
+            s2 = (Cg * Cg).sum(0) if form == "fwd" else (Cg * rd(Z)).sum(0)
+            assert_close("s2 " + form, s[1], s2, rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale) ** 2)
+            outs[(slab, form)] = (Cp[:, :N].clone(), st.clone())
+    if N % 8 == 0:
+        for form in ("fwd", "mask"):
+            assert torch.equal(outs[(False, form)][0], outs[(True, form)][0])
+            assert torch.equal(outs[(False, form)][1], outs[(True, form)][1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(1000, 80), (777, 96), (50, 13), (4096, 192)])
+def test_bnbwd_apply(gpu_lib, dtype, M, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + C)
+    r = lambda *s: torch.randn(*s, generator=g)
+    G, X = r(M, C), r(M, C)
+    c1, c2, c3 = torch.rand(C, generator=g) + 0.5, r(C) * 0.2, r(C) * 0.2
+    act2d = lambda t: torch.cat([t.to(dtype), torch.zeros(M, pad8(C) - C, dtype=dtype)], 1).cuda()
+    Y = fresh(M, C, dtype)
+    ops.bnbwd_apply(act2d(G), act2d(X), cvec(c1), cvec(c2), cvec(c3), Y, M, C)
+    torch.cuda.synchronize()
+    ref = c1.double() * G.to(dtype).double() + c2.double() * X.to(dtype).double() + c3.double()
+    t = tol(dtype)
+    assert_close("dP", Y[:, :C].double().cpu(), ref, t["rtol"], t["atol"] * 4)
+    if pad8(C) > C:
+        assert float(Y[:, C:].float().abs().max()) == 0.0
 
 
 # ---------------------------------------------------------------------------------------------- fused expand backward
