@@ -212,6 +212,9 @@ __device__ __forceinline__ void nt_epilogue_core(const Epilogue& ep, const f32x4
           o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
           c[8 * h8 + i] = o8[i];  // statistics see the stored value
         }
+#ifdef NT_X_NOSTORE
+        if (o8[0] == 123.456f)
+#endif
         VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
       }
     }
@@ -1203,28 +1206,33 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
     srow_g[p] = r;
     srow_l[p] = g * 64 + ((n >> 2) & 3) * 16 + (((n >> 4) << 2) | (n & 3));
   }
-  bf16x8 wreg[WPASS];
-  f32x4 creg = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto stage_load = [&](int nc0, int c) {
+  // (a second chunk of weights in flight -- staging loads issued two iterations before their LDS store -- measured no gain on the
+  // projection and -3..-9 % on the two-stream input gradient, r03: the chunk iteration is not waiting for these loads)
+  bf16x8 wA[WPASS];
+  f32x4 cA = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Round 3: every load of the k-loop is UNCONDITIONAL (addresses clamped into the tensor, the value replaced by zero where the
+  // original condition failed).  With loads behind branches the compiler cannot count the operations issued after a load and waits
+  // with s_waitcnt vmcnt(0): the activation prefetch below could then never be more than one chunk deep.
+  auto stage_load = [&](int nc0, int c, bf16x8 (&wreg)[WPASS], f32x4& creg) {
     const int k = c * WS_KC + sseg * 8;
+    const int kc = k < ldw ? k : ldw - 8;
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
 #pragma unroll
     for (int p = 0; p < WPASS; ++p) {
-      bf16x8 z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
-      wreg[p] = z;
-      if (k < ldw && nc0 + srow_g[p] < wrows) wreg[p] = *reinterpret_cast<const bf16x8*>(Wp + (long)(nc0 + srow_g[p]) * ldw + k);
+      const int wr = nc0 + srow_g[p] < wrows ? nc0 + srow_g[p] : wrows - 1;
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(Wp + (long)wr * ldw + kc);
+      wreg[p] = (k < ldw && nc0 + srow_g[p] < wrows) ? w : z;
     }
     if constexpr (NVEC > 0) {
-      if (tid < NVEC * 16) {
-        const int v = tid >> 4, kk = c * WS_KC + (tid & 15) * 4;
-        const float* src = (v == 0) ? A.c1 : (v == 1 ? A.c2 : A.c3);
-        creg = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kk < K8) creg = *reinterpret_cast<const f32x4*>(src + kk);
-      }
+      const int v = (tid >> 4) < NVEC ? (tid >> 4) : 0, kk = c * WS_KC + (tid & 15) * 4;
+      const float* src = (v == 0) ? A.c1 : (v == 1 ? A.c2 : A.c3);
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(src + (kk < K8 ? kk : K8 - 4));
+      creg = kk < K8 ? cv : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&](int buf, const bf16x8 (&wreg)[WPASS], const f32x4& creg) {
 #pragma unroll
     for (int p = 0; p < WPASS; ++p) *reinterpret_cast<bf16x8*>(s_w + buf * WBUF + srow_l[p] * WS_WP + sseg * 8) = wreg[p];
     if constexpr (NVEC > 0) {
@@ -1235,6 +1243,33 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
   // fixed channel group per workgroup, row blocks rs, rs+R, ... (see k_gemm_nt)
   const int grp = blockIdx.x % ngroups, rs = blockIdx.x / ngroups, R = gridDim.x / ngroups;
   const int nc0 = grp * WROWS;
+  // Raw activations of one chunk: [subtile][k-step], 8 consecutive k of one pixel per lane.  The stream is prefetched TWO chunks
+  // ahead, across row-block boundaries (the sequence of (row block, chunk) items of this workgroup is one pipeline): with one
+  // chunk in flight per wave the kernel was latency-bound -- 2.3 TB/s on the 56x56 projection, 0.9 TB/s on the 7x7 one (54 chunks
+  // of one round trip each), while the same kernel with two streams (the BatchNorm-backward prologue) reached 4.7 TB/s.
+  // Rows past M and k past K read clamped addresses: their products meet zero weights / are dropped by the epilogue.
+  WsRaw<MODE> a1[RT][2], a2[RT][2];
+  auto load_a = [&](long rb, int c, WsRaw<MODE> (&dst)[RT][2]) {
+#pragma unroll
+    for (int s = 0; s < RT; ++s) {
+      long r = rb * (64 * RT) + (wave * RT + s) * 16 + j;
+      r = r < M ? r : M - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        int k = c * WS_KC + ks * 32 + 8 * q;
+        k = k < K ? k : K8 - 8;
+        dst[s][ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(r, k, A.ld1, A.ss1));
+        if constexpr (MODE == PRO_BNBWD)
+          dst[s][ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(r, k, A.ld2, A.ss2));
+      }
+    }
+  };
+  stage_load(nc0, 0, wA, cA);
+  load_a(rs, 0, a1);
+  if (nchunk > 1) load_a(rs, 1, a2); else load_a(rs + R, 0, a2);
+  stage_store(0, wA, cA);
+  __syncthreads();
+  int buf = 0;
   for (long rb = rs; rb < rblocks; rb += R) {
     long row[RT];
     bool rowvalid[RT];
@@ -1251,40 +1286,19 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[s][g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // raw activations of one chunk: [subtile][k-step], 8 consecutive k of one pixel per lane
-    WsRaw<MODE> anx[RT][2], acur[RT][2];
-    auto load_a = [&](int c) {
-#pragma unroll
-      for (int s = 0; s < RT; ++s)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int k = c * WS_KC + ks * 32 + 8 * q;
-          bf16x8 z;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
-          anx[s][ks].a = z;
-          if constexpr (MODE == PRO_BNBWD) anx[s][ks].x = z;
-          if (rowvalid[s] && k < K) {   // beyond K the packed weights are zero: no masking needed, but never read past a row
-            anx[s][ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row[s], k, A.ld1, A.ss1));
-            if constexpr (MODE == PRO_BNBWD)
-              anx[s][ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row[s], k, A.ld2, A.ss2));
-          }
-        }
-    };
-
-    stage_load(nc0, 0);
-    load_a(0);
-    stage_store(0);
-    __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
-      const int buf = c & 1;
+      WsRaw<MODE> acur[RT][2];
 #pragma unroll
       for (int s = 0; s < RT; ++s)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acur[s][ks] = anx[s][ks];
-      if (c + 1 < nchunk) {
-        stage_load(nc0, c + 1);
-        load_a(c + 1);
+        for (int ks = 0; ks < 2; ++ks) { acur[s][ks] = a1[s][ks]; a1[s][ks] = a2[s][ks]; }
+      {   // weights of the next item, activations of the one after it
+        stage_load(nc0, c + 1 < nchunk ? c + 1 : 0, wA, cA);
+        int c2 = c + 2;
+        long rb2 = rb;
+        if (c2 >= nchunk) { c2 -= nchunk; rb2 += R; }
+        if (c2 >= nchunk) { c2 -= nchunk; rb2 += R; }   // nchunk == 1
+        load_a(rb2, c2, a2);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -1322,8 +1336,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
             for (int s = 0; s < RT; ++s) acc[s][g][t] = MM::mma(wf, af[s], acc[s][g][t]);
           }
       }
-      if (c + 1 < nchunk) stage_store(buf ^ 1);
+      stage_store(buf ^ 1, wA, cA);
       __syncthreads();
+      buf ^= 1;
     }
 
 #pragma unroll

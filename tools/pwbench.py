@@ -1,8 +1,10 @@
 """Micro-benchmark of the pointwise GEMM entry points through the C ABI on the step's shapes (experiments; not a test).
 
-    python tools/pwbench.py [lib.so] [expand|mask|all] [N]
+    python tools/pwbench.py [lib.so] [expand|mask|project|dgrad|all] [N]
 expand: gemm_nt of the expand forward (x[M,inp] -> E[M,hid] slab-major, sum / sum-of-squares statistics)
 mask  : gemm_nt of the projection input gradient through the depthwise activation (dP[M,oup] -> g[M,hid], z = D, statistics sum g, sum g*z)
+project: gemm_nt of the projection forward (act(bn(D))[M,hid] -> P[M,oup], sum / sum-of-squares statistics)
+dgrad : gemm_nt of the expand input gradient (BatchNorm-backward prologue over h, E [M,hid] -> Gx[M,inp], + residual gradient)
 Tensor sets rotate so that the 256 MiB Infinity Cache does not serve re-runs.  GB/s counts the wide tensors only (written / read once).
 """
 import os, sys, torch
@@ -74,6 +76,28 @@ for (H, inp, hid) in CASES:
         t = bench(f, ITERS); tot["mask"] += t
         line += "  mask %.3f ms %5.0f GB/s" % (t, 2 * M * hid * 2 / t / 1e6)
         del z
+    if which in ("project", "dgrad", "all"):
+        from atomnas_amd.ops import PRO_BNRELU, PRO_BNBWD
+        a = [Slab.from_plain(torch.randn(M, hid, device="cuda").bfloat16()) for _ in range(nset)]
+        WT = pack_w(torch.randn(inp, hid, device="cuda") / hid ** 0.5)
+        out = torch.empty(M, inp, dtype=torch.bfloat16, device="cuda")
+        c1, c2, c3 = torch.rand(hid, device="cuda") + 0.5, torch.randn(hid, device="cuda") * 0.2, torch.randn(hid, device="cuda") * 0.2
+        rows2 = ops.stat_rows_for(inp)
+        st2 = torch.empty(rows2 * 2 * inp, device="cuda")
+        if which in ("project", "all"):
+            def f():
+                i = cnt[0] % nset; cnt[0] += 1
+                ops.gemm_nt(a[i], WT, out, M, inp, hid, a_mode=PRO_BNRELU, ac1=c1, ac2=c2, a_relu=1, stats=st2, stat_mode=STAT_SQ, stat_rows=rows2)
+            t = bench(f, ITERS); tot["project"] = tot.get("project", 0.0) + t
+            line += "  project %.3f ms %5.0f GB/s" % (t, M * hid * 2 / t / 1e6)
+        if which in ("dgrad", "all"):
+            res = torch.randn(M, inp, device="cuda").bfloat16()
+            def f():
+                i = cnt[0] % nset; cnt[0] += 1
+                ops.gemm_nt(a[i], WT, out, M, inp, hid, a_mode=PRO_BNBWD, a2=wide[i], ac1=c1, ac2=c2, ac3=c3, add=res)
+            t = bench(f, ITERS); tot["dgrad"] = tot.get("dgrad", 0.0) + t
+            line += "  dgrad %.3f ms %5.0f GB/s" % (t, 2 * M * hid * 2 / t / 1e6)
+        del a
     print(line, flush=True)
     del x, wide
-print("sum expand %.3f ms  mask %.3f ms" % (tot["expand"], tot["mask"]))
+print("sum " + "  ".join("%s %.3f ms" % kv for kv in tot.items()))
