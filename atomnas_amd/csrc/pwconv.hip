@@ -684,8 +684,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __r
 //   ST_FWD  : C = A * W^T, optional sum c / sum c^2 statistics               (the expand forward, mobilenet_base.py:316-320)
 //   ST_MASK : C = mask_z(A * W^T), optional sum c / sum c*z statistics        (the input gradient of the projection through the
 //             activation of the depthwise BatchNorm; A is the already differentiated BatchNorm output, see atomnas_bnbwd_apply)
+//   ST_PBWD : ST_MASK plus the projection's weight gradient of the wave's 64 channels (atomnas_project_bwd without a prologue)
 // A is plain bf16 without a prologue, K a multiple of 8; weights as for k_gemm_nt_cs (rows >= N and columns >= K of Wp are zero).
-enum { ST_FWD = 1, ST_MASK = 2 };
+constexpr int PB_RP = 16 + 4;   // rows of a tile + pad (elements): 40-byte rows, 8-byte aligned fragment reads
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+enum { ST_FWD = 1, ST_MASK = 2, ST_PBWD = 3 };
 // per k-steps: burst tiles of the narrow operand (0: per-tile ring), ring depth (of z, and of the operand when there is no
 // burst), waves per SIMD the registers are allocated for
 #ifndef ST_BT1
@@ -697,6 +700,12 @@ enum { ST_FWD = 1, ST_MASK = 2 };
 #ifndef ST_BT3
 #define ST_BT3 4
 #endif
+#ifndef ST_PB_BT1
+#define ST_PB_BT1 4
+#endif
+#ifndef ST_PB_BT2
+#define ST_PB_BT2 2
+#endif
 #ifndef ST_WPE1
 #define ST_WPE1 1
 #endif
@@ -707,7 +716,8 @@ enum { ST_FWD = 1, ST_MASK = 2 };
 #define ST_WPE3 1
 #endif
 template <int KSTEPS, int EPK> struct StCfg {
-  static constexpr int BT = KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : 0;
+  static constexpr int BT = EPK == ST_PBWD ? (KSTEPS == 1 ? ST_PB_BT1 : ST_PB_BT2)   // registers: + the weight-gradient accumulators
+                                            : KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : 0;
   static constexpr int PD = BT > 0 ? (BT >= 2 ? 2 : 1) : 2;
   static constexpr int WPE = EPK != ST_FWD ? 1 : KSTEPS == 1 ? ST_WPE1 : KSTEPS == 2 ? ST_WPE2 : KSTEPS == 3 ? ST_WPE3 : 1;
 };
@@ -719,10 +729,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* p) {
 }
 __device__ __forceinline__ bf16x8 st_as_bf16(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int KSTEPS, int EPK, int PD, int BT, int WPE>
+template <int KSTEPS, int EPK, int PD, int BT, int WPE, int UT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_gemm_nt_st(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K,
-                                                    int nchunks, int tiles_per_item) {
+                                                    int nchunks, int tiles_per_item, float* __restrict__ ws) {
   using MM = Mma<bf16_t>;
+  constexpr bool MASKED = EPK != ST_FWD;
+  extern __shared__ u32x4 st_stage[];   // [4 waves][BT * KSTEPS][64] burst staging, then (ST_PBWD) [4 waves] transposed tiles
   const int lane = threadIdx.x & 63;
   const int q = lane >> 4, j = lane & 15;
   const int wrow = 16 * (j >> 2) + (j & 3);
@@ -772,8 +784,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   }
   __amdgpu_buffer_rsrc_t rz = rc;
   unsigned z_tile = 0;
-  float zs[16], zh[16];
-  if constexpr (EPK == ST_MASK) {
+  // per-channel scale / shift of z: in a wave-private LDS slot (read back per tile), not in 32 registers
+  float* s_zc = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(st_stage + 4 * BT * KSTEPS * 64) + 4 * (16 * (UT > 0 ? UT : 1) + 64) * PB_RP) + wave * 128;
+  if constexpr (MASKED) {
     const bf16_t* zp = reinterpret_cast<const bf16_t*>(ep.z) + (ep.zss ? (long)(nc >> 4) * ep.zss + row0 * 16 : row0 * ep.ldz + nc);
     rz = st_rsrc(zp);
     z_tile = ep.zss ? 512u : 32u * (unsigned)ep.ldz;
@@ -783,35 +796,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       const long e = ep.zss ? (long)q * ep.zss + j * 16 + 8 * h : (long)j * ep.ldz + 16 * q + 8 * h;
       z_lane[h] = nb + 8 * h < zalloc ? (unsigned)(2 * e) : ST_OOB;
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {   // per-channel vectors are readable up to N rounded up to 8; beyond that the lane never uses them
-      const bool ok = nb + i < (N + 7) / 8 * 8;
-      zs[i] = ok ? ep.zscale[nb + i] : 0.f;
-      zh[i] = ok ? ep.zshift[nb + i] : 0.f;
+    {   // per-channel vectors are readable up to N rounded up to 8; beyond that: zeros
+      const int n = nc + lane;
+      const bool ok = n < (N + 7) / 8 * 8;
+      s_zc[lane] = ok ? ep.zscale[n] : 0.f;
+      s_zc[64 + lane] = ok ? ep.zshift[n] : 0.f;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   const Act am = act_of(ep.mask);
 
   float s1[16], s2[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+  // ST_PBWD: the weight gradient dWp[o][n] += sum_m A[m][o] * act(bn(z))[m][n] of the wave's 64 channels, as in k_project_bwd_cs
+  // (both operands transposed through a wave-private LDS region, 16x16x16 MFMAs over the tile's 16 rows)
+  constexpr int UTA = UT > 0 ? UT : 1;
+  f32x4 racc[UTA][4];
+#pragma unroll
+  for (int t = 0; t < UTA; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) racc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16_t* s_p = reinterpret_cast<bf16_t*>(st_stage + 4 * BT * KSTEPS * 64) + wave * (16 * UTA + 64) * PB_RP;   // [16*UT][PB_RP] A^T
+  bf16_t* s_a = s_p + 16 * UTA * PB_RP;                                                                         // [64][PB_RP] act(bn(z))^T
 
   // ---- epilogue of one tile: accumulators -> (mask) -> bf16 -> store, statistics of the stored values
-  auto finish = [&](int t, const f32x4 (&acc)[4], const u32x4 (&zc)[2]) {
+  auto finish = [&](int t, const f32x4 (&acc)[4], const u32x4 (&zc)[2], const u32x4 (&araw)[KSTEPS]) {
     float c[16];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[4 * u + r] = acc[u][r];
-    float zv[16];
-    if constexpr (EPK == ST_MASK) {
+    float zv[16], a16[16];
+    if constexpr (MASKED) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const bf16x8 zb = st_as_bf16(zc[h]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) zv[8 * h + i] = (float)zb[i];
       }
-      float a16[16];
+      float zs[16], zh[16];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s_zc + 16 * q + 4 * v);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(s_zc + 64 + 16 * q + 4 * v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zs[4 * v + r] = a[r]; zh[4 * v + r] = b2[r]; }
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) a16[i] = zv[i] * zs[i] + zh[i];
       if (__builtin_expect(am.swish, 0)) {
@@ -821,6 +854,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
         for (int i = 0; i < 16; ++i) c[i] = act_pass(a16[i], am) ? c[i] : 0.f;
       }
+    }
+    if constexpr (EPK == ST_PBWD) {
+      // the projection's forward operand act(bn(z)) and A, both transposed ([channel][row]); rows past M carry A = 0
+      act_apply_v<16>(a16, am);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_a[(16 * q + i) * PB_RP + j] = (bf16_t)a16[i];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bf16x8 af = st_as_bf16(araw[ks]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int o = ks * 32 + 8 * q + e;
+          if (o < 16 * UTA) s_p[o * PB_RP + j] = af[e];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      s16x4 bfr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bfr[u] = *reinterpret_cast<const s16x4*>(s_a + (16 * u + j) * PB_RP + 4 * q);
+#pragma unroll
+      for (int tt = 0; tt < UTA; ++tt) {
+        const s16x4 afr = *reinterpret_cast<const s16x4*>(s_p + (16 * tt + j) * PB_RP + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) racc[tt][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afr, bfr[u], racc[tt][u], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // the next tile overwrites s_p / s_a
     }
     const bool rv = j < rows_item - 16 * t;
 #pragma unroll
@@ -866,14 +928,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     // 4 / 8 tiles 198 / 171 us): the operand is fetched BT tiles (several KB, contiguous) at a time.  The burst lands in registers,
     // is parked in a lane-private LDS slot (each lane reads back exactly what it wrote: no barrier), and the same registers take the
     // next burst, which has the whole BT-tile period to arrive.
-    extern __shared__ u32x4 st_stage[];
     u32x4* my = st_stage + (long)wave * (BT * KSTEPS * 64) + lane;
     u32x4 bn[BT][KSTEPS];
 #pragma unroll
     for (int u = 0; u < BT; ++u)
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) bn[u][ks] = load_a(u, ks);
-    if constexpr (EPK == ST_MASK) {
+    if constexpr (MASKED) {
 #pragma unroll
       for (int u = 0; u < PD; ++u) { zn[u][0] = load_z(u, 0); zn[u][1] = load_z(u, 1); }
 #pragma unroll
@@ -910,7 +971,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           ac[ks] = my[eo + ks * 64];
           asm volatile("" : "+v"(ac[ks]));
         }
-        if constexpr (EPK == ST_MASK) {
+        if constexpr (MASKED) {
           asm volatile("" : "+v"(zn[u % PD][0]));
           zc[0] = zn[u % PD][0]; zc[1] = zn[u % PD][1];
         }
@@ -923,8 +984,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
           for (int v = 0; v < 4; ++v) acc[v] = MM::mma(wf[ks][v], af, acc[v]);
         }
-        finish(t, acc, zc);
-        if constexpr (EPK == ST_MASK) { zn[u % PD][0] = load_z(t + PD, 0); zn[u % PD][1] = load_z(t + PD, 1); }
+        finish(t, acc, zc, ac);
+        if constexpr (MASKED) { zn[u % PD][0] = load_z(t + PD, 0); zn[u % PD][1] = load_z(t + PD, 1); }
         __builtin_amdgcn_sched_barrier(0);   // one tile at a time
       }
     }
@@ -938,13 +999,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     for (int u = 0; u < PD; ++u) {
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) an[u][ks] = load_a(u, ks);
-      if constexpr (EPK == ST_MASK) { zn[u][0] = load_z(u, 0); zn[u][1] = load_z(u, 1); }
+      if constexpr (MASKED) { zn[u][0] = load_z(u, 0); zn[u][1] = load_z(u, 1); }
     }
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(an[u][ks]));
-      if constexpr (EPK == ST_MASK) { asm volatile("" : "+v"(zn[u][0])); asm volatile("" : "+v"(zn[u][1])); }
+      if constexpr (MASKED) { asm volatile("" : "+v"(zn[u][0])); asm volatile("" : "+v"(zn[u][1])); }
     }
     for (int t0 = 0; t0 < ntiles; t0 += PD) {
 #pragma unroll
@@ -954,7 +1015,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         u32x4 zc[2];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(an[slot][ks]));
-        if constexpr (EPK == ST_MASK) { zc[0] = zn[slot][0]; zc[1] = zn[slot][1]; }
+        if constexpr (MASKED) { zc[0] = zn[slot][0]; zc[1] = zn[slot][1]; }
         f32x4 acc[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -964,10 +1025,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
           for (int v = 0; v < 4; ++v) acc[v] = MM::mma(wf[ks][v], af, acc[v]);
         }
+        u32x4 akeep[KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) an[slot][ks] = load_a(t + PD, ks);
-        if constexpr (EPK == ST_MASK) { zn[slot][0] = load_z(t + PD, 0); zn[slot][1] = load_z(t + PD, 1); }
-        finish(t, acc, zc);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          akeep[ks] = an[slot][ks];
+          an[slot][ks] = load_a(t + PD, ks);
+        }
+        if constexpr (MASKED) { zn[slot][0] = load_z(t + PD, 0); zn[slot][1] = load_z(t + PD, 1); }
+        finish(t, acc, zc, akeep);
         __builtin_amdgcn_sched_barrier(0);   // one tile at a time
       }
     }
@@ -990,6 +1055,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       }
     }
   }
+  if constexpr (EPK == ST_PBWD) {
+    // partial of the weight gradient: (o, n) at ws[(range * K + o) * N + n], summed in range order by reduce_parts
+#pragma unroll
+    for (int t = 0; t < UTA; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = nc + 16 * u + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * t + 4 * q + r;
+          if (o < K && n < N) ws[((long)range * K + o) * N + n] = racc[t][u][r];
+        }
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ fused project backward
@@ -1000,8 +1079,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 // region (no workgroup barrier: LDS operations of one wave complete in order) and accumulates R[oup][64] with 16x16x16 MFMAs
 // (contraction over the tile's 16 rows).  One partial per (row range, chunk) in the caller's workspace, summed in range order by
 // reduce_parts.  This removes atomnas_pw_gemm_tn's second pass over z.
-constexpr int PB_RP = 16 + 4;   // rows of a tile + pad (elements): 40-byte rows, 8-byte aligned fragment reads
-typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <int KSTEPS, int UT>
 __global__ __launch_bounds__(256) void k_project_bwd_cs(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, float* __restrict__ ws,
@@ -1841,8 +1918,8 @@ static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, co
 #define ST_CASE(EPKV)                                                                                                   \
   {                                                                                                                     \
     using Cfg = StCfg<KSTEPS, EPKV>;                                                                                    \
-    auto kern = k_gemm_nt_st<KSTEPS, EPKV, Cfg::PD, Cfg::BT, Cfg::WPE>;                                                 \
-    const size_t lds = (size_t)4 * Cfg::BT * KSTEPS * 1024;   /* the burst staging, one lane-private slot per wave */   \
+    auto kern = k_gemm_nt_st<KSTEPS, EPKV, Cfg::PD, Cfg::BT, Cfg::WPE, 0>;                                               \
+    const size_t lds = (size_t)4 * Cfg::BT * KSTEPS * 1024 + (EPKV == ST_FWD ? 0 : (size_t)4 * (16 + 64) * PB_RP * sizeof(bf16_t) + 4 * 128 * sizeof(float)); /* burst staging (+ z coefficients) */ \
     const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;                                           \
     long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;                                                       \
     if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
@@ -1851,7 +1928,7 @@ static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, co
     if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges; \
     if (tiles_per_item > 4096) tiles_per_item = 4096;   /* keeps t * tile bytes in 32 bits (nt_st_kind) */              \
     const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;                                      \
-    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item, (float*)nullptr); \
   }
   if (kind == ST_FWD) ST_CASE(ST_FWD) else ST_CASE(ST_MASK)
 #undef ST_CASE
@@ -2104,6 +2181,33 @@ static int launch_tn(int umode, const Operand& U, int NU, int vmode, const Opera
 }
 
 // fused project backward (column-stationary input gradient + weight gradient)
+// the streaming form of the fused projection backward: A is the materialised dP (atomnas_bnbwd_apply), no prologue
+template <int KSTEPS, int UT>
+static int launch_project_bwd_st(const Operand& A, const bf16_t* W, int ldw, const Epilogue& ep, float* dwp, long si, long sj, float* ws,
+                                 long ws_floats, long M, int N, int K, hipStream_t st) {
+  using Cfg = StCfg<KSTEPS, ST_PBWD>;
+  const int nchunks = (N + 63) / 64;
+  const long mtiles = (M + 15) / 16;
+  auto kern = k_gemm_nt_st<KSTEPS, ST_PBWD, Cfg::PD, Cfg::BT, Cfg::WPE, UT>;
+  const size_t lds = (size_t)4 * Cfg::BT * KSTEPS * 1024 + (size_t)4 * (16 * UT + 64) * PB_RP * sizeof(bf16_t) + 4 * 128 * sizeof(float);
+  const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;
+  long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;
+  if (tiles_per_item < 8) tiles_per_item = 8;
+  const long min_tpi = (mtiles + ep.stat_rows - 1) / ep.stat_rows;   // every row range owns one partial row of the statistics
+  if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;
+  const long max_parts = ws_floats / ((long)K * N);   // ... and one partial of the weight gradient
+  ATOMNAS_REQUIRE(max_parts >= 1, "project_bwd: workspace too small for one partial (%ld floats)", (long)K * N);
+  long max_ranges = waves / nchunks > 0 ? waves / nchunks : 1;
+  if (max_ranges > max_parts) max_ranges = max_parts;
+  if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges;
+  ATOMNAS_REQUIRE(tiles_per_item <= 4096, "project_bwd: %ld row tiles per work item (workspace / statistics rows too small for M=%ld)", tiles_per_item, M);
+  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
+  const long items = nranges * nchunks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item, ws);
+  if (int rc = check_launch("project_bwd_st")) return rc;
+  return reduce_parts(ws, (long)K * N, (int)nranges, (long)K * N, dwp, N, si, sj, st);
+}
+
 template <int KSTEPS, int UT>
 static int launch_project_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, const Epilogue& ep, float* dwp, long si, long sj, float* ws,
                                   long ws_floats, long M, int N, int K, hipStream_t st) {
@@ -2278,9 +2382,10 @@ extern "C" int atomnas_project_bwd(const void* g, int ldg, const void* p, int ld
                                    int act, void* gh, int ldgh, long gh_ss, float* stats, int stat_rows, float* dwp, long si, long sj,
                                    float* ws, long ws_floats, long M, int oup, int hid, int dtype, void* stream) {
   ATOMNAS_REQUIRE(atomnas_project_bwd_supported(oup, hid, dtype), "project_bwd: unsupported shape oup=%d hid=%d dtype=%d", oup, hid, dtype);
-  ATOMNAS_REQUIRE(g && p && c1 && c2 && c3 && wpt && z && zscale && zshift && gh && stats && dwp && ws && M > 0, "project_bwd: bad arguments");
+  const bool have_dp = !p && !c1 && !c2 && !c3;   // g is already dP = c1*g + c2*p + c3 (atomnas_bnbwd_apply): the streaming kernel
+  ATOMNAS_REQUIRE(g && (have_dp || (p && c1 && c2 && c3)) && wpt && z && zscale && zshift && gh && stats && dwp && ws && M > 0, "project_bwd: bad arguments");
   ATOMNAS_REQUIRE(act >= ACT_RELU && act <= ACT_SWISH && stat_rows > 0, "project_bwd: bad activation / stat_rows");
-  ATOMNAS_REQUIRE(ldg >= oup && ldg % 8 == 0 && ldp >= oup && ldp % 8 == 0, "project_bwd: bad pitch");
+  ATOMNAS_REQUIRE(ldg >= oup && ldg % 8 == 0 && (have_dp || (ldp >= oup && ldp % 8 == 0)), "project_bwd: bad pitch");
   ATOMNAS_REQUIRE((z_ss >= M * 16 || (z_ss == 0 && ldz >= hid && ldz % 8 == 0)) && (gh_ss >= M * 16 || (gh_ss == 0 && ldgh >= hid && ldgh % 8 == 0)),
                   "project_bwd: bad hidden layout");
   ATOMNAS_REQUIRE(ldw >= (oup + 31) / 32 * 32 && ldw % 8 == 0, "project_bwd: packed weight pitch %d too small for oup=%d", ldw, oup);
@@ -2289,6 +2394,14 @@ extern "C" int atomnas_project_bwd(const void* g, int ldg, const void* p, int ld
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* W = (const bf16_t*)wpt;
   const int ut = (oup + 15) / 16;
+  if (have_dp) {
+    ATOMNAS_REQUIRE(oup % 8 == 0 && oup <= 64, "project_bwd: the dP form needs oup %% 8 == 0 and oup <= 64 (got %d)", oup);
+    ATOMNAS_REQUIRE(nt_st_kind(PRO_NONE, A, ep, M, hid, oup) == ST_MASK, "project_bwd: the dP form needs slab-major hidden tensors (or plain ones with hid %% 8 == 0) below 2 GB per 64-channel chunk");
+    if (ut == 1) return launch_project_bwd_st<1, 1>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+    if (ut == 2) return launch_project_bwd_st<1, 2>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+    if (ut == 3) return launch_project_bwd_st<2, 3>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+    return launch_project_bwd_st<2, 4>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  }
   if (oup <= 32) {
     if (ut == 1) return launch_project_bwd_cfg<1, 1>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
     return launch_project_bwd_cfg<1, 2>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);

@@ -215,13 +215,14 @@ def project_bwd_supported(oup, hid, dtype):
 
 def project_bwd(g, p, c1, c2, c3, wpt_pack, z, zscale, zshift, act, gh, stats, dwp, si, sj, M, oup, hid, stat_rows=None, ws=None):
     """Fused backward of the projection (include/atomnas_hip.h): masked input gradient gh with the BN-backward statistics, and
-    dwp[o*si + n*sj] += dP^T act(bn(z)), from one pass over z."""
-    _chk_cuda(g, p, z, gh, dwp, wpt_pack)
+    dwp[o*si + n*sj] += dP^T act(bn(z)), from one pass over z.  p = c1 = c2 = c3 = None: g is already dP (bnbwd_apply), the
+    streaming kernel (oup % 8 == 0, oup <= 64)."""
+    _chk_cuda(g, z, gh, dwp, wpt_pack)
     if ws is None:
         ws = torch.empty(min(512 * oup * hid, 16 << 20), dtype=torch.float32, device=g.device)
     if _lib.PROFILE is not None:
-        _lib.profile_tag("M%d N%d K%d fusedbwd" % (M, hid, oup))
-    call("atomnas_project_bwd", _p(g), _ld(g), _p(p), _ld(p), _p(c1), _p(c2), _p(c3), _p(wpt_pack), wpt_pack.stride(0), _p(z), _ld(z), _ss(z),
+        _lib.profile_tag("M%d N%d K%d fusedbwd%s" % (M, hid, oup, "" if p is not None else "+dP"))
+    call("atomnas_project_bwd", _p(g), _ld(g), _p(p), _ld(p) if p is not None else 0, _p(c1), _p(c2), _p(c3), _p(wpt_pack), wpt_pack.stride(0), _p(z), _ld(z), _ss(z),
          _p(zscale), _p(zshift), int(act), _p(gh), _ld(gh), _ss(gh), _p(stats), _rows(stats, stat_rows), _p(dwp), si, sj, _p(ws), ws.numel(),
          M, oup, hid, dt_code(g.dtype), _stream())
 

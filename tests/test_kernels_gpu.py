@@ -583,3 +583,17 @@ def test_project_bwd_fused_matches_the_two_gemm_form(gpu_lib, M, oup, hid, act, 
     A = {1: torch.relu(pre), 2: pre.clamp(0, 6), 3: pre * torch.sigmoid(pre)}[act].float().to(dtype).double()
     ref_dw = dP.t() @ A + 0.5
     assert_close("dwp", dw1, ref_dw, rtol=2e-3, atol=3e-3 * float(ref_dw.abs().max()))
+    if oup % 8 == 0 and oup <= 64 and (slab or hid % 8 == 0):
+        # the streaming form: dP materialised by atomnas_bnbwd_apply, no prologue (k_gemm_nt_st, ST_PBWD)
+        dPt = fresh(M, oup, dtype)
+        ops.bnbwd_apply(G, P, c1, c2, c3, dPt, M, oup)
+        gh3, st3, dw3 = mk(), poisoned_stats(128, hid), torch.full((oup, hid), 0.5, dtype=torch.float32, device="cuda")
+        ops.project_bwd(dPt, None, None, None, None, wpt, Zs, zs, zh, act, gh3, st3, dw3.view(-1), hid, 1, M, oup, hid)
+        torch.cuda.synchronize()
+        c = (gh3.to_plain() if slab else gh3)[:, :hid].float()
+        assert float((c != b).float().mean()) < 0.02
+        assert torch.allclose(c, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+        assert not torch.isnan(st3).any()
+        s3 = st3.sum(0)
+        assert torch.allclose(s3, s2, rtol=1e-3, atol=2e-3 * float(s2.abs().max())), float((s3 - s2).abs().max())
+        assert_close("dwp dP form", dw3, ref_dw, rtol=2e-3, atol=3e-3 * float(ref_dw.abs().max()))
