@@ -19,6 +19,7 @@
 // fp32 storage uses mfma_f32_16x16x4f32 through the same code (exact f32; for parity tests, not for speed).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace atomnas {
 
@@ -1796,52 +1797,130 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_readcyclecounter();
 #endif
+  // Round 3: the staging loads of a slab are issued TOGETHER, one slab ahead, and only then transformed and stored transposed.
+  // Before, every staging iteration (two rows x 8 channels per thread) loaded and immediately consumed its own data: 10 memory
+  // round trips per 128-row slab (139 us for the 7x7 projection weight gradient, 87 MB of operands).  All loads are unconditional
+  // (clamped addresses; validity is applied to the values), so the wait before the transform is a counted one.
+  constexpr int NVU = ((ROWS / 2) * (VW / 8) + 255) / 256;        // V work units (row pair x 8 channels) per thread
+  constexpr int NUU = ((ROWS / 2) * (2 * UTT) + 255) / 256;       // U work units per thread (at most: ut may be smaller)
+  constexpr bool V2 = VMODE == PRO_BNBWD, U2 = UMODE == PRO_BNBWD;
+  bf16x8 rva[NVU][2], rvx[V2 ? NVU : 1][2], rua[NUU][2], rux[U2 ? NUU : 1][2];
+  const int K8V = (NV + 7) & ~7, K8U = (NU + 7) & ~7;
+  auto unit = [&](int idx, int groups, int& cg, int& rp) {
+#if TN2_COALESCED
+    cg = idx % groups; rp = idx / groups;
+#else
+    rp = idx % (ROWS / 2); cg = idx / (ROWS / 2);
+#endif
+  };
+  auto issue = [&](long r0) {
+#pragma unroll
+    for (int i = 0; i < NVU; ++i) {
+      int cg, rp;
+      const int idx = tid + 256 * i;
+      unit(idx < (ROWS / 2) * (VW / 8) ? idx : 0, VW / 8, cg, rp);
+      int k = v0 + cg * 8;
+      k = k < NV ? k : K8V - 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        long r = r0 + 2 * rp + h;
+        r = r < M ? r : M - 1;
+        rva[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p1) + lay_off(r, k, V.ld1, V.ss1));
+        if constexpr (V2) rvx[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p2) + lay_off(r, k, V.ld2, V.ss2));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NUU; ++i) {
+      int cg, rp;
+      const int idx = tid + 256 * i;
+      unit(idx < (ROWS / 2) * ugroups ? idx : 0, ugroups, cg, rp);
+      int k = u0 + cg * 8;
+      k = k < NU ? k : K8U - 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        long r = r0 + 2 * rp + h;
+        r = r < M ? r : M - 1;
+        rua[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p1) + lay_off(r, k, U.ld1, U.ss1));
+        if constexpr (U2) rux[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p2) + lay_off(r, k, U.ld2, U.ss2));
+      }
+    }
+  };
+  // prologue of 8 raw channels of one row (coefficients from LDS; entries of channels >= K are zero), zero where invalid
+  auto xform = [&](auto mode_tag, const Operand& o, const bf16x8& ra, const bf16x8& rx, bool valid, const float* lc1, const float* lc2,
+                   const float* lc3, float (&v)[8]) {
+    constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)ra[e];
+    if constexpr (MODE == PRO_BNRELU) {
+      float sc[8], sh[8];
+      VecIO<float, 8>::load(lc1, sc);
+      VecIO<float, 8>::load(lc2, sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+      act_apply_v<8>(v, act_of(o.relu));
+    } else if constexpr (MODE == PRO_BNBWD) {
+      float a1[8], a2[8], a3[8];
+      VecIO<float, 8>::load(lc1, a1);
+      VecIO<float, 8>::load(lc2, a2);
+      VecIO<float, 8>::load(lc3, a3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = a1[e] * v[e] + a2[e] * (float)rx[e] + a3[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = valid ? v[e] : 0.f;
+  };
+  auto stage = [&](long r0) {
+#pragma unroll
+    for (int i = 0; i < NVU; ++i) {
+      int cg, rp;
+      const int idx = tid + 256 * i;
+      const bool active = idx < (ROWS / 2) * (VW / 8);
+      unit(active ? idx : 0, VW / 8, cg, rp);
+      float a[8], bb[8];
+      const float* lc = s_cv + cg * 8;
+      const bool kv = v0 + cg * 8 < NV;
+      xform(std::integral_constant<int, VMODE>{}, V, rva[i][0], rvx[V2 ? i : 0][0], kv && (r0 + 2 * rp) < r_end, lc, lc + VW, lc + 2 * VW, a);
+      xform(std::integral_constant<int, VMODE>{}, V, rva[i][1], rvx[V2 ? i : 0][1], kv && (r0 + 2 * rp + 1) < r_end, lc, lc + VW, lc + 2 * VW, bb);
+      const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
+      if (active) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+          const int e = (ii + rot) & 7;
+          bf16x2 pk;
+          pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)bb[e];
+          *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * RP + 2 * rp]) = pk;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NUU; ++i) {
+      int cg, rp;
+      const int idx = tid + 256 * i;
+      const bool active = idx < (ROWS / 2) * ugroups;
+      unit(active ? idx : 0, ugroups, cg, rp);
+      float a[8], bb[8];
+      const float* lc = s_cu + cg * 8;
+      const bool kv = u0 + cg * 8 < NU;
+      xform(std::integral_constant<int, UMODE>{}, U, rua[i][0], rux[U2 ? i : 0][0], kv && (r0 + 2 * rp) < r_end, lc, lc + 16 * UTT, lc + 32 * UTT, a);
+      xform(std::integral_constant<int, UMODE>{}, U, rua[i][1], rux[U2 ? i : 0][1], kv && (r0 + 2 * rp + 1) < r_end, lc, lc + 16 * UTT, lc + 32 * UTT, bb);
+      const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
+      if (active) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+          const int e = (ii + rot) & 7;
+          bf16x2 pk;
+          pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)bb[e];
+          *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * RP + 2 * rp]) = pk;
+        }
+      }
+    }
+  };
+  issue(r_beg);
   for (long r0 = r_beg; r0 < r_end; r0 += ROWS) {
     TN_MARK(5)
-    // stage: a work unit is (row pair, 8-channel group), channel groups fastest across lanes (whole 128-byte row segments per
-    // load instruction); both rows are loaded, transformed, packed and stored transposed.  The element order is rotated
-    // per channel group so that the 64 lanes of each ds_write_b32 hit 64 distinct banks (RP = 136: bank = 32*(cg&1) +
-    // 4*e + rp; rotating e by 2*(cg>>1) spreads the four groups that would collide).
-    for (int idx = tid; idx < (ROWS / 2) * (VW / 8); idx += 256) {
-#if TN2_COALESCED
-      const int cg = idx % (VW / 8), rp = idx / (VW / 8);
-#else
-      const int rp = idx % (ROWS / 2), cg = idx / (ROWS / 2);
-#endif
-      float a[8], b[8];
-      const float* lc = s_cv + cg * 8;
-      load_pro_lds<VMODE>(V, r0 + 2 * rp, (r0 + 2 * rp) < r_end, v0 + cg * 8, NV, lc, lc + VW, lc + 2 * VW, a);
-      load_pro_lds<VMODE>(V, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, v0 + cg * 8, NV, lc, lc + VW, lc + 2 * VW, b);
-      const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int e = (i + rot) & 7;
-        bf16x2 pk;
-        pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
-        *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * RP + 2 * rp]) = pk;
-      }
-    }
+    stage(r0);
     TN_MARK(0)
-#pragma unroll 2
-    for (int idx = tid; idx < (ROWS / 2) * ugroups; idx += 256) {
-#if TN2_COALESCED
-      const int cg = idx % ugroups, rp = idx / ugroups;
-#else
-      const int rp = idx % (ROWS / 2), cg = idx / (ROWS / 2);
-#endif
-      float a[8], b[8];
-      const float* lc = s_cu + cg * 8;
-      load_pro_lds<UMODE>(U, r0 + 2 * rp, (r0 + 2 * rp) < r_end, u0 + cg * 8, NU, lc, lc + 16 * UTT, lc + 32 * UTT, a);
-      load_pro_lds<UMODE>(U, r0 + 2 * rp + 1, (r0 + 2 * rp + 1) < r_end, u0 + cg * 8, NU, lc, lc + 16 * UTT, lc + 32 * UTT, b);
-      const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int e = (i + rot) & 7;
-        bf16x2 pk;
-        pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)b[e];
-        *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * RP + 2 * rp]) = pk;
-      }
-    }
+    issue(r0 + ROWS);   // the next slab flies during the MFMA phase (past the chunk: clamped rows, values never used)
     TN_MARK(1)
     __syncthreads();
     TN_MARK(2)
