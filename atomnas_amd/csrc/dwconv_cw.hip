@@ -130,10 +130,6 @@ __device__ __forceinline__ float cw_wave_sum63(float v) {
   v += cw_dpp<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
   return v;
 }
-// value of lane `l` (compile-time constant) as a wave-uniform scalar
-__device__ __forceinline__ float cw_bcast(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
 __device__ __forceinline__ unsigned cw_lds_addr(const void* p) {
   return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
 }

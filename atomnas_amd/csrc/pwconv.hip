@@ -213,9 +213,6 @@ __device__ __forceinline__ void nt_epilogue_core(const Epilogue& ep, const f32x4
           o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
           c[8 * h8 + i] = o8[i];  // statistics see the stored value
         }
-#ifdef NT_X_NOSTORE
-        if (o8[0] == 123.456f)
-#endif
         VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
       }
     }
@@ -1447,8 +1444,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
 #endif
 constexpr int XB_DP = 64 + 8;   // transposed LDS pitch (elements): rows of the block + pad; 144 bytes, 16-byte aligned rows
 
+#ifndef EB_MINWG
+#define EB_MINWG 2   // workgroups per CU the registers are allocated for (experiment switch)
+#endif
 template <int UT, int NCH>
-__global__ __launch_bounds__(256, 2) void k_expand_bwd(Operand A, const bf16_t* __restrict__ Wp, int ldw, int wrows, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const bf16_t* __restrict__ Wp, int ldw, int wrows, const bf16_t* __restrict__ x,
                                                     int ldx, Epilogue ep, float* __restrict__ ws, long M, int N, int K) {
   using T = bf16_t;
   using MM = Mma<T>;

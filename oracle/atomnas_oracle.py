@@ -8,7 +8,8 @@ The reference (meijieru/AtomNAS) is pure Python over PyTorch; its arithmetic liv
 state_dict, evaluated with torch CPU ops in fp32 (or fp64 when asked) -- citing the reference line each function follows.
 It is pinned against fixtures generated from the reference itself in this container (tools/make_golden.py ->
 tests/golden/*.pt, checked by tests/test_oracle_golden.py) and against the reference's own known-answer tests
-(tests/utils/prune_test.py, optim_test.py, rmsprop_test.py, models/compress_utils_test.py; see tests/test_reference_known_answers.py).
+(tests/utils/prune_test.py, optim_test.py, rmsprop_test.py, models/compress_utils_test.py: their vectors are restated in
+tests/test_oracle_golden.py and tests/test_host_logic.py).
 """
 import collections
 import math

@@ -1,6 +1,6 @@
 """Bring-up / per-kernel timing of the full-size supernet step (not a test; run on the GPU box)."""
-import sys, os, time, json, collections
-sys.path.insert(0, "/root/repo")
+import os, sys, time, json, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from atomnas_amd.models import mobilenet_supernet as ms, mobilenet_base as mb
 from atomnas_amd.utils import rmsprop, optim as aopt, prune as aprune, model_profiling as mp

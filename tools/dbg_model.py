@@ -1,5 +1,6 @@
 import sys, os, collections, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle"); sys.path.insert(0, "/root/repo/tests")
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "oracle")); sys.path.insert(0, os.path.join(_R, "tests"))
 import atomnas_oracle as orc
 from test_block_gpu import TINY, _randomize, _sd64
 from atomnas_amd.models import mobilenet_supernet as ms

@@ -4,7 +4,7 @@
 CASES can be narrowed with DWBENCH_CASES="56,144,3,1;56,144,7,1" (H,C,k,s).
 """
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from atomnas_amd import _lib
 args = sys.argv[1:]
 libpath = args.pop(0) if args and args[0].endswith(".so") else _lib.LIB_PATH

@@ -1,6 +1,6 @@
 """Which host-side op issues the burst of tiny device copies at the end of backward?  (torch.profiler over one eager step.)"""
-import sys, torch, collections
-sys.path.insert(0, "/root/repo")
+import os, sys, torch, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from torch.profiler import profile, ProfilerActivity
 model, ts, hp = bench.build("atomnas_c_supernet", torch.bfloat16, 32, 1995)[:3]
