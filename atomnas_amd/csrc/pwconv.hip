@@ -1236,6 +1236,15 @@ __global__ __launch_bounds__(256) void k_project_bwd_cs(Operand A, const bf16_t*
 // HBM.  Here a workgroup owns 64*RT rows, and the weights (64*NCG channels x 64 k) and coefficients of a k-chunk are
 // staged ONCE per workgroup into LDS (double-buffered, one barrier per chunk) and read back as ds_read_b128 fragments:
 // the only vector-memory traffic left in the k-loop is the activation stream itself, prefetched one chunk ahead.
+#ifndef WS_TIMING
+#define WS_TIMING 0   // s_memtime phase accounting of k_gemm_nt_ws (tools/wstiming.py, experiment builds only)
+#endif
+#if WS_TIMING
+__device__ unsigned long long g_ws_timing[8];
+#define WS_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); wacc[i] += t_ - wlast; wlast = t_; }
+#else
+#define WS_MARK(i)
+#endif
 constexpr int WS_KC = 64;            // k per chunk (two MFMA k-steps)
 constexpr int WS_WP = WS_KC + 8;     // LDS row pitch (elements): 16 consecutive rows -> 16 distinct 16-byte bank groups
 
@@ -1260,6 +1269,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & 15;
   const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
+#if WS_TIMING
+  unsigned long long wacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long wlast = __builtin_readcyclecounter();
+#endif
   if (do_stats) {
     for (int i = tid; i < 8 * WROWS; i += 256) s_stat[i] = 0.f;
   }
@@ -1323,6 +1336,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
   // chunk in flight per wave the kernel was latency-bound -- 2.3 TB/s on the 56x56 projection, 0.9 TB/s on the 7x7 one (54 chunks
   // of one round trip each), while the same kernel with two streams (the BatchNorm-backward prologue) reached 4.7 TB/s.
   // Rows past M and k past K read clamped addresses: their products meet zero weights / are dropped by the epilogue.
+  constexpr bool LANE_STATS = NCG == 1;
+  float ls1[16], ls2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ls1[i] = ls2[i] = 0.f;
   WsRaw<MODE> a1[RT][2], a2[RT][2];
   auto load_a = [&](long rb, int c, WsRaw<MODE> (&dst)[RT][2]) {
 #pragma unroll
@@ -1362,11 +1379,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
         for (int t = 0; t < 4; ++t) acc[s][g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int c = 0; c < nchunk; ++c) {
+      WS_MARK(0)   // loop top / epilogue of the previous block
       WsRaw<MODE> acur[RT][2];
 #pragma unroll
       for (int s = 0; s < RT; ++s)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { acur[s][ks] = a1[s][ks]; a1[s][ks] = a2[s][ks]; }
+#if WS_TIMING
+#pragma unroll
+      for (int s = 0; s < RT; ++s) { asm volatile("" : "+v"(acur[s][0].a)); asm volatile("" : "+v"(acur[s][1].a)); }
+      WS_MARK(1)   // wait for this chunk's activations
+#endif
       {   // weights of the next item, activations of the one after it
         stage_load(nc0, c + 1 < nchunk ? c + 1 : 0, wA, cA);
         int c2 = c + 2;
@@ -1411,8 +1434,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
             for (int s = 0; s < RT; ++s) acc[s][g][t] = MM::mma(wf, af[s], acc[s][g][t]);
           }
       }
+#if WS_TIMING
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[s][g][t]));
+      WS_MARK(2)   // issue of the next loads, prologue, fragment reads, MFMAs
+#endif
       stage_store(buf ^ 1, wA, cA);
+#if WS_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WS_MARK(3)   // wait for the staged weights, LDS store
+#endif
       __syncthreads();
+      WS_MARK(4)   // barrier
       buf ^= 1;
     }
 
@@ -1421,11 +1458,52 @@ __global__ __launch_bounds__(256) void k_gemm_nt_ws(Operand A, const bf16_t* __r
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
         if (nc0 + 64 * g >= N) continue;
-        nt_epilogue<T>(ep, acc[s][g], row[s], rowvalid[s], nc0 + 64 * g + 16 * q, N, do_stats, sw, WROWS, 64 * g + 16 * q, j);
+        if constexpr (LANE_STATS) {
+          // one chunk group (N <= 64): the statistics stay per lane across the row blocks and are reduced over the 16 rows of a
+          // tile once, after the loop -- the per-tile reduction (128 cross-lane operations) was 28 % of the wave's cycles on the
+          // 56x56 projection (tools/wstiming.py, r03)
+          float c[16], zv[16];
+          nt_epilogue_core<T>(ep, acc[s][g], row[s], rowvalid[s], nc0 + 16 * q, N, c, zv);
+          if (do_stats) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              ls1[i] += c[i];
+              ls2[i] += (ep.stat_mode == STAT_SQ) ? c[i] * c[i] : c[i] * zv[i];
+            }
+          }
+        } else {
+          nt_epilogue<T>(ep, acc[s][g], row[s], rowvalid[s], nc0 + 64 * g + 16 * q, N, do_stats, sw, WROWS, 64 * g + 16 * q, j);
+        }
       }
+    WS_MARK(5)   // epilogue
+  }
+  if constexpr (LANE_STATS) {
+    if (do_stats) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float a = ls1[i], b = ls2[i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        if (j == 0 && nc0 + 16 * q + i < N) {
+          sw[16 * q + i] += a;
+          sw[WROWS + 16 * q + i] += b;
+        }
+      }
+    }
   }
 
+  WS_MARK(5)   // epilogue of the last block
   if (do_stats) nt_flush_stats(ep, s_stat, WROWS, nc0, N, rs, R, tid);
+#if WS_TIMING
+  WS_MARK(6)
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_ws_timing[i], wacc[i]);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ fused expand backward
@@ -2347,6 +2425,14 @@ static int check_operand(const char* who, const Operand& o, int mode, int C) {
 
 }  // namespace atomnas
 
+#if WS_TIMING
+extern "C" int atomnas_debug_ws_timing(unsigned long long* out8, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(atomnas::g_ws_timing), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(atomnas::g_ws_timing), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 #if TN_TIMING
 extern "C" int atomnas_debug_tn_timing(unsigned long long* out8, int reset) {
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
