@@ -1884,42 +1884,69 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
   constexpr bool V2 = VMODE == PRO_BNBWD, U2 = UMODE == PRO_BNBWD;
   bf16x8 rva[NVU][2], rvx[V2 ? NVU : 1][2], rua[NUU][2], rux[U2 ? NUU : 1][2];
   const int K8V = (NV + 7) & ~7, K8U = (NU + 7) & ~7;
-  auto unit = [&](int idx, int groups, int& cg, int& rp) {
+  // work unit (row pair rp, 8-channel group cg) of a thread.  Slab-major operands: consecutive lanes take the two halves of a slab
+  // row and then the next row pair, so that a wave's two loads of a unit cover 2 KB of ONE slab contiguously (16 lines of 128 bytes)
+  // -- with the lanes along the rows of one channel group, every load instruction touched 32 lines for 1 KB of payload and the issue of
+  // a slab's loads was 42-51 % of the kernel's wave cycles (tools/tntiming.py, r03).  Plain operands: lanes along the rows.
+  auto unit = [&](int idx, int groups, bool slab, int& cg, int& rp) {
+    if (slab) {
+      const int u = idx >> 1;
+      rp = u % (ROWS / 2);
+      cg = (u / (ROWS / 2)) * 2 + (idx & 1);
+    } else {
 #if TN2_COALESCED
-    cg = idx % groups; rp = idx / groups;
+      cg = idx % groups; rp = idx / groups;
 #else
-    rp = idx % (ROWS / 2); cg = idx / (ROWS / 2);
+      rp = idx % (ROWS / 2); cg = idx / (ROWS / 2);
 #endif
+    }
   };
+  const bool vslab = V.ss1 != 0, uslab = U.ss1 != 0;
+  // per work unit, loop-invariant: the row pair, the byte-free element offset of (row 0, channel group) and the row multiplier of each
+  // stream.  Computed per load (layout branch, 64-bit products) the address arithmetic was ~20 instructions and two branches per
+  // load, 20 loads per slab.
+  int v_rp[NVU], u_rp[NUU];
+  long v_c1[NVU], v_c2[V2 ? NVU : 1], u_c1[NUU], u_c2[U2 ? NUU : 1];
+  const long v_m1 = V.ss1 ? 16 : V.ld1, v_m2 = V.ss2 ? 16 : V.ld2, u_m1 = U.ss1 ? 16 : U.ld1, u_m2 = U.ss2 ? 16 : U.ld2;
+#pragma unroll
+  for (int i = 0; i < NVU; ++i) {
+    int cg;
+    const int idx = tid + 256 * i;
+    unit(idx < (ROWS / 2) * (VW / 8) ? idx : 0, VW / 8, vslab, cg, v_rp[i]);
+    int k = v0 + cg * 8;
+    k = k < NV ? k : K8V - 8;
+    v_c1[i] = lay_off(0, k, V.ld1, V.ss1);
+    if constexpr (V2) v_c2[i] = lay_off(0, k, V.ld2, V.ss2);
+  }
+#pragma unroll
+  for (int i = 0; i < NUU; ++i) {
+    int cg;
+    const int idx = tid + 256 * i;
+    unit(idx < (ROWS / 2) * ugroups ? idx : 0, ugroups, uslab, cg, u_rp[i]);
+    int k = u0 + cg * 8;
+    k = k < NU ? k : K8U - 8;
+    u_c1[i] = lay_off(0, k, U.ld1, U.ss1);
+    if constexpr (U2) u_c2[i] = lay_off(0, k, U.ld2, U.ss2);
+  }
   auto issue = [&](long r0) {
 #pragma unroll
     for (int i = 0; i < NVU; ++i) {
-      int cg, rp;
-      const int idx = tid + 256 * i;
-      unit(idx < (ROWS / 2) * (VW / 8) ? idx : 0, VW / 8, cg, rp);
-      int k = v0 + cg * 8;
-      k = k < NV ? k : K8V - 8;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        long r = r0 + 2 * rp + h;
+        long r = r0 + 2 * v_rp[i] + h;
         r = r < M ? r : M - 1;
-        rva[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p1) + lay_off(r, k, V.ld1, V.ss1));
-        if constexpr (V2) rvx[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p2) + lay_off(r, k, V.ld2, V.ss2));
+        rva[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p1) + (r * v_m1 + v_c1[i]));
+        if constexpr (V2) rvx[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p2) + (r * v_m2 + v_c2[i]));
       }
     }
 #pragma unroll
     for (int i = 0; i < NUU; ++i) {
-      int cg, rp;
-      const int idx = tid + 256 * i;
-      unit(idx < (ROWS / 2) * ugroups ? idx : 0, ugroups, cg, rp);
-      int k = u0 + cg * 8;
-      k = k < NU ? k : K8U - 8;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        long r = r0 + 2 * rp + h;
+        long r = r0 + 2 * u_rp[i] + h;
         r = r < M ? r : M - 1;
-        rua[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p1) + lay_off(r, k, U.ld1, U.ss1));
-        if constexpr (U2) rux[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p2) + lay_off(r, k, U.ld2, U.ss2));
+        rua[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p1) + (r * u_m1 + u_c1[i]));
+        if constexpr (U2) rux[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p2) + (r * u_m2 + u_c2[i]));
       }
     }
   };
@@ -1953,7 +1980,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       int cg, rp;
       const int idx = tid + 256 * i;
       const bool active = idx < (ROWS / 2) * (VW / 8);
-      unit(active ? idx : 0, VW / 8, cg, rp);
+      unit(active ? idx : 0, VW / 8, vslab, cg, rp);
       float a[8], bb[8];
       const float* lc = s_cv + cg * 8;
       const bool kv = v0 + cg * 8 < NV;
@@ -1975,7 +2002,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       int cg, rp;
       const int idx = tid + 256 * i;
       const bool active = idx < (ROWS / 2) * ugroups;
-      unit(active ? idx : 0, ugroups, cg, rp);
+      unit(active ? idx : 0, ugroups, uslab, cg, rp);
       float a[8], bb[8];
       const float* lc = s_cu + cg * 8;
       const bool kv = u0 + cg * 8 < NU;
