@@ -385,8 +385,14 @@ def test_dwconv_slab_layout_is_bit_identical_to_plain(gpu_lib, k, stride, N, C, 
         torch.cuda.synchronize()
         res.append((y.to_plain()[:, :C] if slab else y[:, :C], h.to_plain()[:, :C] if slab else h[:, :C],
                     st.view(64, 2, -1).sum(0), dw, st2.view(64, 2, -1).sum(0)))
+    # stride 2: the slab-major backward of a supported shape runs the channel-pair kernel (csrc/dwconv_cw.hip, other FMA order), the
+    # plain one the tile kernel: the input gradient then agrees to rounding of the bf16 result, not bit for bit
+    cw_bwd = stride == 2 and _cw_supported(N, H, W, C, k, dtype, 1, stride=2)
     for i, (a, b) in enumerate(zip(*res)):
-        if i < 2:
+        if i == 1 and cw_bwd:
+            assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2 * float(b.float().abs().max()))
+            assert float((a != b).float().mean()) < 0.2
+        elif i < 2:
             assert torch.equal(a, b)
         else:
             assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max())), (i, float((a - b).abs().max()))
