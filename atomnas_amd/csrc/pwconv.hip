@@ -2315,7 +2315,9 @@ static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const O
                          float* ws, long ws_floats, hipStream_t st) {
   static const int wide_env = getenv("ATOMNAS_TN_WIDE") ? atoi(getenv("ATOMNAS_TN_WIDE")) : -1;
   if constexpr (UTT >= 4 && UTT <= 12) {
-    const int wide = wide_env >= 0 ? wide_env : ((UTT == 4 || UTT == 6) ? 1 : (UTT == 10 ? 2 : 0));
+    // r03, after the staging rewrite (same-call A/B over the step's shapes, ATOMNAS_TN_WIDE=0/1/2: 4.36 / 3.46 / 3.88 ms): 128-column V
+    // tiles on 64-row slabs win for every U width (r02 had 64-column tiles for 12 U tiles and 128-row slabs for 10)
+    const int wide = wide_env >= 0 ? wide_env : 1;
     if (wide == 1 && NV >= 256) return launch_tn2_cfg<UTT, 2, 64>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
     if (wide == 2 && NV >= 256) return launch_tn2_cfg<UTT, 2, 128>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
   }
