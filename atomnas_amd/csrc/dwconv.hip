@@ -844,6 +844,8 @@ static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap, long max_wor
   const long slots_xcd = (long)(num_cus() / 8) * per_cu;
   long want = aligned ? (slots_xcd / nslabs) * 8 : ((long)num_cus() * per_cu) / nslabs;
   if (want < 8) want = ((long)num_cus() * per_cu) / nslabs;   // more slabs than slots of an XCD: several rounds either way
+  static const int share = getenv("ATOMNAS_DW_SHARE") ? atoi(getenv("ATOMNAS_DW_SHARE")) : 1;   // experiment: one of `share` concurrent launches
+  if (share > 1) want = want / share > 0 ? want / share : 1;
   static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: force long tile walks
   if (max_env > 0 && want > max_env) want = max_env;
   if (max_workers > 0 && want > max_workers) want = max_workers;   // every worker owns one partial row (statistics, weight gradient)

@@ -1105,7 +1105,9 @@ static bool cw2_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
 static void cw_workers(CwGeom& g, int per_cu, int max_rows, int nw) {
   if (per_cu < 1) per_cu = 1;
   const int units = g.nslabs * (nw == 4 ? 2 : 1);   // workgroups per worker
-  long want = ((long)num_cus() * per_cu) / units;
+  // experiment switch: this launch is one of `share` concurrent ones (the branches of a block on separate streams): 1 / share of the slots
+  static const int share = getenv("ATOMNAS_DW_SHARE") ? atoi(getenv("ATOMNAS_DW_SHARE")) : 1;
+  long want = ((long)num_cus() * per_cu) / units / (share > 1 ? share : 1);
   static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: long tile walks
   if (max_env > 0 && want > max_env) want = max_env;
   if (max_rows > 0 && want > max_rows) want = max_rows;   // every worker owns one partial row

@@ -8,6 +8,7 @@ Parameter gradients are written straight into the gradient arena (p.grad views) 
 Reference call sites: InvertedResidualChannels.forward (models/mobilenet_base.py:371-382), ConvBNReLU (:120-142),
 MobileNetV2.forward (models/mobilenet_supernet.py:169-173), CrossEntropyLabelSmooth.forward (utils/optim.py:199-207).
 """
+import contextlib
 import os
 
 import torch
@@ -166,6 +167,34 @@ class _Side:
         return False
 
 
+# experiment switch: the (independent) depthwise launches of a block's branches on separate streams, each sized for 1 / n of the
+# machine (ATOMNAS_DW_SHARE in the library): the VALU-bound k = 7 instance next to the bandwidth-bound k = 3 / 5 ones
+_DW_STREAMS = int(os.environ.get("ATOMNAS_DW_STREAMS", "1"))
+_dw_streams = []
+
+
+class _Branches:
+    """runs the body of `with b.on(i):` for branch i on stream i % n (forked from the current stream), join() waits for all"""
+    def __init__(self, nb):
+        self.n = min(_DW_STREAMS, nb) if nb > 1 else 1
+        if self.n > 1:
+            while len(_dw_streams) < self.n - 1:
+                _dw_streams.append(torch.cuda.Stream())
+            self.cur = torch.cuda.current_stream()
+            for st in _dw_streams[:self.n - 1]:
+                st.wait_stream(self.cur)
+
+    def on(self, i):
+        if self.n <= 1 or i % self.n == 0:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(_dw_streams[i % self.n - 1])
+
+    def join(self):
+        if self.n > 1:
+            for st in _dw_streams[:self.n - 1]:
+                self.cur.wait_stream(st)
+
+
 def _join_side():
     if _SIDE_WGRAD and _side_stream[0] is not None:
         torch.cuda.current_stream().wait_stream(_side_stream[0])
@@ -212,11 +241,14 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     bsd = bn_uses_batch_stats(pl.bnd)
     D = _hidden(pl, M2, HT, T, dev)
     stD = _stats(HT, dev, pl.bnd["mgr"]) if bsd else None
+    br = _Branches(pl.nb)
     for i in range(pl.nb):
         o, c = pl.seg[i], pl.segpad(pl.hid[i])
         xin = _seg(E, o) if pl.expand else E
-        ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], _seg(D, o),
-                       stD.at(o) if bsd else None, HT, N, H, W, c, pl.ks[i], s, stat_rows=stD.rows if bsd else None)
+        with br.on(i):
+            ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], _seg(D, o),
+                           stD.at(o) if bsd else None, HT, N, H, W, c, pl.ks[i], s, stat_rows=stD.rows if bsd else None)
+    br.join()
     bD = bn_forward_coeffs(pl.bnd, stD, M2, dev)
     bsp = bn_uses_batch_stats(pl.bnp)
     Pr = torch.empty(M2, pl.oup, dtype=T, device=dev)
@@ -321,16 +353,19 @@ def block_backward(pl, sv, G):
     else:
         h = ops.zeros(M, pl.inp, dtype=T, device=dev) if pl.nb > 1 else torch.empty(M, pl.inp, dtype=T, device=dev)
         st2E = None
+    br = _Branches(pl.nb if pl.expand else 1)
     for i in range(pl.nb):
         o, c = pl.seg[i], pl.segpad(pl.hid[i])
         if pl.expand:
-            ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], _seg(E, o), bE.scale[o:], bE.shift[o:], act, pl.taps[i],
-                           _seg(h, o), pl.Wd_grad[i], st2E.at(o), HT, N, H, W, c, pl.ks[i], s, stat_rows=st2E.rows)
+            with br.on(i):
+                ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], _seg(E, o), bE.scale[o:], bE.shift[o:], act, pl.taps[i],
+                               _seg(h, o), pl.Wd_grad[i], st2E.at(o), HT, N, H, W, c, pl.ks[i], s, stat_rows=st2E.rows)
         else:
             if pl.nb > 1:
                 raise NotImplementedError("non-expanding block with more than one branch")
             ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], E, None, None, 0, pl.taps[i], h, pl.Wd_grad[i], None, 0, N, H,
                            W, c, pl.ks[i], s)
+    br.join()
     if not pl.expand:
         _join_side()
         if pl.res:
