@@ -2083,6 +2083,8 @@ static int nt_st_kind(int mode, const Operand& A, const Epilogue& ep, long M, in
   if (!on || mode != PRO_NONE || (K & 7) || ep.bias || ep.add || ep.out_f32) return 0;
   const bool stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
   if (ep.stats != nullptr && ep.stat_mode == STAT_NONE) return 0;
+  // a row range is at most 4096 tiles (32-bit tile offsets) and owns one partial row of the statistics
+  if (stats && ((M + 15) / 16 + ep.stat_rows - 1) / ep.stat_rows > 4096) return 0;
   // 32-bit byte offsets below 2^31 inside the per-wave resources: the whole A tensor, four slabs (one chunk) of C and z
   const long a_bytes = A.ss1 ? ((long)((K + 15) / 16 - 1) * A.ss1 + M * 16) * 2 : M * (long)A.ld1 * 2;
   if (a_bytes >= (1L << 31)) return 0;
