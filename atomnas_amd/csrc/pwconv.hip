@@ -698,6 +698,9 @@ enum { ST_FWD = 1, ST_MASK = 2, ST_PBWD = 3 };
 #ifndef ST_BT3
 #define ST_BT3 4
 #endif
+#ifndef ST_BT6
+#define ST_BT6 0   // six k-steps (K = 192): one tile is already a 6 KB request, per-tile ring
+#endif
 #ifndef ST_PB_BT1
 #define ST_PB_BT1 4
 #endif
@@ -715,7 +718,7 @@ enum { ST_FWD = 1, ST_MASK = 2, ST_PBWD = 3 };
 #endif
 template <int KSTEPS, int EPK> struct StCfg {
   static constexpr int BT = EPK == ST_PBWD ? (KSTEPS == 1 ? ST_PB_BT1 : ST_PB_BT2)   // registers: + the weight-gradient accumulators
-                                            : KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : 0;
+                                            : KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : ST_BT6;
   static constexpr int PD = BT > 0 ? (BT >= 2 ? 2 : 1) : 2;
   static constexpr int WPE = EPK != ST_FWD ? 1 : KSTEPS == 1 ? ST_WPE1 : KSTEPS == 2 ? ST_WPE2 : KSTEPS == 3 ? ST_WPE3 : 1;
 };
