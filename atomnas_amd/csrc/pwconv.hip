@@ -698,6 +698,9 @@ enum { ST_FWD = 1, ST_MASK = 2, ST_PBWD = 3 };
 #ifndef ST_BT3
 #define ST_BT3 4
 #endif
+#ifndef ST_SHARED
+#define ST_SHARED 1
+#endif
 #ifndef ST_BT6
 #define ST_BT6 0   // six k-steps (K = 192): one tile is already a 6 KB request, per-tile ring
 #endif
@@ -721,6 +724,7 @@ template <int KSTEPS, int EPK> struct StCfg {
                                             : KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : ST_BT6;
   static constexpr int PD = BT > 0 ? (BT >= 2 ? 2 : 1) : 2;
   static constexpr int WPE = EPK != ST_FWD ? 1 : KSTEPS == 1 ? ST_WPE1 : KSTEPS == 2 ? ST_WPE2 : KSTEPS == 3 ? ST_WPE3 : 1;
+  static constexpr bool SH = ST_SHARED && BT > 0 && BT % 4 == 0 && EPK != ST_PBWD;   // bursts shared by the workgroup's four waves
 };
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr unsigned ST_OOB = 0x80000000u;   // >= num_records of every resource below
@@ -730,7 +734,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* p) {
 }
 __device__ __forceinline__ bf16x8 st_as_bf16(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int KSTEPS, int EPK, int PD, int BT, int WPE, int UT>
+template <int KSTEPS, int EPK, int PD, int BT, int WPE, int UT, bool SH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_gemm_nt_st(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K,
                                                     int nchunks, int tiles_per_item, float* __restrict__ ws) {
   using MM = Mma<bf16_t>;
@@ -740,15 +744,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   const int q = lane >> 4, j = lane & 15;
   const int wrow = 16 * (j >> 2) + (j & 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long item = (long)blockIdx.x * 4 + wave;
   const long mtiles = (M + 15) / 16;
   const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
-  if (item >= nranges * nchunks) return;
-  const int chunk = (int)(item % nchunks);
-  const long range = item / nchunks;
+  int chunk;
+  long range;
+  bool wave_valid = true;
+  if constexpr (SH) {
+    // shared bursts: a workgroup is one row range x four consecutive chunks (grid = ranges x chunk groups); a wave past the last
+    // chunk repeats it with its stores and statistics switched off -- it still loads its share of the bursts and meets the barriers
+    const int ngroups = (nchunks + 3) / 4;
+    range = blockIdx.x / ngroups;
+    const int cr = (int)(blockIdx.x % ngroups) * 4 + wave;
+    wave_valid = cr < nchunks;
+    chunk = wave_valid ? cr : nchunks - 1;
+  } else {
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= nranges * nchunks) return;
+    chunk = (int)(item % nchunks);
+    range = item / nchunks;
+  }
   const int nc = chunk * 64;
   const int nb = nc + 16 * q;
-  const bool do_stats = ep.stats != nullptr;
+  const bool do_stats = ep.stats != nullptr && wave_valid;
+  constexpr int STAGE_U4 = (SH ? 2 : 4) * BT * KSTEPS * 64;   // burst staging in 16-byte units: two shared halves, or one slot per wave
 
   typename MM::frag wf[KSTEPS][4];
 #pragma unroll
@@ -781,12 +799,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const long e = ep.css ? (long)q * ep.css + j * 16 + 8 * h : (long)j * ep.ldc + 16 * q + 8 * h;
-    c_lane[h] = nb + 8 * h < nalloc ? (unsigned)(2 * e) : ST_OOB;
+    c_lane[h] = (nb + 8 * h < nalloc && wave_valid) ? (unsigned)(2 * e) : ST_OOB;
   }
   __amdgpu_buffer_rsrc_t rz = rc;
   unsigned z_tile = 0;
   // per-channel scale / shift of z: in a wave-private LDS slot (read back per tile), not in 32 registers
-  float* s_zc = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(st_stage + 4 * BT * KSTEPS * 64) + 4 * (16 * (UT > 0 ? UT : 1) + 64) * PB_RP) + wave * 128;
+  float* s_zc = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(st_stage + STAGE_U4) + 4 * (16 * (UT > 0 ? UT : 1) + 64) * PB_RP) + wave * 128;
   if constexpr (MASKED) {
     const bf16_t* zp = reinterpret_cast<const bf16_t*>(ep.z) + (ep.zss ? (long)(nc >> 4) * ep.zss + row0 * 16 : row0 * ep.ldz + nc);
     rz = st_rsrc(zp);
@@ -809,9 +827,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   }
   const Act am = act_of(ep.mask);
 
-  float s1[16], s2[16];
+  f32x2 s1[8], s2[8];   // per-lane statistics of channels nb + 2 i, nb + 2 i + 1 (pairs: v_pk_add_f32 / v_pk_fma_f32)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = f32x2{0.f, 0.f};
   // ST_PBWD: the weight gradient dWp[o][n] += sum_m A[m][o] * act(bn(z))[m][n] of the wave's 64 channels, as in k_project_bwd_cs
   // (both operands transposed through a wave-private LDS region, 16x16x16 MFMAs over the tile's 16 rows)
   constexpr int UTA = UT > 0 ? UT : 1;
@@ -820,7 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   for (int t = 0; t < UTA; ++t)
 #pragma unroll
     for (int u = 0; u < 4; ++u) racc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16_t* s_p = reinterpret_cast<bf16_t*>(st_stage + 4 * BT * KSTEPS * 64) + wave * (16 * UTA + 64) * PB_RP;   // [16*UT][PB_RP] A^T
+  bf16_t* s_p = reinterpret_cast<bf16_t*>(st_stage + STAGE_U4) + wave * (16 * UTA + 64) * PB_RP;   // [16*UT][PB_RP] A^T
   bf16_t* s_a = s_p + 16 * UTA * PB_RP;                                                                         // [64][PB_RP] act(bn(z))^T
 
   // ---- epilogue of one tile: accumulators -> (mask) -> bf16 -> store, statistics of the stored values
@@ -897,13 +915,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       // wrong elements in test_gemm_nt[20000-1440-80]).  The asm below uses `ob` after the statistics: its registers stay intact.
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rc, rv ? c_lane[h] : ST_OOB, (unsigned)t * c_tile, 0);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float o = (float)ob[i];   // statistics see the stored value
-        s1[8 * h + i] += o;
-        s2[8 * h + i] += EPK == ST_FWD ? o * o : o * zv[8 * h + i];
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 o = f32x2{(float)ob[2 * i], (float)ob[2 * i + 1]};   // statistics see the stored value
+        s1[4 * h + i] += o;
+        s2[4 * h + i] += EPK == ST_FWD ? o * o : o * f32x2{zv[8 * h + 2 * i], zv[8 * h + 2 * i + 1]};
         // the accumulation happens HERE: left to itself, instruction selection collects the statistics updates of all unrolled tiles at
         // the end of the loop body, with the 16 stored values of every tile live until then (about 20 registers per unrolled tile)
-        asm volatile("" : "+v"(s1[8 * h + i]), "+v"(s2[8 * h + i]));
+        asm volatile("" : "+v"(s1[4 * h + i]), "+v"(s2[4 * h + i]));
       }
       asm volatile("" ::"v"(__builtin_bit_cast(u32x4, ob)));
     }
@@ -923,7 +941,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   // sched_barrier: instruction selection orders pure operations (the MFMAs) by data dependence only and had hoisted all unrolled
   // tiles' MFMAs to the top of the body (one set of accumulators and temporaries per tile).
   u32x4 zn[PD][2];
-  if constexpr (BT > 0) {
+  if constexpr (BT > 0 && SH) {
+    // (a') bursts SHARED by the workgroup's four waves (same row range, four chunks): the operand is read from L2 / HBM once per
+    // workgroup instead of once per wave, in bursts of BT tiles of which every wave fetches a quarter (tiles wave, wave + 4, ...).
+    // Two LDS halves: while the waves compute from one, the landed quarter-bursts are parked in the other and the next burst is
+    // issued; one LDS-only barrier per BT tiles (s_barrier behind lgkmcnt(0): a __syncthreads() would also wait for every store).
+    static_assert(BT % 4 == 0, "shared bursts: every wave fetches BT / 4 tiles");
+    constexpr int NP = BT * KSTEPS;
+    u32x4* sh = st_stage + lane;
+    u32x4 ld[BT / 4][KSTEPS];
+    auto burst = [&](int tb) {
+#pragma unroll
+      for (int iu = 0; iu < BT / 4; ++iu)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) ld[iu][ks] = load_a(tb + wave + 4 * iu, ks);
+    };
+    auto park = [&](int half) {
+#pragma unroll
+      for (int iu = 0; iu < BT / 4; ++iu)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          asm volatile("" : "+v"(ld[iu][ks]));
+          sh[(half * NP + (wave + 4 * iu) * KSTEPS + ks) * 64] = ld[iu][ks];
+        }
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    burst(0);
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) { zn[u][0] = load_z(u, 0); zn[u][1] = load_z(u, 1); }
+#pragma unroll
+      for (int u = 0; u < PD; ++u) { asm volatile("" : "+v"(zn[u][0])); asm volatile("" : "+v"(zn[u][1])); }
+    }
+    park(0);
+    burst(BT);
+    lds_barrier();
+    int half = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += BT) {
+#pragma unroll
+      for (int u = 0; u < BT; ++u) {
+        int t = t0 + u;
+        asm volatile("" : "+s"(t));
+        u32x4 ac[KSTEPS], zc[2];
+        unsigned eo = (unsigned)((half * NP + u * KSTEPS) * 64);
+        asm volatile("" : "+v"(eo));
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          ac[ks] = sh[eo + ks * 64];
+          asm volatile("" : "+v"(ac[ks]));
+        }
+        if constexpr (MASKED) {
+          asm volatile("" : "+v"(zn[u % PD][0]));
+          zc[0] = zn[u % PD][0]; zc[1] = zn[u % PD][1];
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const bf16x8 af = st_as_bf16(ac[ks]);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] = MM::mma(wf[ks][v], af, acc[v]);
+        }
+        finish(t, acc, zc, ac);
+        if constexpr (MASKED) { zn[u % PD][0] = load_z(t + PD, 0); zn[u % PD][1] = load_z(t + PD, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      int tb = t0 + 2 * BT;
+      asm volatile("" : "+s"(tb));
+      park(half ^ 1);      // the burst issued one period ago; that half was last read before the previous barrier
+      burst(tb);
+      lds_barrier();
+      half ^= 1;
+    }
+  } else if constexpr (BT > 0) {
     // (a) bursts through LDS.  HBM reads trickling into a saturated write stream are what this kernel pays for (r03 knock-outs on
     // the 56x56 expand, 694 MB out / 38 MB in: 215 us; narrow operand from an L2-resident window 157 us; one request burst per
     // 4 / 8 tiles 198 / 171 us): the operand is fetched BT tiles (several KB, contiguous) at a time.  The burst lands in registers,
@@ -1042,7 +1133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   if (do_stats) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float a = s1[i], b = s2[i];
+      float a = s1[i >> 1][i & 1], b = s2[i >> 1][i & 1];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) {
         a += __shfl_xor(a, o, 64);
@@ -1056,7 +1147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       }
     }
   }
-  if constexpr (EPK == ST_PBWD) {
+  if (EPK == ST_PBWD && wave_valid) {
     // partial of the weight gradient: (o, n) at ws[(range * K + o) * N + n], summed in range order by reduce_parts
 #pragma unroll
     for (int t = 0; t < UTA; ++t)
@@ -2104,22 +2195,33 @@ static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, co
   const long mtiles = (M + 15) / 16;
   const bf16_t* W = (const bf16_t*)Wp;
   const long min_tpi = ep.stats ? (mtiles + ep.stat_rows - 1) / ep.stat_rows : 1;   // every row range owns one partial row
-#define ST_CASE(EPKV)                                                                                                   \
+#define ST_LAUNCH(EPKV, SHV)                                                                                            \
   {                                                                                                                     \
     using Cfg = StCfg<KSTEPS, EPKV>;                                                                                    \
-    auto kern = k_gemm_nt_st<KSTEPS, EPKV, Cfg::PD, Cfg::BT, Cfg::WPE, 0>;                                               \
-    const size_t lds = (size_t)4 * Cfg::BT * KSTEPS * 1024 + (EPKV == ST_FWD ? 0 : (size_t)4 * (16 + 64) * PB_RP * sizeof(bf16_t) + 4 * 128 * sizeof(float)); /* burst staging (+ z coefficients) */ \
+    auto kern = k_gemm_nt_st<KSTEPS, EPKV, Cfg::PD, Cfg::BT, Cfg::WPE, 0, SHV>;                                         \
+    const size_t lds = (size_t)(SHV ? 2 : 4) * Cfg::BT * KSTEPS * 1024 + (EPKV == ST_FWD ? 0 : (size_t)4 * (16 + 64) * PB_RP * sizeof(bf16_t) + 4 * 128 * sizeof(float)); /* burst staging (+ z coefficients) */ \
     const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;                                           \
-    long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;                                                       \
+    const long wchunks = SHV ? (long)((nchunks + 3) / 4) * 4 : nchunks;   /* wave slots per row range */                \
+    long tiles_per_item = (mtiles * wchunks + waves - 1) / waves;                                                       \
     if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
     if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;                                                             \
-    const long max_ranges = waves / nchunks > 0 ? waves / nchunks : 1;   /* one round of workgroups, as for k_gemm_nt_cs */ \
+    const long max_ranges = waves / wchunks > 0 ? waves / wchunks : 1;   /* one round of workgroups, as for k_gemm_nt_cs */ \
     if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges; \
     if (tiles_per_item > 4096) tiles_per_item = 4096;   /* keeps t * tile bytes in 32 bits (nt_st_kind) */              \
-    const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;                                      \
-    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item, (float*)nullptr); \
+    const long nrg = (mtiles + tiles_per_item - 1) / tiles_per_item;                                                    \
+    const long blocks = SHV ? nrg * ((nchunks + 3) / 4) : (nrg * nchunks + 3) / 4;                                      \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item, (float*)nullptr); \
+  }
+  // Bursts shared by the four waves of a workgroup (one read of the narrow operand per workgroup instead of per wave) where whole
+  // groups of four chunks waste at most 5 % of the wave slots: 14x14 (23 / 27 chunks) -10..-18 %, 28x28 (12) equal; with 5 or 7 chunks
+  // the repeated chunk costs more than the sharing saves (112x112 +38 %, 56x56 masked form +15 %; r03, tools/pwbench.py).
+#define ST_CASE(EPKV)                                                                                                   \
+  {                                                                                                                     \
+    const bool shared = StCfg<KSTEPS, EPKV>::SH && ((nchunks + 3) / 4 * 4 - nchunks) * 20 <= nchunks;                   \
+    if (shared) ST_LAUNCH(EPKV, (StCfg<KSTEPS, EPKV>::SH)) else ST_LAUNCH(EPKV, false)                                  \
   }
   if (kind == ST_FWD) ST_CASE(ST_FWD) else ST_CASE(ST_MASK)
+#undef ST_LAUNCH
 #undef ST_CASE
 }
 
@@ -2379,7 +2481,7 @@ static int launch_project_bwd_st(const Operand& A, const bf16_t* W, int ldw, con
   using Cfg = StCfg<KSTEPS, ST_PBWD>;
   const int nchunks = (N + 63) / 64;
   const long mtiles = (M + 15) / 16;
-  auto kern = k_gemm_nt_st<KSTEPS, ST_PBWD, Cfg::PD, Cfg::BT, Cfg::WPE, UT>;
+  auto kern = k_gemm_nt_st<KSTEPS, ST_PBWD, Cfg::PD, Cfg::BT, Cfg::WPE, UT, false>;
   const size_t lds = (size_t)4 * Cfg::BT * KSTEPS * 1024 + (size_t)4 * (16 * UT + 64) * PB_RP * sizeof(bf16_t) + 4 * 128 * sizeof(float);
   const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;
   long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;
