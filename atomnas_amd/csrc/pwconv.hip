@@ -702,7 +702,7 @@ enum { ST_FWD = 1, ST_MASK = 2, ST_PBWD = 3 };
 #define ST_SHARED 1
 #endif
 #ifndef ST_BT6
-#define ST_BT6 0   // six k-steps (K = 192): one tile is already a 6 KB request, per-tile ring
+#define ST_BT6 4   // six k-steps (K = 192): bursts only in the shared form (one tile is already a 6 KB request: per-tile ring otherwise)
 #endif
 #ifndef ST_PB_BT1
 #define ST_PB_BT1 4
@@ -725,6 +725,7 @@ template <int KSTEPS, int EPK> struct StCfg {
   static constexpr int PD = BT > 0 ? (BT >= 2 ? 2 : 1) : 2;
   static constexpr int WPE = EPK != ST_FWD ? 1 : KSTEPS == 1 ? ST_WPE1 : KSTEPS == 2 ? ST_WPE2 : KSTEPS == 3 ? ST_WPE3 : 1;
   static constexpr bool SH = ST_SHARED && BT > 0 && BT % 4 == 0 && EPK != ST_PBWD;   // bursts shared by the workgroup's four waves
+  static constexpr int BTP = KSTEPS <= 3 ? BT : 0;   // burst tiles of the private (per-wave) form
 };
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr unsigned ST_OOB = 0x80000000u;   // >= num_records of every resource below
@@ -2195,11 +2196,11 @@ static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, co
   const long mtiles = (M + 15) / 16;
   const bf16_t* W = (const bf16_t*)Wp;
   const long min_tpi = ep.stats ? (mtiles + ep.stat_rows - 1) / ep.stat_rows : 1;   // every row range owns one partial row
-#define ST_LAUNCH(EPKV, SHV)                                                                                            \
+#define ST_LAUNCH(EPKV, SHV, BTV)                                                                                         \
   {                                                                                                                     \
     using Cfg = StCfg<KSTEPS, EPKV>;                                                                                    \
-    auto kern = k_gemm_nt_st<KSTEPS, EPKV, Cfg::PD, Cfg::BT, Cfg::WPE, 0, SHV>;                                         \
-    const size_t lds = (size_t)(SHV ? 2 : 4) * Cfg::BT * KSTEPS * 1024 + (EPKV == ST_FWD ? 0 : (size_t)4 * (16 + 64) * PB_RP * sizeof(bf16_t) + 4 * 128 * sizeof(float)); /* burst staging (+ z coefficients) */ \
+    auto kern = k_gemm_nt_st<KSTEPS, EPKV, Cfg::PD, BTV, Cfg::WPE, 0, SHV>;                                            \
+    const size_t lds = (size_t)(SHV ? 2 : 4) * (BTV) * KSTEPS * 1024 + (EPKV == ST_FWD ? 0 : (size_t)4 * (16 + 64) * PB_RP * sizeof(bf16_t) + 4 * 128 * sizeof(float)); /* burst staging (+ z coefficients) */ \
     const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;                                           \
     const long wchunks = SHV ? (long)((nchunks + 3) / 4) * 4 : nchunks;   /* wave slots per row range */                \
     long tiles_per_item = (mtiles * wchunks + waves - 1) / waves;                                                       \
@@ -2218,7 +2219,8 @@ static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, co
 #define ST_CASE(EPKV)                                                                                                   \
   {                                                                                                                     \
     const bool shared = StCfg<KSTEPS, EPKV>::SH && ((nchunks + 3) / 4 * 4 - nchunks) * 20 <= nchunks;                   \
-    if (shared) ST_LAUNCH(EPKV, (StCfg<KSTEPS, EPKV>::SH)) else ST_LAUNCH(EPKV, false)                                  \
+    if (shared) ST_LAUNCH(EPKV, (StCfg<KSTEPS, EPKV>::SH), (StCfg<KSTEPS, EPKV>::BT))                                   \
+    else ST_LAUNCH(EPKV, false, (StCfg<KSTEPS, EPKV>::BTP))                                                            \
   }
   if (kind == ST_FWD) ST_CASE(ST_FWD) else ST_CASE(ST_MASK)
 #undef ST_LAUNCH
