@@ -266,3 +266,14 @@ def test_ctypes_signatures_match_the_header_prototypes():
         want = [] if decl in ("", "void") else [kind_of(a) for a in decl.split(",")]
         got = [kinds[a] for a in args]
         assert got == want, (name, got, want)
+
+
+def test_tools_and_entry_points_compile():
+    """the experiment harnesses under tools/ and the repo-root entry points are importable Python (they run on the GPU box only)"""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, f) for f in ("bench.py", "train.py", "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        py_compile.compile(f, doraise=True)
