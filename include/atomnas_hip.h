@@ -122,8 +122,10 @@ int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde
                        float* dwe, float* ws, long ws_floats, long M, int inp, int hid, int dtype, void* stream);
 
 /* Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) in ONE pass over the raw depthwise
- *   output z (bf16 storage; shapes per atomnas_project_bwd_supported: oup <= 48, the early stages):
+ *   output z (bf16 storage; shapes per atomnas_project_bwd_supported: oup <= 96; the Python layer uses it up to 48, the early stages):
  *     dP = c1*g + c2*p + c3                                      (BatchNorm backward of the block-output BN; g, p: [M, oup])
+ *       or, ABI 3: p = c1 = c2 = c3 = NULL and g IS dP (atomnas_bnbwd_apply's output; oup a multiple of 8 and <= 64, hidden tensors
+ *       slab-major or plain with hid % 8 == 0): the prologue-free streaming kernel
  *     gh[M, hid] = act'(z*zscale + zshift) * (dP * Wp),  statistics rows [sum gh, sum gh*z]
  *     dwp[o*si + n*sj] += sum_m dP[m][o] * act(z*zscale + zshift)[m][n]
  *   wpt = Wp^T packed by atomnas_pack_weights ([hid padded to 64][ldw >= oup rounded up to 32]); ws: per-row-range partials of the
