@@ -15,31 +15,82 @@ namespace atomnas {
 
 __device__ __forceinline__ float sigmoidf_(float a) { return 1.f / (1.f + __expf(-a)); }
 
-// pooled[n][c] = mean_hw act(D*scale+shift); one thread per (n, 8 channels)
-template <typename T>
-__global__ __launch_bounds__(256) void k_se_squeeze(const T* __restrict__ d, int ldd, long dss, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, int act, float* __restrict__ pooled, int ldp,
-                                                    int N, int HW, int C) {
-  const int cg = (C + 7) / 8;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * cg) return;
-  const int n = i / cg, c0 = (i % cg) * 8;
-  float s[8], h[8], acc[8];
-  VecIO<float, 8>::load(scale + c0, s);
-  VecIO<float, 8>::load(shift + c0, h);
+// Per-image channel reductions over the pixels of one image (the squeeze and the gate gradient):
+//   DG = false: out[n][c] = mean_hw act(D*scale+shift)                       (SqueezeAndExcitation.forward, mobilenet_base.py:110)
+//   DG = true : out[n][c] = sum_hw dS[m][c] * act(D[m][c]*scale+shift)       (its backward through the gating product, :112)
+// A workgroup owns one image and CGB groups of 8 channels; its 256 threads are CGB channel groups x PL = 256 / CGB pixel lanes,
+// ordered (slab half, pixel lane, slab) so that on slab-major tensors a wave reads runs of PL x 32 contiguous bytes.  Every thread
+// walks the pixels p = pl, pl + PL, ... with four independent 16-byte loads in flight; the PL partial sums of a channel are added in
+// lane order by one thread (fixed order, no atomics).  Round 3 had one thread per (image, 8 channels) walking all HW pixels
+// serially: 768 threads for the 48-channel 112 x 112 layer of AtomNAS-C+, 0.9 ms per launch.
+template <typename T, bool DG>
+__global__ __launch_bounds__(256) void k_se_pool(const T* __restrict__ d, int ldd, long dss, const T* __restrict__ ds, int ldds, long dsss,
+                                                 const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                 float* __restrict__ out, int ldo, int HW, int C, int cgb) {
+  __shared__ float s_red[256 * 8];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int PL = 256 / cgb;
+  int cgl, pl;
+  if (cgb >= 2) { cgl = (tid & 1) + 2 * (tid / (2 * PL)); pl = (tid >> 1) % PL; } else { cgl = 0; pl = tid; }
+  const int cg = blockIdx.y * cgb + cgl;
+  const int c0 = cg * 8;
+  const int ncg = (C + 7) / 8;
+  float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  const Act m = act_of(act);
-  for (int p = 0; p < HW; ++p) {
-    float v[8];
-    VecIO<T, 8>::load(d + lay_off((long)n * HW + p, c0, ldd, dss), v);
+  if (cg < ncg) {
+    float s[8], h[8];
+    VecIO<float, 8>::load(scale + c0, s);
+    VecIO<float, 8>::load(shift + c0, h);
+    const Act m = act_of(act);
+    const long row0 = (long)n * HW;
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      float v[4][8], g[4][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += act_apply(v[e] * s[e] + h[e], m);
+      for (int u = 0; u < 4; ++u) {
+        VecIO<T, 8>::load(d + lay_off(row0 + p + u * PL, c0, ldd, dss), v[u]);
+        if (DG) VecIO<T, 8>::load(ds + lay_off(row0 + p + u * PL, c0, ldds, dsss), g[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = act_apply(v[u][e] * s[e] + h[e], m);
+          acc[e] += DG ? g[u][e] * a : a;
+        }
+    }
+    for (; p < HW; p += PL) {
+      float v[8], g[8];
+      VecIO<T, 8>::load(d + lay_off(row0 + p, c0, ldd, dss), v);
+      if (DG) VecIO<T, 8>::load(ds + lay_off(row0 + p, c0, ldds, dsss), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = act_apply(v[e] * s[e] + h[e], m);
+        acc[e] += DG ? g[e] * a : a;
+      }
+    }
   }
-  const float inv = 1.0f / (float)HW;
+  // s_red[pl][cgl * 8 + e]
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = (c0 + e < C) ? acc[e] * inv : 0.f;
-  VecIO<float, 8>::store(pooled + (long)n * ldp + c0, acc);
+  for (int e = 0; e < 8; ++e) s_red[pl * (cgb * 8) + cgl * 8 + e] = acc[e];
+  __syncthreads();
+  if (tid < cgb * 8) {
+    const int c = blockIdx.y * cgb * 8 + tid;
+    if (c < ncg * 8) {
+      float a = 0.f;
+      for (int q = 0; q < PL; ++q) a += s_red[q * (cgb * 8) + tid];
+      if (!DG) a *= 1.0f / (float)HW;
+      out[(long)n * ldo + c] = (c < C) ? a : 0.f;
+    }
+  }
+}
+
+static int se_pool_cgb(int C) {
+  const int ncg = (C + 7) / 8;
+  int cgb = 2;
+  while (cgb < ncg && cgb < 32) cgb *= 2;
+  return cgb;
 }
 
 // one workgroup per image: hpre[n][j] = b1[j] + sum_c W1[j][cmap c] * pooled[n][c];  gate[n][c] = sigmoid(b2 + sum_j W2[cmap c][j] * act(hpre))
@@ -51,14 +102,19 @@ __global__ __launch_bounds__(256) void k_se_mlp_fwd(const float* __restrict__ po
   const int n = blockIdx.x;
   const Act m = act_of(act);
   const float* pn = pooled + (long)n * ldp;
-  for (int j = threadIdx.x; j < hid; j += 256) {
-    float a = b1[j];
-    for (int c = 0; c < HT; ++c) {
+  // one wave per hidden unit, the lanes over the channels (rows of W1 are contiguous over the channels: coalesced), butterfly sum
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < hid; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < HT; c += 64) {
       const int cc = cmap[c];
       if (cc >= 0) a += w1[(long)j * total + cc] * pn[c];
     }
-    hpre[(long)n * hid + j] = a;
-    s_h[j] = act_apply(a, m);
+    a = wave_sum(a) + b1[j];
+    if (lane == 0) {
+      hpre[(long)n * hid + j] = a;
+      s_h[j] = act_apply(a, m);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < HT; c += 256) {
@@ -74,7 +130,7 @@ __global__ __launch_bounds__(256) void k_se_mlp_fwd(const float* __restrict__ po
 }
 
 // S = act(D*scale+shift) * gate[n]   (mode 0)        -- the projection's input
-// dgate[n][c] = sum_hw dS * act(D*scale+shift)  is k_se_dgate below
+// dgate[n][c] = sum_hw dS * act(D*scale+shift)  is k_se_pool<T, true> above
 template <typename T>
 __global__ __launch_bounds__(256) void k_se_scale(const T* __restrict__ d, int ldd, long dss, const float* __restrict__ scale,
                                                   const float* __restrict__ shift, int act, const float* __restrict__ gate, int ldg,
@@ -97,33 +153,6 @@ __global__ __launch_bounds__(256) void k_se_scale(const T* __restrict__ d, int l
   }
 }
 
-// dgate[n][c] = sum_hw dS[m][c] * act(D[m][c]*scale+shift); one thread per (n, 8 channels)
-template <typename T>
-__global__ __launch_bounds__(256) void k_se_dgate(const T* __restrict__ ds, int ldds, long dsss, const T* __restrict__ d, int ldd, long dss,
-                                                  const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                                  float* __restrict__ dgate, int ldg, int N, int HW, int C) {
-  const int cg = (C + 7) / 8;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * cg) return;
-  const int n = i / cg, c0 = (i % cg) * 8;
-  float s[8], h[8], acc[8];
-  VecIO<float, 8>::load(scale + c0, s);
-  VecIO<float, 8>::load(shift + c0, h);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  const Act m = act_of(act);
-  for (int p = 0; p < HW; ++p) {
-    float v[8], g[8];
-    VecIO<T, 8>::load(d + lay_off((long)n * HW + p, c0, ldd, dss), v);
-    VecIO<T, 8>::load(ds + lay_off((long)n * HW + p, c0, ldds, dsss), g);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += g[e] * act_apply(v[e] * s[e] + h[e], m);
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) if (c0 + e >= C) acc[e] = 0.f;
-  VecIO<float, 8>::store(dgate + (long)n * ldg + c0, acc);
-}
-
 // per image: dz2[n][c] = dgate * gate * (1 - gate);  dz1[n][j] = act'(hpre) * sum_c W2[cmap c][j] * dz2;  dpooled[n][c] = sum_j W1[j][cmap c] * dz1
 __global__ __launch_bounds__(256) void k_se_mlp_bwd_img(const float* __restrict__ dgate, const float* __restrict__ gate, int ldg,
                                                         const int* __restrict__ cmap, const float* __restrict__ w1,
@@ -142,17 +171,32 @@ __global__ __launch_bounds__(256) void k_se_mlp_bwd_img(const float* __restrict_
     dz2[(long)n * ldg + c] = v;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < hid; j += 256) {
-    float a = 0.f;
-    for (int c = 0; c < HT; ++c) {
-      const int cc = cmap[c];
-      if (cc >= 0) a += w2[(long)cc * hid + j] * s_z2[c];
+  // dz1: the 256 threads are JP hidden units x (256 / JP) channel ranges (rows of W2 are contiguous over the hidden units: coalesced);
+  // the range partials are added in range order
+  {
+    int JP = 1;
+    while (JP < hid && JP < 256) JP *= 2;
+    const int parts = 256 / JP, j = threadIdx.x % JP, part = threadIdx.x / JP;
+    float* s_part = s_z1 + hid;   // [parts][JP]
+    for (int j0 = 0; j0 < hid; j0 += JP) {
+      float a = 0.f;
+      if (j0 + j < hid)
+        for (int c = part; c < HT; c += parts) {
+          const int cc = cmap[c];
+          if (cc >= 0) a += w2[(long)cc * hid + j0 + j] * s_z2[c];
+        }
+      s_part[part * JP + j] = a;
+      __syncthreads();
+      if (part == 0 && j0 + j < hid) {
+        float t = s_part[j];
+        for (int q = 1; q < parts; ++q) t += s_part[q * JP + j];
+        const float v = act_bwd(t, hpre[(long)n * hid + j0 + j], m);
+        s_z1[j0 + j] = v;
+        dz1[(long)n * hid + j0 + j] = v;
+      }
+      __syncthreads();
     }
-    const float v = act_bwd(a, hpre[(long)n * hid + j], m);
-    s_z1[j] = v;
-    dz1[(long)n * hid + j] = v;
   }
-  __syncthreads();
   for (int c = threadIdx.x; c < HT; c += 256) {
     const int cc = cmap[c];
     float a = 0.f;
@@ -272,11 +316,14 @@ extern "C" int atomnas_se_squeeze(const void* d, int ldd, long d_ss, const float
                                   int ldp, int N, int HW, int C, int dtype, void* stream) {
   ATOMNAS_REQUIRE(d && scale && shift && pooled && N > 0 && HW > 0 && C > 0 && ldp >= (C + 7) / 8 * 8, "se_squeeze: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  const int total = N * ((C + 7) / 8);
+  const int cgb = se_pool_cgb(C);
+  const dim3 grid(N, ((C + 7) / 8 + cgb - 1) / cgb);
   if (dtype == DT_F32)
-    hipLaunchKernelGGL(k_se_squeeze<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)d, ldd, d_ss, scale, shift, act, pooled, ldp, N, HW, C);
+    hipLaunchKernelGGL((k_se_pool<float, false>), grid, dim3(256), 0, st, (const float*)d, ldd, d_ss, (const float*)nullptr, 0, 0L, scale, shift,
+                       act, pooled, ldp, HW, C, cgb);
   else
-    hipLaunchKernelGGL(k_se_squeeze<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)d, ldd, d_ss, scale, shift, act, pooled, ldp, N, HW, C);
+    hipLaunchKernelGGL((k_se_pool<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)d, ldd, d_ss, (const bf16_t*)nullptr, 0, 0L, scale,
+                       shift, act, pooled, ldp, HW, C, cgb);
   return check_launch("se_squeeze");
 }
 
@@ -314,16 +361,17 @@ extern "C" int atomnas_se_bwd_gate(const void* ds, int ldds, long ds_ss, const v
   ATOMNAS_REQUIRE(ds && d && scale && shift && gate && pooled && cmap && w1 && w2 && hpre && dgate && dz2 && dz1 && dpooled && dw1 &&
                       db1 && dw2 && db2 && N > 0 && HW > 0 && HT > 0 && hid > 0,
                   "se_bwd_gate: bad arguments");
-  ATOMNAS_REQUIRE((size_t)(HT + hid) * sizeof(float) <= 60 * 1024, "se_bwd_gate: block too wide for the per-image kernel");
+  ATOMNAS_REQUIRE((size_t)(HT + hid + 256) * sizeof(float) <= 60 * 1024, "se_bwd_gate: block too wide for the per-image kernel");
   hipStream_t st = (hipStream_t)stream;
-  const int total_t = N * ((HT + 7) / 8);
+  const int cgb = se_pool_cgb(HT);
+  const dim3 grid(N, ((HT + 7) / 8 + cgb - 1) / cgb);
   if (dtype == DT_F32)
-    hipLaunchKernelGGL(k_se_dgate<float>, dim3((total_t + 255) / 256), dim3(256), 0, st, (const float*)ds, ldds, ds_ss, (const float*)d, ldd,
-                       d_ss, scale, shift, act, dgate, ldg, N, HW, HT);
+    hipLaunchKernelGGL((k_se_pool<float, true>), grid, dim3(256), 0, st, (const float*)d, ldd, d_ss, (const float*)ds, ldds, ds_ss, scale, shift,
+                       act, dgate, ldg, HW, HT, cgb);
   else
-    hipLaunchKernelGGL(k_se_dgate<bf16_t>, dim3((total_t + 255) / 256), dim3(256), 0, st, (const bf16_t*)ds, ldds, ds_ss, (const bf16_t*)d,
-                       ldd, d_ss, scale, shift, act, dgate, ldg, N, HW, HT);
-  hipLaunchKernelGGL(k_se_mlp_bwd_img, dim3(N), dim3(256), (size_t)(HT + hid) * sizeof(float), st, dgate, gate, ldg, cmap, w1, w2, hpre, act,
+    hipLaunchKernelGGL((k_se_pool<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)d, ldd, d_ss, (const bf16_t*)ds, ldds, ds_ss, scale,
+                       shift, act, dgate, ldg, HW, HT, cgb);
+  hipLaunchKernelGGL(k_se_mlp_bwd_img, dim3(N), dim3(256), (size_t)(HT + hid + 256) * sizeof(float), st, dgate, gate, ldg, cmap, w1, w2, hpre, act,
                      dz2, dz1, dpooled, HT, total, hid);
   long elems = 2L * HT * hid + HT + hid;
   long blocks = (elems + 255) / 256;
