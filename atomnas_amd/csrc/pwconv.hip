@@ -1620,7 +1620,9 @@ constexpr int XB_DP = 64 + 8;   // transposed LDS pitch (elements): rows of the 
 #ifndef EB_MINWG
 #define EB_MINWG 2   // workgroups per CU the registers are allocated for (experiment switch)
 #endif
-template <int UT, int NCH>
+// NOE: dE = c1*h only -- the form of the E-elimination (xdw.hip): the c2*E + c3 part of the BatchNorm backward reaches dX / dWe
+// through inp x inp sized corrections (atomnas_xb_coeffs), so the raw expand output is neither read nor does it exist.
+template <int UT, int NCH, bool NOE>
 __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const bf16_t* __restrict__ Wp, int ldw, int wrows, const bf16_t* __restrict__ x,
                                                     int ldx, Epilogue ep, float* __restrict__ ws, long M, int N, int K) {
   using T = bf16_t;
@@ -1712,7 +1714,7 @@ __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const b
         anx[ks].x = z;
         if (rowvalid && k < K) {
           anx[ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row, k, A.ld1, A.ss1));
-          anx[ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row, k, A.ld2, A.ss2));
+          if constexpr (!NOE) anx[ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row, k, A.ld2, A.ss2));
         }
       }
     };
@@ -1756,7 +1758,7 @@ __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const b
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            v[e] = rowvalid ? c1v[e] * (float)acur[ks].a[e] + c2v[e] * (float)acur[ks].x[e] + c3v[e] : 0.f;
+            v[e] = rowvalid ? (NOE ? c1v[e] * (float)acur[ks].a[e] : c1v[e] * (float)acur[ks].a[e] + c2v[e] * (float)acur[ks].x[e] + c3v[e]) : 0.f;
           const bf16x8 af = MM::pack(v);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -2538,7 +2540,7 @@ static inline int xb_nch(int HT) {
 template <int UT, int NCH>
 static int launch_expand_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, int wrows, const bf16_t* x, int ldx, const Epilogue& ep, float* dwe,
                                  float* ws, long ws_floats, long M, int N, int K, hipStream_t st) {
-  auto kern = k_expand_bwd<UT, NCH>;
+  auto kern = A.p2 ? k_expand_bwd<UT, NCH, false> : k_expand_bwd<UT, NCH, true>;
   const size_t lds = (size_t)2 * 64 * WS_WP * sizeof(bf16_t) + 2 * 3 * WS_KC * sizeof(float) + (size_t)2 * 64 * XB_DP * sizeof(bf16_t) +
                      (size_t)16 * UT * XB_DP * sizeof(bf16_t);
   const long rblocks = (M + 63) / 64;
@@ -2649,9 +2651,10 @@ extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void*
                                   const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx,
                                   int ldgx, float* dwe, float* ws, long ws_floats, long M, int inp, int hid, int dtype, void* stream) {
   ATOMNAS_REQUIRE(atomnas_expand_bwd_supported(inp, hid, dtype), "expand_bwd: unsupported shape inp=%d hid=%d dtype=%d", inp, hid, dtype);
-  ATOMNAS_REQUIRE(h && e && c1 && c2 && c3 && x && wt && gx && dwe && ws && M > 0, "expand_bwd: bad arguments");
-  ATOMNAS_REQUIRE((h_ss >= M * 16 || (h_ss == 0 && ldh >= hid && ldh % 8 == 0)) && (e_ss >= M * 16 || (e_ss == 0 && lde >= hid && lde % 8 == 0)),
+  ATOMNAS_REQUIRE(h && c1 && x && wt && gx && dwe && ws && M > 0 && (!e || (c2 && c3)), "expand_bwd: bad arguments");
+  ATOMNAS_REQUIRE((h_ss >= M * 16 || (h_ss == 0 && ldh >= hid && ldh % 8 == 0)) && (!e || e_ss >= M * 16 || (e_ss == 0 && lde >= hid && lde % 8 == 0)),
                   "expand_bwd: bad hidden layout");
+  if (!e) { c2 = c1; c3 = c1; }   // e == NULL: dE = c1*h (the kernel stages, but does not use, the other two coefficient vectors)
   ATOMNAS_REQUIRE(ldx >= inp && ldx % 8 == 0 && ldgx >= inp && ldgx % 8 == 0 && (!add || (ldadd >= inp && ldadd % 8 == 0)), "expand_bwd: bad pitch");
   ATOMNAS_REQUIRE(ldw >= (hid + 31) / 32 * 32 && ldw % 8 == 0, "expand_bwd: packed weight pitch %d too small for hid=%d", ldw, hid);
   Operand A{h, ldh, e, lde, h_ss, e_ss, c1, c2, c3, 0};
