@@ -53,17 +53,12 @@ SIGNATURES = {
     "atomnas_mask_index": [vp, i32, vp, vp, vp],
     "atomnas_gather_dim": [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp],
     "atomnas_gram": [vp, i32, i64, i32, vp, i64, vp, vp, i32, vp],
-    "atomnas_gram_stats": [vp, i32, vp, vp, i32, i32, i32, vp, i32, vp],
-    "atomnas_xdw_fwd": [vp, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "atomnas_xdw_bwd": [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i64, vp, vp, i32, i32, vp, i32, i32,
-                        i32, i32, i32, i32, vp],
     "atomnas_xb_coeffs": [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp],
 }
 NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version": (i32, []),
              "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32]),
              "atomnas_project_bwd_supported": (i32, [i32, i32, i32]),
-             "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
-             "atomnas_xdw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32])}
+             "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32])}
 
 ABI_VERSION = 4   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None

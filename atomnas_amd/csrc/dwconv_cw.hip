@@ -505,6 +505,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
 #endif
 }
 
+#ifdef ATOMNAS_EXPERIMENTAL_XDW   // round-4 experiment (csrc/experimental/xdw_fused.hip): not part of the product library
 // ------------------------------------------------------------------------------------------- backward, expand recomputed
 // k_dwb_cw with its input operand recomputed on chip ("E-elimination", see xdw.hip): the raw expand output E = xin W1^T of the
 // tile's pixels comes out of an MFMA stage (weights of the slab as the A operand, 16-pixel groups of the narrow block input xin
@@ -889,6 +890,8 @@ __global__ __launch_bounds__(256, WPS) void k_xdwb(const bf16_t* __restrict__ gu
   }
 #endif
 }
+
+#endif   // ATOMNAS_EXPERIMENTAL_XDW
 
 // ------------------------------------------------------------------------------------------------------- backward, stride 2
 // Stride-2 depthwise backward in the same form.  The lanes live on the dY grid (Ho x Wo = H/2 x W/2): a lane owns 7 dY columns of
@@ -1594,6 +1597,7 @@ static int cw2_launch_bwd(const void* gup, long gss, const void* yraw, long yrss
   return 0;
 }
 
+#ifdef ATOMNAS_EXPERIMENTAL_XDW
 template <int K, int KC>
 static int xdw_launch_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
                           const void* xin, int ldx, int inp, const void* wexp, int ldwe, const float* sc, const float* sh, int relu,
@@ -1639,6 +1643,8 @@ int xdw_cw_bwd_supported(int N, int H, int W, int C, int k) {
   const size_t lds = (size_t)4 * g.plane * sizeof(f32x2) + (size_t)4 * g.TPIXp * (sizeof(f32x2) + sizeof(unsigned)) + 48 * sizeof(float);
   return lds <= 160 * 1024 ? 1 : 0;
 }
+
+#endif   // ATOMNAS_EXPERIMENTAL_XDW
 
 // -1: not one of this file's cases (the caller continues with the tile kernels of dwconv.hip); otherwise the launch status
 int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,

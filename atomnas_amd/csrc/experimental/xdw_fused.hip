@@ -19,7 +19,7 @@
 //     so one pass over h (existing GEMM kernels, c1 as their scale prologue) plus inp x inp sized corrections.
 // Numerics: E is never rounded to the storage type (it used to be stored as bf16); everything else as in dwconv_cw.hip.
 // No atomics; all reductions in a fixed order.
-#include "common.h"
+#include "../common.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -474,98 +474,6 @@ __global__ __launch_bounds__(512, 4) void k_xdwf(const bf16_t* __restrict__ x, i
   }
 }
 
-// ------------------------------------------------------------------------------------------------- Gram matrix of the block input
-// G = X^T X (inp x inp) and sx = sum_m x_m of the narrow block input x [M][ldx] (bf16): per-workgroup partials [G | sx] over a range
-// of 128-pixel tiles (staged in LDS as fp32; thread = one row element times four columns of G), summed in workgroup order by
-// k_gram_reduce -- fixed order, no atomics.  inp <= 64, a multiple of 8.
-__global__ __launch_bounds__(256) void k_gram_part(const bf16_t* __restrict__ x, int ldx, long M, int inp, float* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) float s_t[];   // [128][inp]
-  const int tid = threadIdx.x;
-  const int nq = inp >> 2, nitems = inp * nq;
-  f32x4 acc[4];
-  int it_i[4], it_q[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int it = tid + 256 * u;
-    it_i[u] = it < nitems ? it / nq : -1;
-    it_q[u] = it % nq;
-  }
-  float sxa = 0.f;
-  const long ntiles = (M + 127) / 128;
-  const long t_beg = blockIdx.x * ntiles / gridDim.x, t_end = (blockIdx.x + 1) * ntiles / gridDim.x;
-  const int npc = 128 * (inp >> 3);   // 16-byte pieces per tile
-  // the pieces of a tile (at most 4 per thread: inp <= 64) are fetched one tile ahead
-  bf16x8 pf[4];
-  auto fetch = [&](long t) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pc = tid + 256 * u;
-      const int r = pc / (inp >> 3), cg = pc - r * (inp >> 3);
-      const long row = t * 128 + r;
-      const bool ok = pc < npc && row < M;
-      pf[u] = *reinterpret_cast<const bf16x8*>(x + (ok ? row * ldx + cg * 8 : 0));
-    }
-  };
-  if (t_beg < t_end) fetch(t_beg);
-  for (long t = t_beg; t < t_end; ++t) {
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pc = tid + 256 * u;
-      if (pc < npc) {
-        const int r = pc / (inp >> 3), cg = pc - r * (inp >> 3);
-        const bool ok = t * 128 + r < M;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ok ? (float)pf[u][e] : 0.f;
-        VecIO<float, 8>::store(s_t + r * inp + cg * 8, v);
-      }
-    }
-    __syncthreads();
-    fetch(t + 1 < t_end ? t + 1 : t);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (it_i[u] >= 0) {
-        const float* pa = s_t + it_i[u];
-        const float* pb = s_t + 4 * it_q[u];
-        f32x4 a4 = acc[u];
-#pragma unroll 8
-        for (int pp = 0; pp < 128; ++pp) {
-          const float a = pa[pp * inp];
-          const f32x4 b = *reinterpret_cast<const f32x4*>(pb + pp * inp);
-          a4[0] += a * b[0]; a4[1] += a * b[1]; a4[2] += a * b[2]; a4[3] += a * b[3];
-        }
-        acc[u] = a4;
-      }
-    }
-    if (tid < inp) {
-      float sacc = 0.f;
-#pragma unroll 8
-      for (int pp = 0; pp < 128; ++pp) sacc += s_t[pp * inp + tid];
-      sxa += sacc;
-    }
-  }
-  float* o = ws + (long)blockIdx.x * (inp * inp + inp);
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    if (it_i[u] >= 0) *reinterpret_cast<f32x4*>(o + it_i[u] * inp + 4 * it_q[u]) = acc[u];
-  if (tid < inp) o[inp * inp + tid] = sxa;
-}
-// one wave per output element: lane l adds the partials l, l + 64, ... in order, then a fixed-order butterfly over the lanes
-__global__ __launch_bounds__(256) void k_gram_reduce(const float* __restrict__ ws, int parts, int inp, float* __restrict__ gram,
-                                                     float* __restrict__ sx) {
-  const int n = inp * inp + inp;
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (e >= n) return;
-  float a = 0.f;
-  for (int r = lane; r < parts; r += 64) a += ws[(long)r * n + e];
-  a = wave_sum(a);
-  if (lane == 0) {
-    if (e < inp * inp) gram[e] = a; else sx[e - inp * inp] = a;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------- Gram-matrix statistics
 // Statistics of the expand BatchNorm without the expanded tensor: with e_c = w_c . x,
 //   sum_m e_c = w_c . sx,   sum_m e_c^2 = w_c^T G w_c,     sx = sum_m x_m,  G = X^T X  (inp x inp)
@@ -598,37 +506,6 @@ __global__ __launch_bounds__(64) void k_gram_stats(const float* __restrict__ gra
   }
   stats[c] = (float)s1;
   stats[stat_ld + c] = (float)(s2 > 0.0 ? s2 : 0.0);
-}
-
-// The inp x inp sized corrections of the expand backward without E (see the file header):
-//   mp[n][k]      = bf16( sum_c c2_c W[c][n] W[c][k] )          packed for atomnas_pw_gemm_nt ([inp rounded up to 64][ldm], zero padded by the caller)
-//   vb[n]         = sum_c c3_c W[c][n]                          (its bias vector)
-//   dwe[c*inp+k] += c2_c sum_j W[c][j] G[j][k] + c3_c sx[k]
-// One thread per output element, fixed-order sums.
-__global__ __launch_bounds__(256) void k_xb_coeffs(const float* __restrict__ c2, const float* __restrict__ c3, const bf16_t* __restrict__ wexp,
-                                                   int ldwe, const float* __restrict__ gram, int ldg, const float* __restrict__ sx,
-                                                   int inp, int C, bf16_t* __restrict__ mp, int ldm,
-                                                   float* __restrict__ vb, float* __restrict__ dwe) {
-  const long n_m = (long)inp * inp, n_w = (long)C * inp;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_m + inp + n_w; i += (long)gridDim.x * 256) {
-    if (i < n_m) {
-      const int n = (int)(i / inp), k = (int)(i % inp);
-      float a = 0.f;
-      for (int c = 0; c < C; ++c) a += c2[c] * (float)wexp[(long)c * ldwe + n] * (float)wexp[(long)c * ldwe + k];
-      mp[(long)n * ldm + k] = (bf16_t)a;
-    } else if (i < n_m + inp) {
-      const int n = (int)(i - n_m);
-      float a = 0.f;
-      for (int c = 0; c < C; ++c) a += c3[c] * (float)wexp[(long)c * ldwe + n];
-      vb[n] = a;
-    } else {
-      const long e = i - n_m - inp;
-      const int c = (int)(e / inp), k = (int)(e % inp);
-      float a = 0.f;
-      for (int jj = 0; jj < inp; ++jj) a += (float)wexp[(long)c * ldwe + jj] * gram[jj * ldg + k];
-      dwe[e] += c2[c] * a + c3[c] * sx[k];
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
@@ -761,23 +638,6 @@ extern "C" int atomnas_xdw_fwd(const void* x, int ldx, int inp, const void* wexp
   return 1;
 }
 
-// Gram matrix G = X^T X [inp][inp] and column sums sx [inp] of the block input x [M][ldx] (bf16; inp <= 64, a multiple of 8).
-// ws: caller-owned scratch of ws_floats floats for the per-workgroup partials (inp*inp + inp floats each; at least one).
-extern "C" int atomnas_gram(const void* x, int ldx, long M, int inp, float* ws, long ws_floats, float* gram, float* sx, int dtype, void* stream) {
-  ATOMNAS_REQUIRE(x && ws && gram && sx && M > 0 && inp >= 8 && inp <= 64 && inp % 8 == 0 && ldx >= inp && ldx % 8 == 0 && dtype == DT_BF16,
-                  "gram: bad arguments (bf16, inp <= 64 and a multiple of 8)");
-  const long ps = (long)inp * inp + inp;
-  long parts = 2L * num_cus();
-  const long ntiles = (M + 127) / 128;
-  if (parts > ntiles) parts = ntiles;
-  if (parts > ws_floats / ps) parts = ws_floats / ps;
-  ATOMNAS_REQUIRE(parts >= 1, "gram: workspace too small for one partial (%ld floats)", ps);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gram_part, dim3((unsigned)parts), dim3(256), (size_t)128 * inp * sizeof(float), st, (const bf16_t*)x, ldx, M, inp, ws);
-  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((ps + 3) / 4)), dim3(256), 0, st, ws, (int)parts, inp, gram, sx);
-  return check_launch("gram");
-}
-
 // Statistics row of the expand BatchNorm from the Gram matrix of the block input (see k_gram_stats).  gram [inp][ldg], sx [inp]:
 // atomnas_gram's outputs; wexp: packed expand weight [C][ldwe] bf16.  Writes stats[0 .. C) = sum e_c and stats[stat_ld .. + C) = sum e_c^2.
 extern "C" int atomnas_gram_stats(const float* gram, int ldg, const float* sx, const void* wexp, int ldwe, int inp, int C, float* stats,
@@ -788,18 +648,6 @@ extern "C" int atomnas_gram_stats(const float* gram, int ldg, const float* sx, c
   hipLaunchKernelGGL(k_gram_stats, dim3((C + 63) / 64), dim3(64), lds, (hipStream_t)stream, gram, ldg, sx, (const bf16_t*)wexp, ldwe, inp, C,
                      stats, stat_ld);
   return check_launch("gram_stats");
-}
-
-// Corrections of the expand backward without E (see k_xb_coeffs); c2 / c3: BatchNorm-backward coefficients of the C hidden channels.
-extern "C" int atomnas_xb_coeffs(const float* c2, const float* c3, const void* wexp, int ldwe, const float* gram, int ldg, const float* sx,
-                                 int inp, int C, void* mp, int ldm, float* vb, float* dwe, void* stream) {
-  ATOMNAS_REQUIRE(c2 && c3 && wexp && gram && sx && mp && vb && dwe && inp > 0 && inp <= 64 && C > 0 && ldg >= inp && ldwe >= inp && ldm >= inp,
-                  "xb_coeffs: bad arguments");
-  long blocks = ((long)inp * inp + inp + (long)C * inp + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_xb_coeffs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c2, c3, (const bf16_t*)wexp, ldwe, gram, ldg, sx,
-                     inp, C, (bf16_t*)mp, ldm, vb, dwe);
-  return check_launch("xb_coeffs");
 }
 
 // Backward of the depthwise convolution of one branch segment with its input operand recomputed from the block input

@@ -204,6 +204,10 @@ def _join_side():
 # situ: 1.30 ms against 1.19 ms for the two GEMMs (x is re-staged and Gx re-read per segment): off
 _FUSED_EXPAND_SEG = bool(int(os.environ.get("ATOMNAS_FUSED_EXPAND_SEG", "0")))
 _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
+# Expand backward without the raw expand output E (csrc/xbwd.hip): with dE = c1*h + c2*E + c3 and E = x We^T the c2 / c3 terms are
+# inp x inp sized corrections (Gram matrix of x), so the wide GEMMs read h only.  Widest block input that takes this form (0: never;
+# bf16 only).  Beyond 48 the Gram / coefficient launches cost what the second hidden stream did (small maps, measured).
+_EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "48"))
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
 _DP_TENSOR = bool(int(os.environ.get("ATOMNAS_DP_TENSOR", "1")))   # experiment switch: 0 = the BatchNorm-backward prologue in every GEMM tile
 TAIL_TAP = None   # set to a list by tests to receive the dropout keep mask of every tail forward
@@ -373,6 +377,8 @@ def block_backward(pl, sv, G):
         return h
     e1, e2, e3 = bn_backward_coeffs(pl.bne, bE, st2E, M, dev)
     Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
+    if T == torch.bfloat16 and not pl.fused and pl.inp <= _EXPAND_BWD_NOE and pl.inp % 8 == 0:
+        return _expand_backward_noe(pl, x2d, h, e1, e2, e3, G if pl.res else None, Gx, M, HT, dev, T)
     if pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and ops.expand_bwd_supported(pl.inp, HT, T):
         # early stages (16 -> 288, 24 -> 432): input and weight gradient of the expand convolution from ONE pass over h and E
         ops.expand_bwd(h, E, e1, e2, e3, x2d, pl.WeT_pack, G if pl.res else None, Gx, pl.We_grad, M, pl.inp, HT)
@@ -399,6 +405,44 @@ def block_backward(pl, sv, G):
                         vc3=e3[sg:])
     # expand input gradient (+ residual branch)
     ops.gemm_nt(h, pl.WeT_pack, Gx, M, pl.inp, HT, a_mode=PRO_BNBWD, a2=E, ac1=e1, ac2=e2, ac3=e3, add=G if pl.res else None)
+    _join_side()
+    return Gx
+
+
+def _plan_buffer(pl, name, make):
+    """small per-plan scratch that survives across steps (created on first use, i.e. in an eager step before any graph capture)"""
+    cache = pl.__dict__.setdefault("_scratch", {})
+    t = cache.get(name)
+    if t is None:
+        t = cache[name] = make()
+    return t
+
+
+def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
+    """Backward of the expand convolution from ONE hidden stream (models/mobilenet_base.py:316-320 backward).  With the BatchNorm
+    backward dE = e1*h + e2*E + e3 and E = x We^T:
+        dX  = (e1*h) We + x M + v (+ residual),        M = We^T diag(e2) We,  v = e3^T We
+        dWe = (e1*h)^T x + diag(e2) We (X^T X) + e3 (sum x)^T
+    The e2 / e3 terms are inp x inp sized (atomnas_gram + atomnas_xb_coeffs); the wide GEMMs read h alone (e1 as their scale
+    prologue), where the BNBWD-prologue forms read h and E."""
+    inp = pl.inp
+    gram = torch.empty(inp * inp, dtype=torch.float32, device=dev)
+    sx = torch.empty(inp, dtype=torch.float32, device=dev)
+    ops.gram(x2d, M, inp, gram, sx, ws=_plan_buffer(pl, "gram_ws", lambda: torch.empty(512 * (inp * inp + inp), dtype=torch.float32, device=dev)))
+    # M packed as a gemm_nt weight (padding stays zero: the buffer is created zeroed once and only its inp x inp corner is rewritten)
+    mp = _plan_buffer(pl, "xb_mp", lambda: ops.zeros((inp + 63) // 64 * 64, (inp + 31) // 32 * 32, dtype=T, device=dev))
+    vb = torch.empty(pad8(inp), dtype=torch.float32, device=dev)
+    ops.xb_coeffs(e2, e3, pl.We_pack, gram, sx, inp, HT, mp, vb, pl.We_grad)
+    gx1 = torch.empty(M, inp, dtype=T, device=dev)
+    ops.gemm_nt(x2d, mp, gx1, M, inp, inp, bias=vb, add=res)
+    if inp <= _FUSED_EXPAND_BWD and ops.expand_bwd_supported(inp, HT, T):
+        ops.expand_bwd(h, None, e1, None, None, x2d, pl.WeT_pack, gx1, Gx, pl.We_grad, M, inp, HT)
+        _join_side()
+        return Gx
+    zeros = _plan_buffer(pl, "xb_zero%d" % e1.numel(), lambda: ops.zeros(e1.numel(), dtype=torch.float32, device=dev))
+    with _Side():
+        ops.gemm_tn(x2d, inp, h, HT, pl.We_grad, 1, inp, M, v_mode=PRO_BNRELU, vc1=e1, vc2=zeros, v_relu=0)
+    ops.gemm_nt(h, pl.WeT_pack, Gx, M, inp, HT, a_mode=PRO_BNRELU, ac1=e1, ac2=zeros, a_relu=0, add=gx1)
     _join_side()
     return Gx
 

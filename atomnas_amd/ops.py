@@ -161,11 +161,6 @@ def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, d
          _p(dw_ws), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
 
-def xdw_supported(N, H, W, inp, C, k, stride, dtype):
-    """1 when the fused expand + depthwise kernels (csrc/xdw.hip) have instances for a branch segment of C hidden channels"""
-    return bool(_lib.load().atomnas_xdw_supported(int(N), int(H), int(W), int(inp), int(C), int(k), int(stride), dt_code(dtype)))
-
-
 def gram(x, M, inp, gram_out, sx_out, ws=None):
     """G = X^T X [inp][inp] and column sums sx [inp] of the block input x [M, ld] (include/atomnas_hip.h)"""
     _chk_cuda(x, gram_out, sx_out)
@@ -174,34 +169,6 @@ def gram(x, M, inp, gram_out, sx_out, ws=None):
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d inp%d" % (M, inp))
     call("atomnas_gram", _p(x), _ld(x), M, inp, _p(ws), ws.numel(), _p(gram_out), _p(sx_out), dt_code(x.dtype), _stream())
-
-
-def gram_stats(gram_m, sx, wexp, inp, C, stats, stat_ld):
-    """statistics row [2][stat_ld] of the expand BatchNorm from the Gram matrix of the block input (include/atomnas_hip.h)"""
-    call("atomnas_gram_stats", _p(gram_m), inp, _p(sx), _p(wexp), wexp.stride(0), inp, C, _p(stats), stat_ld, _stream())
-
-
-def xdw_fwd(x, inp, wexp, in_scale, in_shift, act, w_taps, y, stats, stat_ld, N, H, W, C, k, stat_rows=None):
-    """y = dwconv_k(act(in_scale * (x wexp^T) + in_shift)): expand + BN + activation on chip in front of the depthwise conv"""
-    _chk_cuda(x, wexp, y, w_taps)
-    if _lib.PROFILE is not None:
-        _lib.profile_tag("N%d H%d C%d k%d s1 inp%d" % (N, H, C, k, inp))
-    call("atomnas_xdw_fwd", _p(x), _ld(x), inp, _p(wexp), wexp.stride(0), _p(in_scale), _p(in_shift), int(act), _p(w_taps), w_taps.stride(0),
-         _p(y), _ss(y), _p(stats), stat_ld, _rows(stats, stat_rows), N, H, W, C, k, dt_code(x.dtype), _stream())
-
-
-def xdw_bwd(g, yraw, c1, c2, c3, x, inp, wexp, in_scale, in_shift, act, w_taps, h, dw, stats, stat_ld, N, H, W, C, k, stat_rows=None,
-            dw_ws=None):
-    """atomnas_dwconv_bwd with the expand output recomputed from the block input x (include/atomnas_hip.h)"""
-    _chk_cuda(g, x, h, w_taps, wexp)
-    rows = _rows(stats, stat_rows) if stats is not None else stat_rows_for(C)
-    if dw is not None and dw_ws is None:
-        dw_ws = torch.empty(rows * C * k * k, dtype=torch.float32, device=x.device)
-    if _lib.PROFILE is not None:
-        _lib.profile_tag("N%d H%d C%d k%d s1 inp%d" % (N, H, C, k, inp))
-    call("atomnas_xdw_bwd", _p(g), _ss(g), _p(yraw), _ss(yraw), _p(c1), _p(c2), _p(c3), _p(x), _ld(x), inp, _p(wexp), wexp.stride(0),
-         _p(in_scale), _p(in_shift), int(act), _p(w_taps), w_taps.stride(0), _p(h), _ss(h), _p(dw), _p(stats), stat_ld, rows, _p(dw_ws),
-         N, H, W, C, k, dt_code(x.dtype), _stream())
 
 
 def xb_coeffs(c2, c3, wexp, gram, sx, inp, C, mp, vb, dwe):

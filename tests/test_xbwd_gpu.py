@@ -1,0 +1,87 @@
+"""Kernel-level parity (GPU) of the expand backward without E (csrc/xbwd.hip, include/atomnas_hip.h): the Gram matrix of the block
+input, the inp x inp corrections, and atomnas_expand_bwd with e = NULL -- against float64 torch restatements of
+models/mobilenet_base.py:316-320 (backward) on inputs rounded to bf16.
+"""
+import pytest
+import torch
+
+from kutil import assert_close, cvec
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _ops():
+    from atomnas_amd import ops
+    return ops
+
+
+def pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def pack_we(w):
+    """[C, inp] -> packed expand weight [pad64(C)][pad32(inp)] bf16 (atomnas_pack_weights mode 0)"""
+    C, inp = w.shape
+    buf = torch.zeros(pad(C, 64), pad(inp, 32), dtype=BF, device="cuda")
+    buf[:C, :inp] = w.to(BF).cuda()
+    return buf
+
+
+@pytest.mark.parametrize("M,inp,C", [(5000, 24, 432), (3000, 40, 720), (1234, 16, 96), (2000, 64, 128)])
+def test_gram_and_coeffs(gpu_lib, M, inp, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + inp)
+    x = torch.randn(M, inp, generator=g) + 0.3
+    we = torch.randn(C, inp, generator=g) / inp ** 0.5
+    xb = x.to(BF).cuda().contiguous()
+    wp = pack_we(we)
+    xr, wr = x.to(BF).double(), we.to(BF).double()
+    E = xr @ wr.t()
+    gram = torch.full((inp, inp), float("nan"), dtype=torch.float32, device="cuda")
+    sx = torch.full((inp,), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gram(xb, M, inp, gram, sx)
+    torch.cuda.synchronize()
+    assert_close("gram", gram, xr.t() @ xr, rtol=1e-5, atol=1e-3)
+    assert_close("sx", sx, xr.sum(0), rtol=1e-5, atol=1e-2)
+    # corrections of the expand backward
+    c2 = torch.randn(C, generator=g) * 0.1
+    c3 = torch.randn(C, generator=g) * 0.1
+    mp = torch.zeros(pad(inp, 64), pad(inp, 32), dtype=BF, device="cuda")
+    vb = torch.empty(inp, dtype=torch.float32, device="cuda")
+    dwe0 = torch.randn(C, inp, generator=g)
+    dwe = dwe0.float().cuda().contiguous()
+    ops.xb_coeffs(cvec(c2), cvec(c3), wp, gram, sx, inp, C, mp, vb, dwe)
+    torch.cuda.synchronize()
+    Mref = wr.t() @ (c2.double().view(-1, 1) * wr)
+    assert_close("M", mp[:inp, :inp], Mref, rtol=1e-2, atol=1e-2 * float(Mref.abs().max()))
+    assert float(mp[inp:].abs().max() if mp.shape[0] > inp else 0) == 0.0
+    assert_close("v", vb, c3.double() @ wr, rtol=1e-4, atol=1e-4)
+    dref = dwe0.double() + c2.double().view(-1, 1) * (wr @ (xr.t() @ xr)) + c3.double().view(-1, 1) * xr.sum(0).view(1, -1)
+    assert_close("dwe", dwe, dref, rtol=1e-4, atol=1e-3 * float(dref.abs().max()))
+
+
+def test_expand_bwd_without_e(gpu_lib):
+    """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add, dwe += (c1*h)^T x"""
+    ops = _ops()
+    M, inp, hid = 3000, 24, 432
+    if not ops.expand_bwd_supported(inp, hid, BF):
+        pytest.skip("no instance")
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(M, hid, generator=g)
+    x = torch.randn(M, inp, generator=g)
+    we = torch.randn(hid, inp, generator=g) / inp ** 0.5
+    add = torch.randn(M, inp, generator=g)
+    c1 = torch.rand(hid, generator=g) + 0.5
+    hb = ops.Slab.from_plain(h.to(BF).cuda().contiguous(), hid)
+    wt = torch.zeros(pad(inp, 64), pad(hid, 32), dtype=BF, device="cuda")
+    wt[:inp, :hid] = we.t().to(BF).cuda()
+    gx = torch.empty(M, inp, dtype=BF, device="cuda")
+    dwe = torch.zeros(hid, inp, dtype=torch.float32, device="cuda")
+    ops.expand_bwd(hb, None, cvec(c1), None, None, x.to(BF).cuda().contiguous(), wt, add.to(BF).cuda().contiguous(), gx, dwe, M, inp, hid)
+    torch.cuda.synchronize()
+    dE = (c1.double().view(1, -1) * h.to(BF).double()).to(BF).double()   # the kernel rounds dE to the MFMA input type
+    gref = dE @ we.to(BF).double() + add.to(BF).double()
+    assert_close("gx", gx, gref, rtol=1.2e-2, atol=2e-2 * float(gref.abs().max()))
+    dref = dE.t() @ x.to(BF).double()
+    assert_close("dwe", dwe, dref, rtol=2e-3, atol=2e-3 * float(dref.abs().max()))

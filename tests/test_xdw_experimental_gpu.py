@@ -1,7 +1,8 @@
-"""Kernel-level parity (GPU) of the E-elimination entry points (csrc/xdw.hip, include/atomnas_hip.h): the expand 1x1 convolution +
-BatchNorm + activation computed on chip in front of the depthwise convolution, forward and backward, the Gram-matrix statistics of
-the expand BatchNorm and the inp x inp corrections of the expand backward -- each against a float64 torch restatement of
-models/mobilenet_base.py:316-336 on inputs rounded to bf16.
+"""Kernel-level parity (GPU) of the round-4 E-elimination EXPERIMENT (atomnas_amd/csrc/experimental/: the expand 1x1 convolution +
+BatchNorm + activation computed on chip in front of the depthwise convolution, forward and backward; not part of the product
+library) against a float64 torch restatement of models/mobilenet_base.py:316-336 on inputs rounded to bf16.  Runs only when the
+experiment library is loaded:
+    tools/build_xdw_experiment.sh && ATOMNAS_HIP_LIB=atomnas_amd/csrc/build/variants/libxdw.so python -m pytest tests/test_xdw_experimental_gpu.py -m gpu
 """
 import itertools
 
@@ -20,9 +21,21 @@ SHAPES = [(5, 7, 7, 16, 16), (3, 14, 14, 24, 32), (2, 28, 28, 40, 48), (1, 56, 5
 ACTS = {1: torch.relu, 2: lambda t: torch.clamp(t, 0.0, 6.0), 3: lambda t: t * torch.sigmoid(t)}
 
 
+class _Ops:
+    """product ops + the experiment's wrappers"""
+    def __getattr__(self, name):
+        import os
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments"))
+        import xdw_ops
+        from atomnas_amd import ops
+        if not xdw_ops.available():
+            pytest.skip("the E-elimination experiment library is not loaded (tools/build_xdw_experiment.sh, ATOMNAS_HIP_LIB)")
+        return getattr(xdw_ops, name) if hasattr(xdw_ops, name) and name.startswith(("xdw_", "gram_stats")) else getattr(ops, name)
+
+
 def _ops():
-    from atomnas_amd import ops
-    return ops
+    return _Ops()
 
 
 def pad(n, m):
@@ -103,7 +116,7 @@ def test_xdw_fwd_long_tile_walk(gpu_lib, workers, monkeypatch):
     env = dict(os.environ)
     if workers:
         env["ATOMNAS_DW_MAX_WORKERS"] = str(workers)
-    code = ("import sys; sys.path.insert(0, 'tests'); import torch, test_xdw_gpu as t; "
+    code = ("import sys; sys.path.insert(0, 'tests'); import torch, test_xdw_experimental_gpu as t; "
             "[t.test_xdw_fwd(None, 9, 28, 28, 40, 48, k, 1) for k in (3, 7)]; [t.test_xdw_bwd(None, 9, 28, 28, 40, 48, k, 1) for k in (3, 7)]; print('ok')")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -149,64 +162,3 @@ def test_xdw_bwd(gpu_lib, N, H, W, inp, C, k, act):
     assert_close("sum_he", st[1], (hk * E).sum((0, 2, 3)), rtol=2e-4, atol=5e-3)
 
 
-@pytest.mark.parametrize("M,inp,C", [(5000, 24, 432), (3000, 40, 720), (1234, 16, 96), (2000, 64, 128)])
-def test_gram_stats_and_coeffs(gpu_lib, M, inp, C):
-    ops = _ops()
-    g = torch.Generator().manual_seed(M + inp)
-    x = torch.randn(M, inp, generator=g) + 0.3
-    we = torch.randn(C, inp, generator=g) / inp ** 0.5
-    xb = x.to(BF).cuda().contiguous()
-    wp = pack_we(we)
-    xr, wr = x.to(BF).double(), we.to(BF).double()
-    E = xr @ wr.t()
-    gram = torch.full((inp, inp), float("nan"), dtype=torch.float32, device="cuda")
-    sx = torch.full((inp,), float("nan"), dtype=torch.float32, device="cuda")
-    ops.gram(xb, M, inp, gram, sx)
-    stats = torch.full((2, C), float("nan"), dtype=torch.float32, device="cuda")
-    ops.gram_stats(gram, sx, wp, inp, C, stats, C)
-    torch.cuda.synchronize()
-    assert_close("gram", gram, xr.t() @ xr, rtol=1e-5, atol=1e-3)
-    assert_close("sx", sx, xr.sum(0), rtol=1e-5, atol=1e-2)
-    assert_close("sum_e", stats[0], E.sum(0), rtol=1e-4, atol=2e-2)
-    assert_close("sum_e2", stats[1], (E * E).sum(0), rtol=1e-4, atol=1e-2)
-    # corrections of the expand backward
-    c2 = torch.randn(C, generator=g) * 0.1
-    c3 = torch.randn(C, generator=g) * 0.1
-    mp = torch.zeros(pad(inp, 64), pad(inp, 32), dtype=BF, device="cuda")
-    vb = torch.empty(inp, dtype=torch.float32, device="cuda")
-    dwe0 = torch.randn(C, inp, generator=g)
-    dwe = dwe0.float().cuda().contiguous()
-    ops.xb_coeffs(cvec(c2), cvec(c3), wp, gram, sx, inp, C, mp, vb, dwe)
-    torch.cuda.synchronize()
-    Mref = wr.t() @ (c2.double().view(-1, 1) * wr)
-    assert_close("M", mp[:inp, :inp], Mref, rtol=1e-2, atol=1e-2 * float(Mref.abs().max()))
-    assert float(mp[inp:].abs().max() if mp.shape[0] > inp else 0) == 0.0
-    assert_close("v", vb, c3.double() @ wr, rtol=1e-4, atol=1e-4)
-    dref = dwe0.double() + c2.double().view(-1, 1) * (wr @ (xr.t() @ xr)) + c3.double().view(-1, 1) * xr.sum(0).view(1, -1)
-    assert_close("dwe", dwe, dref, rtol=1e-4, atol=1e-3 * float(dref.abs().max()))
-
-
-def test_expand_bwd_without_e(gpu_lib):
-    """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add, dwe += (c1*h)^T x"""
-    ops = _ops()
-    M, inp, hid = 3000, 24, 432
-    if not ops.expand_bwd_supported(inp, hid, BF):
-        pytest.skip("no instance")
-    g = torch.Generator().manual_seed(5)
-    h = torch.randn(M, hid, generator=g)
-    x = torch.randn(M, inp, generator=g)
-    we = torch.randn(hid, inp, generator=g) / inp ** 0.5
-    add = torch.randn(M, inp, generator=g)
-    c1 = torch.rand(hid, generator=g) + 0.5
-    hb = ops.Slab.from_plain(h.to(BF).cuda().contiguous(), hid)
-    wt = torch.zeros(pad(inp, 64), pad(hid, 32), dtype=BF, device="cuda")
-    wt[:inp, :hid] = we.t().to(BF).cuda()
-    gx = torch.empty(M, inp, dtype=BF, device="cuda")
-    dwe = torch.zeros(hid, inp, dtype=torch.float32, device="cuda")
-    ops.expand_bwd(hb, None, cvec(c1), None, None, x.to(BF).cuda().contiguous(), wt, add.to(BF).cuda().contiguous(), gx, dwe, M, inp, hid)
-    torch.cuda.synchronize()
-    dE = (c1.double().view(1, -1) * h.to(BF).double()).to(BF).double()   # the kernel rounds dE to the MFMA input type
-    gref = dE @ we.to(BF).double() + add.to(BF).double()
-    assert_close("gx", gx, gref, rtol=1.2e-2, atol=2e-2 * float(gref.abs().max()))
-    dref = dE.t() @ x.to(BF).double()
-    assert_close("dwe", dwe, dref, rtol=2e-3, atol=2e-3 * float(dref.abs().max()))

@@ -1,10 +1,13 @@
 """Phase accounting of the fused expand + depthwise forward (experiment build with -DXD_TIMING=1):
-    tools/variant.sh xdt xdw.hip -DXD_TIMING=1
+    tools/build_xdw_experiment.sh xdt -DXD_TIMING=1
     ATOMNAS_HIP_LIB=atomnas_amd/csrc/build/variants/libxdt.so python tools/xdtiming.py
 Prints, per shape, the share of wave cycles per phase of a slab-tile and the cycles per slab-tile and wave."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from atomnas_amd import _lib, ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments"))
+import xdw_ops
+assert xdw_ops.available(), "load the experiment library (tools/build_xdw_experiment.sh xdt -DXD_TIMING=1)"
 from atomnas_amd.ops import Slab
 lib = _lib.load()
 fn = lib.atomnas_debug_xd_timing
@@ -24,7 +27,7 @@ for (H, inp, C, k) in CASES:
     sc = torch.rand(C, device="cuda") + 0.5; sh = torch.randn(C, device="cuda")
     rows = ops.stat_rows_for(C)
     st = torch.empty(rows * 2 * C, device="cuda")
-    run = lambda: ops.xdw_fwd(x, inp, wexp, sc, sh, 1, w, D, st, C, N, H, H, C, k, stat_rows=rows)
+    run = lambda: xdw_ops.xdw_fwd(x, inp, wexp, sc, sh, 1, w, D, st, C, N, H, H, C, k, stat_rows=rows)
     run(); run()
     out = (ctypes.c_ulonglong * 8)()
     fn(None, 1)

@@ -13,6 +13,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from atomnas_amd import ops  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments"))
+import xdw_ops  # noqa: E402
+if not xdw_ops.available():
+    raise SystemExit("load the experiment library: tools/build_xdw_experiment.sh; ATOMNAS_HIP_LIB=atomnas_amd/csrc/build/variants/libxdw.so")
 from atomnas_amd.ops import Slab  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -45,7 +49,7 @@ print("N", N, "S", os.environ.get("ATOMNAS_XDW_S", "3"))
 tot = dict(f0=0.0, f1=0.0, b0=0.0, b1=0.0)
 for (H, inp, C, k) in CASES:
     M = N * H * H
-    if not ops.xdw_supported(N, H, H, inp, C, k, 1, BF):
+    if not xdw_ops.xdw_supported(N, H, H, inp, C, k, 1, BF):
         print("H%d inp%d C%d k%d: no instance" % (H, inp, C, k))
         continue
     mk = lambda: Slab.from_plain(torch.randn(M, C, device="cuda").to(BF))
@@ -77,7 +81,7 @@ for (H, inp, C, k) in CASES:
 
     def fwd1():
         x, E, D, g, h = nxt()
-        ops.xdw_fwd(x, inp, wexp, sc, sh, 1, w, D, st, C, N, H, H, C, k, stat_rows=rows)
+        xdw_ops.xdw_fwd(x, inp, wexp, sc, sh, 1, w, D, st, C, N, H, H, C, k, stat_rows=rows)
 
     def bwd0():
         x, E, D, g, h = nxt()
@@ -85,7 +89,7 @@ for (H, inp, C, k) in CASES:
 
     def bwd1():
         x, E, D, g, h = nxt()
-        ops.xdw_bwd(g, D, c1, c2, c3, x, inp, wexp, sc, sh, 1, w, h, dw, st, C, N, H, H, C, k, stat_rows=rows, dw_ws=ws)
+        xdw_ops.xdw_bwd(g, D, c1, c2, c3, x, inp, wexp, sc, sh, 1, w, h, dw, st, C, N, H, H, C, k, stat_rows=rows, dw_ws=ws)
 
     te, f0, f1, b0, b1 = bench(expand), bench(fwd0), bench(fwd1), bench(bwd0), bench(bwd1)
     tot["f0"] += f0 + te; tot["f1"] += f1; tot["b0"] += b0; tot["b1"] += b1
@@ -105,7 +109,7 @@ for (H, inp, HT) in [(56, 24, 432), (28, 40, 720)]:
 
     def gram_path():
         ops.gram(x, M, inp, gram, sx, ws=gws)
-        ops.gram_stats(gram, sx, wexp, inp, HT, stats, HT)
+        xdw_ops.gram_stats(gram, sx, wexp, inp, HT, stats, HT)
 
     print("H%-3d inp%-3d HT%-4d: Gram statistics (partials + reduce + quadratic forms) %.3f ms" % (H, inp, HT, bench(gram_path)))
 print("sum: expand + fwd %.3f -> %.3f ms;  bwd %.3f -> %.3f ms" % (tot["f0"], tot["f1"], tot["b0"], tot["b1"]))
