@@ -20,7 +20,8 @@ SIGNATURES = {
                            i32, vp, vp, i32, i32, i64, i32, i32, i32, vp],
     "atomnas_pw_gemm_tn": [i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32,
                            vp, i64, i64, i64, vp, i64, i32, vp],
-    "atomnas_expand_bwd": [vp, i32, i64, vp, i32, i64, vp, vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, i64, i32, i32, i32, vp],
+    "atomnas_expand_bwd": [vp, i32, i64, vp, i32, i64, vp, vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, i64, i32, i32, i32,
+                           vp],
     "atomnas_project_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, i32, vp, i64, i64, vp, i64, i64,
                             i32, i32, i32, vp],
     "atomnas_bn_finalize_fwd": [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],

@@ -1624,7 +1624,8 @@ constexpr int XB_DP = 64 + 8;   // transposed LDS pitch (elements): rows of the 
 // through inp x inp sized corrections (atomnas_xb_coeffs), so the raw expand output is neither read nor does it exist.
 template <int UT, int NCH, bool NOE>
 __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const bf16_t* __restrict__ Wp, int ldw, int wrows, const bf16_t* __restrict__ x,
-                                                    int ldx, Epilogue ep, float* __restrict__ ws, long M, int N, int K) {
+                                                    int ldx, Epilogue ep, float* __restrict__ ws, long M, int N, int K,
+                                                    const bf16_t* __restrict__ mpk, int ldm) {
   using T = bf16_t;
   using MM = Mma<T>;
   constexpr int WROWS = 64;
@@ -1772,6 +1773,25 @@ __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const b
         if (c + 1 < nchunk) stage_store(buf ^ 1);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);   // the chunk loop is unrolled for static accumulator indices only: no motion across chunks
+      }
+    }
+    if constexpr (NOE) {
+      // + x M (mpk: M = We^T diag(c2) We packed [N rounded up to 64][ldm], zero padded): the c2 term of the BatchNorm backward, a
+      // product of the narrow input with an inp x inp matrix; its bias v rides in the epilogue
+      if (mpk) {
+        for (int kx = 0; kx < N; kx += 32) {
+          const int k = kx + 8 * q;
+          bf16x8 xb;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xb[e] = (bf16_t)0.f;
+          if (rowvalid && k < N) xb = *reinterpret_cast<const bf16x8*>(x + row * ldx + k);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int n = 16 * (j >> 2) + 4 * t + (j & 3);   // output channel of accumulator row j of tile t (row permutation of s_w)
+            const bf16x8 mf = *reinterpret_cast<const bf16x8*>(mpk + (long)n * ldm + k);
+            acc[t] = MM::mma(mf, xb, acc[t]);
+          }
+        }
       }
     }
     nt_epilogue<T>(ep, acc, row, rowvalid, 16 * q, N, false, nullptr, 0, 0, j);
@@ -2539,7 +2559,7 @@ static inline int xb_nch(int HT) {
 }
 template <int UT, int NCH>
 static int launch_expand_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, int wrows, const bf16_t* x, int ldx, const Epilogue& ep, float* dwe,
-                                 float* ws, long ws_floats, long M, int N, int K, hipStream_t st) {
+                                 float* ws, long ws_floats, long M, int N, int K, const bf16_t* mpk, int ldm, hipStream_t st) {
   auto kern = A.p2 ? k_expand_bwd<UT, NCH, false> : k_expand_bwd<UT, NCH, true>;
   const size_t lds = (size_t)2 * 64 * WS_WP * sizeof(bf16_t) + 2 * 3 * WS_KC * sizeof(float) + (size_t)2 * 64 * XB_DP * sizeof(bf16_t) +
                      (size_t)16 * UT * XB_DP * sizeof(bf16_t);
@@ -2549,7 +2569,7 @@ static int launch_expand_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, int
   const long max_parts = ws_floats / ((long)N * K);   // every workgroup owns one partial of the weight gradient
   if (R > max_parts) R = max_parts;
   ATOMNAS_REQUIRE(R >= 1, "expand_bwd: workspace too small for one partial (%ld floats)", (long)N * K);
-  hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(256), lds, st, A, W, ldw, wrows, x, ldx, ep, ws, M, N, K);
+  hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(256), lds, st, A, W, ldw, wrows, x, ldx, ep, ws, M, N, K, mpk, ldm);
   if (int rc = check_launch("expand_bwd")) return rc;
   // dWe[n * inp + k] += sum over workgroups of R[k][n], in workgroup order
   return reduce_parts(ws, (long)N * K, (int)R, (long)N * K, dwe, K, 1, N, st);
@@ -2649,23 +2669,25 @@ extern "C" int atomnas_expand_bwd_supported(int inp, int hid, int dtype) {
 //   dwe[n * inp + k] += sum_m dE[m][n] * x[m][k].   wt: We^T packed by atomnas_pack_weights ([inp padded to 64][ldw >= hid]).
 extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde, long e_ss, const float* c1, const float* c2,
                                   const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx,
-                                  int ldgx, float* dwe, float* ws, long ws_floats, long M, int inp, int hid, int dtype, void* stream) {
+                                  int ldgx, float* dwe, float* ws, long ws_floats, const void* mp, int ldm, const float* vb, long M, int inp,
+                                  int hid, int dtype, void* stream) {
   ATOMNAS_REQUIRE(atomnas_expand_bwd_supported(inp, hid, dtype), "expand_bwd: unsupported shape inp=%d hid=%d dtype=%d", inp, hid, dtype);
   ATOMNAS_REQUIRE(h && c1 && x && wt && gx && dwe && ws && M > 0 && (!e || (c2 && c3)), "expand_bwd: bad arguments");
   ATOMNAS_REQUIRE((h_ss >= M * 16 || (h_ss == 0 && ldh >= hid && ldh % 8 == 0)) && (!e || e_ss >= M * 16 || (e_ss == 0 && lde >= hid && lde % 8 == 0)),
                   "expand_bwd: bad hidden layout");
   if (!e) { c2 = c1; c3 = c1; }   // e == NULL: dE = c1*h (the kernel stages, but does not use, the other two coefficient vectors)
+  ATOMNAS_REQUIRE(!mp || (!e && ldm >= (inp + 31) / 32 * 32 && ldm % 8 == 0), "expand_bwd: the x M term belongs to the e == NULL form (ldm=%d)", ldm);
   ATOMNAS_REQUIRE(ldx >= inp && ldx % 8 == 0 && ldgx >= inp && ldgx % 8 == 0 && (!add || (ldadd >= inp && ldadd % 8 == 0)), "expand_bwd: bad pitch");
   ATOMNAS_REQUIRE(ldw >= (hid + 31) / 32 * 32 && ldw % 8 == 0, "expand_bwd: packed weight pitch %d too small for hid=%d", ldw, hid);
   Operand A{h, ldh, e, lde, h_ss, e_ss, c1, c2, c3, 0};
-  Epilogue ep{gx, ldgx, 0, add, ldadd, nullptr, 0, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, STAT_NONE, 0};
+  Epilogue ep{gx, ldgx, 0, add, ldadd, nullptr, 0, 0, 0, nullptr, nullptr, 0, mp ? vb : nullptr, nullptr, STAT_NONE, 0};
   hipStream_t st = (hipStream_t)stream;
   const int ut = (inp + 15) / 16, nch = xb_nch(hid);
   const bf16_t* W = (const bf16_t*)wt;
   const bf16_t* X = (const bf16_t*)x;
   const int wrows = (inp + 63) / 64 * 64;
 #define XB_CASE(UTV, NCHV) \
-  if (ut == UTV && nch == NCHV) return launch_expand_bwd_cfg<UTV, NCHV>(A, W, ldw, wrows, X, ldx, ep, dwe, ws, ws_floats, M, inp, hid, st);
+  if (ut == UTV && nch == NCHV) return launch_expand_bwd_cfg<UTV, NCHV>(A, W, ldw, wrows, X, ldx, ep, dwe, ws, ws_floats, M, inp, hid, (const bf16_t*)mp, ldm, st);
   XB_CASE(1, 5) XB_CASE(1, 7) XB_CASE(1, 12) XB_CASE(2, 5) XB_CASE(2, 7) XB_CASE(3, 5)
 #undef XB_CASE
   set_error("expand_bwd: no instance for inp=%d hid=%d", inp, hid);

@@ -126,31 +126,47 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const float* __restrict__ w
 //   mp[n][k]      = bf16( sum_c c2_c W[c][n] W[c][k] )          packed for atomnas_pw_gemm_nt ([inp rounded up to 64][ldm], zero padded by the caller)
 //   vb[n]         = sum_c c3_c W[c][n]                          (its bias vector)
 //   dwe[c*inp+k] += c2_c sum_j W[c][j] G[j][k] + c3_c sx[k]
-// One thread per output element, fixed-order sums.
+// Workgroups 0 .. inp-1 own one row n of M (and v[n]): 256 threads = KP columns x S channel subsets, the subsets added in order;
+// the remaining workgroups own 256 elements of dwe each.  Fixed-order sums.
 __global__ __launch_bounds__(256) void k_xb_coeffs(const float* __restrict__ c2, const float* __restrict__ c3, const bf16_t* __restrict__ wexp,
                                                    int ldwe, const float* __restrict__ gram, int ldg, const float* __restrict__ sx,
                                                    int inp, int C, bf16_t* __restrict__ mp, int ldm,
                                                    float* __restrict__ vb, float* __restrict__ dwe) {
-  const long n_m = (long)inp * inp, n_w = (long)C * inp;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_m + inp + n_w; i += (long)gridDim.x * 256) {
-    if (i < n_m) {
-      const int n = (int)(i / inp), k = (int)(i % inp);
-      float a = 0.f;
-      for (int c = 0; c < C; ++c) a += c2[c] * (float)wexp[(long)c * ldwe + n] * (float)wexp[(long)c * ldwe + k];
-      mp[(long)n * ldm + k] = (bf16_t)a;
-    } else if (i < n_m + inp) {
-      const int n = (int)(i - n_m);
-      float a = 0.f;
-      for (int c = 0; c < C; ++c) a += c3[c] * (float)wexp[(long)c * ldwe + n];
-      vb[n] = a;
-    } else {
-      const long e = i - n_m - inp;
-      const int c = (int)(e / inp), k = (int)(e % inp);
-      float a = 0.f;
-      for (int jj = 0; jj < inp; ++jj) a += (float)wexp[(long)c * ldwe + jj] * gram[jj * ldg + k];
-      dwe[e] += c2[c] * a + c3[c] * sx[k];
+  __shared__ float s_p[256 + 64];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < inp) {
+    const int n = blockIdx.x;
+    int KP = 8;
+    while (KP < inp) KP *= 2;   // 8 .. 64
+    const int S = 256 / KP;
+    const int k = tid % KP, sub = tid / KP;
+    float a = 0.f, va = 0.f;
+    for (int c = sub; c < C; c += S) {
+      const float wn = (float)wexp[(long)c * ldwe + n];
+      if (k < inp) a += c2[c] * wn * (float)wexp[(long)c * ldwe + k];
+      if (k == 0) va += c3[c] * wn;
     }
+    s_p[sub * KP + k] = a;
+    if (k == 0) s_p[256 + sub] = va;
+    __syncthreads();
+    if (sub == 0 && k < inp) {
+      float t = s_p[k];
+      for (int q = 1; q < S; ++q) t += s_p[q * KP + k];
+      mp[(long)n * ldm + k] = (bf16_t)t;
+    }
+    if (tid == 0) {
+      float t = s_p[256];
+      for (int q = 1; q < S; ++q) t += s_p[256 + q];
+      vb[n] = t;
+    }
+    return;
   }
+  const long e = (long)(blockIdx.x - inp) * 256 + tid;
+  if (e >= (long)C * inp) return;
+  const int c = (int)(e / inp), k = (int)(e % inp);
+  float a = 0.f;
+  for (int jj = 0; jj < inp; ++jj) a += (float)wexp[(long)c * ldwe + jj] * gram[jj * ldg + k];
+  dwe[e] += c2[c] * a + c3[c] * sx[k];
 }
 
 }  // namespace atomnas
@@ -181,8 +197,7 @@ extern "C" int atomnas_xb_coeffs(const float* c2, const float* c3, const void* w
                                  int inp, int C, void* mp, int ldm, float* vb, float* dwe, void* stream) {
   ATOMNAS_REQUIRE(c2 && c3 && wexp && gram && sx && mp && vb && dwe && inp > 0 && inp <= 64 && C > 0 && ldg >= inp && ldwe >= inp && ldm >= inp,
                   "xb_coeffs: bad arguments");
-  long blocks = ((long)inp * inp + inp + (long)C * inp + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  const long blocks = inp + ((long)C * inp + 255) / 256;
   hipLaunchKernelGGL(k_xb_coeffs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c2, c3, (const bf16_t*)wexp, ldwe, gram, ldg, sx,
                      inp, C, (bf16_t*)mp, ldm, vb, dwe);
   return check_launch("xb_coeffs");

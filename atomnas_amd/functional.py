@@ -206,8 +206,10 @@ _FUSED_EXPAND_SEG = bool(int(os.environ.get("ATOMNAS_FUSED_EXPAND_SEG", "0")))
 _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
 # Expand backward without the raw expand output E (csrc/xbwd.hip): with dE = c1*h + c2*E + c3 and E = x We^T the c2 / c3 terms are
 # inp x inp sized corrections (Gram matrix of x), so the wide GEMMs read h only.  Widest block input that takes this form (0: never;
-# bf16 only).  Beyond 48 the Gram / coefficient launches cost what the second hidden stream did (small maps, measured).
-_EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "48"))
+# bf16 only).  Same-box A/B of the bs-256 step (profiles/r04_expand_bwd_noe_ab.txt): 31.40 ms with the two-stream form everywhere,
+# 31.15 with inp <= 24 (the 112 x 112 and 56 x 56 stages, fused kernel: x M + v added inside it), 31.41 with inp <= 48 (the 28 x 28
+# stage has no fused instance: its extra narrow GEMM and Gram pass cost what the second hidden stream did).
+_EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "24"))
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
 _DP_TENSOR = bool(int(os.environ.get("ATOMNAS_DP_TENSOR", "1")))   # experiment switch: 0 = the BatchNorm-backward prologue in every GEMM tile
 TAIL_TAP = None   # set to a list by tests to receive the dropout keep mask of every tail forward
@@ -433,12 +435,13 @@ def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
     mp = _plan_buffer(pl, "xb_mp", lambda: ops.zeros((inp + 63) // 64 * 64, (inp + 31) // 32 * 32, dtype=T, device=dev))
     vb = torch.empty(pad8(inp), dtype=torch.float32, device=dev)
     ops.xb_coeffs(e2, e3, pl.We_pack, gram, sx, inp, HT, mp, vb, pl.We_grad)
-    gx1 = torch.empty(M, inp, dtype=T, device=dev)
-    ops.gemm_nt(x2d, mp, gx1, M, inp, inp, bias=vb, add=res)
     if inp <= _FUSED_EXPAND_BWD and ops.expand_bwd_supported(inp, HT, T):
-        ops.expand_bwd(h, None, e1, None, None, x2d, pl.WeT_pack, gx1, Gx, pl.We_grad, M, inp, HT)
+        # one pass over h: both gradients, x M + v added inside the kernel
+        ops.expand_bwd(h, None, e1, None, None, x2d, pl.WeT_pack, res, Gx, pl.We_grad, M, inp, HT, mp=mp, vb=vb)
         _join_side()
         return Gx
+    gx1 = torch.empty(M, inp, dtype=T, device=dev)
+    ops.gemm_nt(x2d, mp, gx1, M, inp, inp, bias=vb, add=res)
     zeros = _plan_buffer(pl, "xb_zero%d" % e1.numel(), lambda: ops.zeros(e1.numel(), dtype=torch.float32, device=dev))
     with _Side():
         ops.gemm_tn(x2d, inp, h, HT, pl.We_grad, 1, inp, M, v_mode=PRO_BNRELU, vc1=e1, vc2=zeros, v_relu=0)

@@ -213,8 +213,9 @@ def expand_bwd_workspace(inp, hid, dev):
     return torch.empty(min(1024 * inp * hid, 16 << 20), dtype=torch.float32, device=dev)
 
 
-def expand_bwd(h, e, c1, c2, c3, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None):
-    """Fused backward of the expand convolution (include/atomnas_hip.h): gx = dE * We (+ add), dwe += dE^T x, dE = c1*h + c2*e + c3."""
+def expand_bwd(h, e, c1, c2, c3, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None, mp=None, vb=None):
+    """Fused backward of the expand convolution (include/atomnas_hip.h): gx = dE * We (+ add), dwe += dE^T x, dE = c1*h + c2*e + c3.
+    e = None: dE = c1*h, and with mp / vb (atomnas_xb_coeffs) gx += x M + v."""
     _chk_cuda(h, x, gx, dwe, wt_pack)   # e = None: dE = c1*h (the E-elimination form)
     wt, ldw = wt_pack, wt_pack.stride(0)
     if ws is None:
@@ -222,7 +223,8 @@ def expand_bwd(h, e, c1, c2, c3, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d fusedbwd" % (M, inp, hid))
     call("atomnas_expand_bwd", _p(h), _ld(h), _ss(h), _p(e), _ld(e) if e is not None else 0, _ss(e), _p(c1), _p(c2), _p(c3), _p(x), _ld(x), _p(wt), ldw,
-         _p(add), _ld(add) if add is not None else 0, _p(gx), _ld(gx), _p(dwe), _p(ws), ws.numel(), M, inp, hid, dt_code(x.dtype), _stream())
+         _p(add), _ld(add) if add is not None else 0, _p(gx), _ld(gx), _p(dwe), _p(ws), ws.numel(), _p(mp), mp.stride(0) if mp is not None else 0,
+         _p(vb), M, inp, hid, dt_code(x.dtype), _stream())
 
 
 def project_bwd_supported(oup, hid, dtype):

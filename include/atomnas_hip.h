@@ -119,10 +119,12 @@ int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, long u_ss, const void
 int atomnas_expand_bwd_supported(int inp, int hid, int dtype);
 int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde, long e_ss, const float* c1, const float* c2,
                        const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx, int ldgx,
-                       float* dwe, float* ws, long ws_floats, long M, int inp, int hid, int dtype, void* stream);
+                       float* dwe, float* ws, long ws_floats, const void* mp, int ldm, const float* vb, long M, int inp, int hid, int dtype,
+                       void* stream);
 
-/*   ABI 4: e == NULL (c2, c3 ignored): dE = c1*h -- the expand backward without E below, whose c2 / c3 terms arrive through `add`
- *   and atomnas_xb_coeffs. */
+/*   ABI 4: e == NULL (c2, c3 ignored): dE = c1*h -- the expand backward without E below.  Its c2 / c3 terms are inp x inp sized
+ *   (atomnas_xb_coeffs): mp / vb (optional, with e == NULL only) add x M + v to gx inside the kernel; the dwe terms are added by
+ *   atomnas_xb_coeffs itself. */
 
 /* ---- expand backward without the raw expand output (csrc/xbwd.hip; bf16, inp <= 64 and a multiple of 8).  With the BatchNorm
  *      backward dE = c1*h + c2*E + c3 and E = x We^T (x: the block input [M][ldx], plain layout):

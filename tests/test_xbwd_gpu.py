@@ -62,7 +62,7 @@ def test_gram_and_coeffs(gpu_lib, M, inp, C):
 
 
 def test_expand_bwd_without_e(gpu_lib):
-    """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add, dwe += (c1*h)^T x"""
+    """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add (+ x M + v), dwe += (c1*h)^T x"""
     ops = _ops()
     M, inp, hid = 3000, 24, 432
     if not ops.expand_bwd_supported(inp, hid, BF):
@@ -73,15 +73,25 @@ def test_expand_bwd_without_e(gpu_lib):
     we = torch.randn(hid, inp, generator=g) / inp ** 0.5
     add = torch.randn(M, inp, generator=g)
     c1 = torch.rand(hid, generator=g) + 0.5
+    mm = torch.randn(inp, inp, generator=g) * 0.2
+    mm = mm + mm.t()
+    vb = torch.randn(inp, generator=g)
     hb = ops.Slab.from_plain(h.to(BF).cuda().contiguous(), hid)
     wt = torch.zeros(pad(inp, 64), pad(hid, 32), dtype=BF, device="cuda")
     wt[:inp, :hid] = we.t().to(BF).cuda()
-    gx = torch.empty(M, inp, dtype=BF, device="cuda")
-    dwe = torch.zeros(hid, inp, dtype=torch.float32, device="cuda")
-    ops.expand_bwd(hb, None, cvec(c1), None, None, x.to(BF).cuda().contiguous(), wt, add.to(BF).cuda().contiguous(), gx, dwe, M, inp, hid)
-    torch.cuda.synchronize()
+    mp = torch.zeros(pad(inp, 64), pad(inp, 32), dtype=BF, device="cuda")
+    mp[:inp, :inp] = mm.to(BF).cuda()
+    xb = x.to(BF).cuda().contiguous()
     dE = (c1.double().view(1, -1) * h.to(BF).double()).to(BF).double()   # the kernel rounds dE to the MFMA input type
-    gref = dE @ we.to(BF).double() + add.to(BF).double()
-    assert_close("gx", gx, gref, rtol=1.2e-2, atol=2e-2 * float(gref.abs().max()))
     dref = dE.t() @ x.to(BF).double()
-    assert_close("dwe", dwe, dref, rtol=2e-3, atol=2e-3 * float(dref.abs().max()))
+    for with_m in (False, True):
+        gx = torch.empty(M, inp, dtype=BF, device="cuda")
+        dwe = torch.zeros(hid, inp, dtype=torch.float32, device="cuda")
+        ops.expand_bwd(hb, None, cvec(c1), None, None, xb, wt, add.to(BF).cuda().contiguous(), gx, dwe, M, inp, hid,
+                       mp=mp if with_m else None, vb=cvec(vb) if with_m else None)
+        torch.cuda.synchronize()
+        gref = dE @ we.to(BF).double() + add.to(BF).double()
+        if with_m:
+            gref = gref + x.to(BF).double() @ mm.to(BF).double() + vb.double().view(1, -1)
+        assert_close("gx", gx, gref, rtol=1.2e-2, atol=2e-2 * float(gref.abs().max()))
+        assert_close("dwe", dwe, dref, rtol=2e-3, atol=2e-3 * float(dref.abs().max()))
