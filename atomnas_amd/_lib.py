@@ -59,6 +59,7 @@ SIGNATURES = {
 NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version": (i32, []),
              "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32]),
              "atomnas_project_bwd_supported": (i32, [i32, i32, i32]),
+             "atomnas_project_bwd_dp_supported": (i32, [i64, i32, i32, i32, i32, i64, i32, i64, i32, i32]),
              "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32])}
 
 ABI_VERSION = 4   # include/atomnas_hip.h ATOMNAS_ABI_VERSION

@@ -17,10 +17,26 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
+# The depthwise kernels issue asynchronous loads from inline asm and wait for them by hand (csrc/dwconv_cw.hip cw_row_issue): whether the
+# compiler leaves those registers alone between issue and wait was checked on the ISA of this toolchain (tools/check_asm_waits.py,
+# profiles/r04_asm_wait_check.txt).  Another hipcc gets a warning: re-run the check before trusting its build.
+HIPCC_VALIDATED = "HIP version: 7.2"
+_warned = [False]
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
         raise RuntimeError("hipcc not found; the AtomNAS HIP kernels cannot be built")
+    if not _warned[0]:
+        _warned[0] = True
+        try:
+            ver = subprocess.run([exe, "--version"], capture_output=True, text=True).stdout
+            if HIPCC_VALIDATED not in ver:
+                sys.stderr.write("atomnas_amd.build: hipcc is not the validated %s toolchain (%s): run `python tools/check_asm_waits.py "
+                                 "atomnas_amd/csrc/dwconv_cw.hip atomnas_amd/csrc/dwconv.hip` on its output\n" % (HIPCC_VALIDATED, ver.splitlines()[0] if ver else "?"))
+        except OSError:
+            pass
     return exe
 
 
@@ -32,6 +48,18 @@ def _digest(path):
     h = hashlib.sha1()
     for p in [path, os.path.join(CSRC, "common.h")]:
         with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def sources_digest():
+    """sha1 over every kernel source, common.h and the compiler flags: identifies the library a measurement belongs to
+    (profiles/*_pmc_*.json carry it as `lib_src_sha`; bench.py drops PMC-derived figures taken on another build)"""
+    h = hashlib.sha1()
+    for p in sources() + [os.path.join(CSRC, "common.h")]:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode())
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()

@@ -185,6 +185,7 @@ int check_launch(const char* what);
 // once (measured: a partial second round of workgroups cost the depthwise kernels up to 1.8x).  Host-side queries only,
 // cached per (kernel, dynamic LDS size): nothing is enqueued, so launches stay capturable into a hipGraph.
 int num_cus();
+size_t max_lds_bytes();   // LDS bytes per workgroup on the current device (160 KiB on gfx950), queried
 int resident_per_cu_raw(const void* kern, int threads, size_t lds);
 template <typename KernelT>
 static inline int resident_per_cu(KernelT kern, int threads, size_t lds) {

@@ -889,7 +889,7 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   g.RP = lds_pitch(g.LW, cb);
   const int nslabs = (cpad + cb - 1) / cb;
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 8 * cb) * sizeof(float) + (DW_FWD_STAGE ? (size_t)g.TH * g.TW * cb * sizeof(T) : 0);
-  ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
+  ATOMNAS_REQUIRE(lds <= max_lds_bytes(), "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env = getenv("ATOMNAS_DW_FWD_PERCU") ? atoi(getenv("ATOMNAS_DW_FWD_PERCU")) : 0;
   const int cap = cap_env ? cap_env : 8;
 #define FWD_CASE(CBV, TMV)                                                                                                   \
@@ -945,7 +945,7 @@ static int launch_bwd_sw(const void* gup, int ldg, long gss, const void* yraw, i
   const int pf = (lmaxb * lmaxw * (cb / 8) + 255) / 256;
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2) + 3 * (size_t)cb) * sizeof(float) +
                      (size_t)2 * tm * tm * cb * sizeof(T) + ((DW_DMA && sizeof(T) == 2) ? (size_t)2 * pf * 256 * 16 : 0);
-  ATOMNAS_REQUIRE(lds <= 160 * 1024, "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
+  ATOMNAS_REQUIRE(lds <= max_lds_bytes(), "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
   static const int cap_env2 = getenv("ATOMNAS_DW_BWD_PERCU") ? atoi(getenv("ATOMNAS_DW_BWD_PERCU")) : 0;
   const int cap = cap_env2 ? cap_env2 : 8;
 #define BWD_CASE(CBV, TMV)                                                                                                \

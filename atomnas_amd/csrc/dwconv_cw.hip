@@ -1530,7 +1530,7 @@ static int cw_launch_bwd(const void* gup, long gss, const void* yraw, long yrss,
   if (!cw_geometry(g, N, H, W, C, K)) return -1;
   const int nw = cw_nw();
   const size_t lds = cw_lds<T>(g, nw);
-  if (lds > 160 * 1024) return -1;
+  if (lds > max_lds_bytes()) return -1;
   // waves per SIMD the instances are compiled for: half-slab workgroups 3 (k = 3: 139 registers) or 2; whole-slab workgroups 2
   constexpr int WPS4 = K == 3 ? 3 : 2;
 #define CW_BWD(KERN, AMV, NWV, WPSV)                                                                                        \
@@ -1558,7 +1558,7 @@ static int cw_launch_fwd(const void* x, long xss, const float* sc, const float* 
   if (!cw_geometry(g, N, H, W, C, K)) return -1;
   const int nw = cw_nw();
   const size_t lds = cw_lds<T>(g, nw);
-  if (lds > 160 * 1024) return -1;
+  if (lds > max_lds_bytes()) return -1;
 #define CW_FWD(AMV, NWV)                                                                                                    \
   {                                                                                                                         \
     auto kern = k_dwf_cw<T, K, AMV, NWV, 4>;                                                                                \
@@ -1582,7 +1582,7 @@ static int cw2_launch_bwd(const void* gup, long gss, const void* yraw, long yrss
   CwGeom g;
   if (!cw2_geometry(g, N, H, W, C, K)) return -1;
   const size_t lds = cw_lds<T>(g, 4);
-  if (lds > 160 * 1024) return -1;
+  if (lds > max_lds_bytes()) return -1;
 #define CW2_BWD(AMV)                                                                                                        \
   {                                                                                                                         \
     auto kern = k_dwb_cw2<T, K, AMV, 4, 2>;                                                                                 \
@@ -1606,7 +1606,7 @@ static int xdw_launch_bwd(const void* gup, long gss, const void* yraw, long yrss
   CwGeom g;
   if (!cw_geometry(g, N, H, W, C, K)) return -1;
   const size_t lds = (size_t)4 * g.plane * sizeof(f32x2) + (size_t)4 * g.TPIXp * (sizeof(f32x2) + sizeof(unsigned)) + 48 * sizeof(float);
-  if (lds > 160 * 1024) return -1;
+  if (lds > max_lds_bytes()) return -1;
   constexpr int WPSV = (K == 3 && KC == 1) ? 3 : 2;
 #define XDW_BWD(AMV)                                                                                                          \
   {                                                                                                                           \
@@ -1641,7 +1641,7 @@ int xdw_cw_bwd_supported(int N, int H, int W, int C, int k) {
   CwGeom g;
   if (!(k == 3 || k == 5 || k == 7) || C % 16 || !cw_geometry(g, N, H, W, C, k)) return 0;
   const size_t lds = (size_t)4 * g.plane * sizeof(f32x2) + (size_t)4 * g.TPIXp * (sizeof(f32x2) + sizeof(unsigned)) + 48 * sizeof(float);
-  return lds <= 160 * 1024 ? 1 : 0;
+  return lds <= max_lds_bytes() ? 1 : 0;
 }
 
 #endif   // ATOMNAS_EXPERIMENTAL_XDW
@@ -1709,10 +1709,10 @@ extern "C" int atomnas_dwconv_cw_supported(int N, int H, int W, int C, int k, in
     if (!(cw_mode() & (dir ? 4 : 8)) || dir == 0) return 0;   // stride 2: backward only so far
     if (!cw2_geometry(g, N, H, W, C, k)) return 0;
     const size_t lds = dtype == DT_F32 ? cw_lds<float>(g, 4) : cw_lds<bf16_t>(g, 4);
-    return lds <= 160 * 1024 ? 1 : 0;
+    return lds <= max_lds_bytes() ? 1 : 0;
   }
   if (stride != 1 || !(cw_mode() & (dir ? 1 : 2))) return 0;
   if (!cw_geometry(g, N, H, W, C, k)) return 0;
   const size_t lds = dtype == DT_F32 ? cw_lds<float>(g, cw_nw()) : cw_lds<bf16_t>(g, cw_nw());
-  return lds <= 160 * 1024 ? 1 : 0;
+  return lds <= max_lds_bytes() ? 1 : 0;
 }

@@ -609,7 +609,7 @@ extern "C" int atomnas_xdw_supported(int N, int H, int W, int inp, int C, int k,
   if (!xd_geometry(g, N, H, W, C, inp, k)) return 0;
   if (xd_gpw(g) > (inp <= 32 ? 7 : 5)) return 0;
   if (!xdw_cw_bwd_supported(N, H, W, C, k)) return 0;
-  return xd_lds_fwd(g) <= 160 * 1024 ? 1 : 0;
+  return xd_lds_fwd(g) <= max_lds_bytes() ? 1 : 0;
 }
 
 // Forward of expand 1x1 + BatchNorm + activation + depthwise k x k of one branch segment (models/mobilenet_base.py:316-336):

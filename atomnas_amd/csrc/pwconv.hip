@@ -2699,6 +2699,18 @@ extern "C" int atomnas_project_bwd_supported(int oup, int hid, int dtype) {
   return dtype == DT_BF16 && oup >= 1 && oup <= 96 && hid >= 96 && hid >= 2 * oup && hid <= NT_MAX_STAT;
 }
 
+// 1 when atomnas_project_bwd takes its dP form (p = c1 = c2 = c3 = NULL: g is the differentiated BatchNorm output) for these layouts:
+// the streaming kernel's conditions (nt_st_kind: switch, 2 GB per 64-channel chunk, 4096 tiles per statistics row).  Callers gate the
+// form on this query and use the prologue form otherwise.
+extern "C" int atomnas_project_bwd_dp_supported(long M, int oup, int hid, int ldg, int ldz, long z_ss, int ldgh, long gh_ss, int stat_rows,
+                                                int dtype) {
+  if (!atomnas_project_bwd_supported(oup, hid, dtype) || oup % 8 != 0 || oup > 64 || M <= 0 || stat_rows <= 0) return 0;
+  static float dummy;
+  Operand A{&dummy, ldg, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+  Epilogue ep{&dummy, ldgh, 0, nullptr, 0, &dummy, ldz, gh_ss, z_ss, nullptr, nullptr, ACT_RELU, nullptr, &dummy, STAT_Z, stat_rows};
+  return nt_st_kind(PRO_NONE, A, ep, M, hid, oup) == ST_MASK ? 1 : 0;
+}
+
 // Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) in ONE pass over the raw depthwise output:
 //   dP = c1*g + c2*p + c3   (BatchNorm backward of the block-output BN; g, p: [M, oup])
 //   gh[M, hid] = act'(z*zscale + zshift) * (dP * Wp)            -- gradient wrt the raw depthwise-BN output, masked

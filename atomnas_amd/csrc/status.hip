@@ -36,6 +36,22 @@ int num_cus() {
   return n;
 }
 
+// LDS bytes one workgroup may use on the current device (gfx950: 160 KiB), queried once; 64 KiB -- what every CDNA part has -- when
+// the query fails.  Shapes that need more take the tile kernels / are reported as unsupported instead of failing at launch.
+size_t max_lds_bytes() {
+  static size_t v = 0;
+  if (v == 0) {
+    int dev = 0, b = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&b, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && b > 0)
+      v = (size_t)b;
+    else {
+      (void)hipGetLastError();
+      v = 64 * 1024;
+    }
+  }
+  return v;
+}
+
 int resident_per_cu_raw(const void* kern, int threads, size_t lds) {
   static std::mutex mu;
   static std::unordered_map<size_t, int> cache;
@@ -54,7 +70,7 @@ int resident_per_cu_raw(const void* kern, int threads, size_t lds) {
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) {
     (void)hipGetLastError();
-    nb = (int)(160 * 1024 / (lds + 1024));
+    nb = (int)(max_lds_bytes() / (lds + 1024));
     if (nb > 2) nb = 2;
     if (nb < 1) nb = 1;
   }

@@ -334,7 +334,7 @@ def block_backward(pl, sv, G):
         ops.se_bwd_gate(dS, D, bD.scale, bD.shift, int(act), se["gate"], se["pooled"], pl.cmap, pl.se_w1, pl.se_w2, se["hpre"], dgate, dz2,
                         dz1, dpooled, pl.se_dw1, pl.se_db1, pl.se_dw2, pl.se_db2, N, HWo, HT, pl.total, pl.se_hid)
         ops.se_bwd_apply(dS, D, bD.scale, bD.shift, int(act), se["gate"], dpooled, g, st2D.t, M2, HWo, HT, stat_rows=st2D.rows)
-    elif fused_pb and _DP_TENSOR and T == torch.bfloat16 and pl.oup % 8 == 0 and pl.oup <= 64 and (isinstance(g, Slab) or HT % 8 == 0):
+    elif fused_pb and _DP_TENSOR and ops.project_bwd_dp_supported(M2, pl.oup, HT, G, D, g, st2D.rows):
         # dP once (a narrow tensor), then the streaming form of the fused kernel: no prologue, nothing behind a branch
         dPf = torch.empty(M2, pl.oup, dtype=T, device=dev)
         ops.bnbwd_apply(G, Pr, p1, p2, p3, dPf, M2, pl.oup)

@@ -231,6 +231,12 @@ def project_bwd_supported(oup, hid, dtype):
     return bool(_lib.load().atomnas_project_bwd_supported(int(oup), int(hid), dt_code(dtype)))
 
 
+def project_bwd_dp_supported(M, oup, hid, g, z, gh, stat_rows):
+    """whether atomnas_project_bwd takes its dP form (g = the differentiated BatchNorm output) for these tensors"""
+    return bool(_lib.load().atomnas_project_bwd_dp_supported(int(M), int(oup), int(hid), _ld(g), _ld(z), _ss(z), _ld(gh), _ss(gh), int(stat_rows),
+                                                             dt_code(g.dtype)))
+
+
 def project_bwd(g, p, c1, c2, c3, wpt_pack, z, zscale, zshift, act, gh, stats, dwp, si, sj, M, oup, hid, stat_rows=None, ws=None):
     """Fused backward of the projection (include/atomnas_hip.h): masked input gradient gh with the BN-backward statistics, and
     dwp[o*si + n*sj] += dP^T act(bn(z)), from one pass over z.  p = c1 = c2 = c3 = None: g is already dP (bnbwd_apply), the

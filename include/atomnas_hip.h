@@ -151,6 +151,8 @@ int atomnas_xb_coeffs(const float* c2, const float* c3, const void* wexp, int ld
  *   wpt = Wp^T packed by atomnas_pack_weights ([hid padded to 64][ldw >= oup rounded up to 32]); ws: per-row-range partials of the
  *   weight gradient (oup*hid floats each).  Replaces atomnas_pw_gemm_nt(BNBWD, mask, STAT_Z) + atomnas_pw_gemm_tn. */
 int atomnas_project_bwd_supported(int oup, int hid, int dtype);
+/* 1 when the dP form (p = c1 = c2 = c3 = NULL) is available for these pitches / slab strides; otherwise use the prologue form */
+int atomnas_project_bwd_dp_supported(long M, int oup, int hid, int ldg, int ldz, long z_ss, int ldgh, long gh_ss, int stat_rows, int dtype);
 int atomnas_project_bwd(const void* g, int ldg, const void* p, int ldp, const float* c1, const float* c2, const float* c3, const void* wpt,
                         int ldw, const void* z, int ldz, long z_ss, const float* zscale, const float* zshift, int act, void* gh, int ldgh,
                         long gh_ss, float* stats, int stat_rows, float* dwp, long si, long sj, float* ws, long ws_floats, long M, int oup,
@@ -178,7 +180,8 @@ int atomnas_bn_apply(const void* x, int ldx, const float* scale, const float* sh
                      int ldy, long M, int C, int dtype, void* stream);
 /* y = c1*g + c2*x + c3 per channel (plain layouts): the gradient through a training-mode BatchNorm as a tensor, i.e. what the
  *   PRO_BNBWD prologue of the GEMMs computes per tile (torch.nn.BatchNorm2d backward behind models/mobilenet_base.py:338-339).
- *   Used where one narrow gradient feeds many GEMM tiles (ABI 3). */
+ *   Used where one narrow gradient feeds many GEMM tiles (ABI 3).  C must be a multiple of 8 (whole 8-channel groups are moved: the
+ *   coefficient vectors are read in groups of 8) and g, x, y, c1, c2, c3 16-byte aligned. */
 int atomnas_bnbwd_apply(const void* g, int ldg, const void* x, int ldx, const float* c1, const float* c2, const float* c3, void* y,
                         int ldy, long M, int C, int dtype, void* stream);
 /* pooled[n][c] = dropout(mean_hw act(x*scale+shift)): last ConvBNReLU activation + AvgPool2d + Dropout,

@@ -277,3 +277,15 @@ def test_tools_and_entry_points_compile():
     assert len(files) > 10
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_asm_loads_are_waited_for_before_use():
+    """ISA check of the inline-asm asynchronous loads of the depthwise kernels (tools/check_asm_waits.py): no instruction may touch a
+    register between the load that writes it and the manual s_waitcnt.  Assembling the two files takes ~3 minutes the first time (cached
+    by source digest afterwards), so the test runs on request: ATOMNAS_ISA_CHECK=1."""
+    import subprocess
+    if not os.environ.get("ATOMNAS_ISA_CHECK"):
+        pytest.skip("set ATOMNAS_ISA_CHECK=1 (about 3 minutes of hipcc -S on first use)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_waits.py"), os.path.join(ROOT, "atomnas_amd", "csrc", "dwconv_cw.hip"),
+                        os.path.join(ROOT, "atomnas_amd", "csrc", "dwconv.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -34,5 +34,8 @@ for fam, d in agg.items():
         r["mfma_util"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["duration_ns"] * 1e-9 * 2.4e9 * 1024)
         r["tflops"] = d["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / (d["duration_ns"] * 1e-9) / 1e12
     out[fam] = r
-print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES over "
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from atomnas_amd import build as _build  # noqa: E402
+print(json.dumps({"lib_src_sha": _build.sources_digest(), "source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES over "
                             "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline` (its own pass)", "families": out}, indent=1))
