@@ -877,7 +877,7 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   // r03: for slab-major tensors whole slabs win on every stride-2 shape of the step since the prefetch became branch-free (8-channel
   // workgroups read half of every 32-byte slab row; tools/dwbench.py fwd, ATOMNAS_DW_FWD_CB=16 vs the rule: 1.55 -> 1.36 ms)
   int cb_rule = 16;
-  const bool whole_slabs = xss != 0 && sizeof(T) == 2;   // (bf16 only: the fp32 instances keep the round-2 rule they are tested with)
+  const bool whole_slabs = xss != 0;
   if (S == 2 && C <= 96 && !whole_slabs) cb_rule = 8;
   else if (S == 2 && K >= 5 && H <= 56 && !whole_slabs) cb_rule = 8;
   else if (S == 1 && C <= 32) cb_rule = 32;

@@ -147,7 +147,62 @@ TINY = dict(num_classes=10, input_size=64, input_channel=16, last_channel=64, wi
                                        [6, 40, 1, 2, [3, 5, 7]]])
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_forward_backward_fp32_against_measured_fp32_noise(gpu_lib):
+    """Whole tiny network, fp32 storage, all gradients against the float64 oracle -- with a bound derived from what fp32 arithmetic itself
+    does to this network instead of a fixed one.  A random-init ReLU network turns a 1e-7 forward difference into a 1e-3 ... 1e-2
+    gradient difference whenever one pre-activation near zero lands on the other side ("mask flip"): the oracle run in fp32 torch
+    arithmetic shows exactly that against its own float64 run on 4 of 8 batches (profiles/r04_fp32_flip_noise.txt: up to 1.45e-2, else
+    4e-6), and which batch flips differs between two equally valid summation orders.  So, per batch: the forward (logits, loss) must be
+    tight; the gradients must be within 10x the fp32 oracle's own distance to float64 (floor 2e-5) unless a flip is in play, in which
+    case 5e-2 (3x the largest measured flip); and at least two of the three batches must be flip-free for the HIP path -- exact
+    arithmetic parity is demonstrated there.  (Round 3 kept a slower slab rule for the fp32 depthwise instances because one batch read
+    9e-4 against a fixed 1e-4: that was a flip, not the rule -- the rule is gone.)"""
+    from atomnas_amd.models import mobilenet_supernet as ms
+    from atomnas_amd.utils import optim as aopt
+    clean = 0
+    for seed in (3, 6, 7):
+        model = ms.Model(**TINY)
+        model.set_compute_dtype(torch.float32)
+        _randomize(model, 5)
+        sd0 = _sd64(model)
+        spec = orc.spec_from_model(model)
+        g = torch.Generator().manual_seed(seed)
+        N = 6
+        x = torch.randn(N, 3, 64, 64, generator=g)
+        y = torch.randint(0, 10, (N,), generator=g)
+        model.cuda().train()
+        logits = model(x.cuda())
+        loss = aopt.CrossEntropyLabelSmooth(10, 0.1, reduction="none")(logits, y.cuda()).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+
+        def oracle(dt):
+            work = {k: (v.clone().to(dt).requires_grad_(True) if (v.is_floating_point() and "running" not in k)
+                        else (v.to(dt) if v.is_floating_point() else v)) for k, v in sd0.items()}
+            ref = orc.model_forward(x.to(dt), work, spec, True, {}, q=orc.NoQuant)
+            rl = orc.ce_label_smooth(ref, y, 0.1).mean()
+            rl.backward()
+            return ref.detach().double(), float(rl.detach()), {n: work[n].grad.double() for n, _ in model.named_parameters()}
+        r64, l64, g64 = oracle(torch.float64)
+        _, _, g32 = oracle(torch.float32)
+        rel = lambda a, b: float((a - b).norm() / max(float(b.norm()), 1e-30))
+        assert rel(logits.double().cpu(), r64) < 2e-5 and abs(float(loss.detach()) - l64) < 1e-5
+        gnorm = max(float(v.norm()) for v in g64.values())
+        hip = ora = 0.0
+        for name, p in model.named_parameters():
+            if float(g64[name].norm()) > 1e-6 * gnorm:
+                hip = max(hip, rel(p.grad.double().cpu(), g64[name]))
+                ora = max(ora, rel(g32[name], g64[name]))
+            else:   # a bias in front of another BatchNorm: the true gradient is zero, both sides hold rounding noise
+                assert float(p.grad.abs().max()) < 1e-5 * gnorm, (name, float(p.grad.abs().max()), gnorm)
+        assert hip < 5e-2, (seed, hip, ora)
+        if hip < 1e-4:
+            clean += 1
+            assert hip <= 10 * max(ora, 2e-6) or ora > 1e-4, (seed, hip, ora)
+    assert clean >= 2, clean
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
 def test_model_forward_backward(gpu_lib, dtype):
     from atomnas_amd.models import mobilenet_supernet as ms
     from atomnas_amd.utils import optim as aopt

@@ -265,3 +265,93 @@ def test_bench_gpus_2_launches_itself(gpu_lib):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "8", "--steps", "1"],
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "must agree" in (bad.stdout + bad.stderr)
+
+
+# --------------------------------------------------------------------------------------------------- real RCCL, >= 2 GPUs
+def _rccl_worker(rank, world, port, out):
+    """One rank per GPU, backend "nccl" (RCCL over xGMI): the bucketed all-reduce issued from inside backward is captured into the
+    step graph; the reduced arena is the one-shot all-reduce bit for bit; parameters stay rank-identical over three steps."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from atomnas_amd import engine
+        from atomnas_amd.models import mobilenet_base as mb
+        from atomnas_amd.models import mobilenet_supernet as ms
+        from atomnas_amd.utils import model_profiling as mp_
+        from atomnas_amd.utils import optim as aopt
+        from atomnas_amd.utils import prune as aprune
+        from atomnas_amd.utils import rmsprop
+        torch.manual_seed(7)
+        model = ms.Model(num_classes=10, input_size=64, input_channel=16, last_channel=64, dropout_ratio=0.0, batch_norm_momentum=0.01,
+                         batch_norm_epsilon=1e-3, active_fn="nn.ReLU",
+                         inverted_residual_setting=[[1, 8, 1, 1, [3]], [6, 16, 2, 2, [3, 5, 7]], [6, 24, 1, 2, [3, 5, 7]], [6, 32, 1, 2, [3, 5, 7]],
+                                                    [6, 40, 1, 2, [3, 5, 7]]])
+        model.apply(mb.init_weights_mnas)
+        mp_.model_profiling(model, 64, 64, verbose=False)
+        model.cuda().train()
+        pinfo = aprune.get_bn_to_prune(model, {'bn_prune_filter': 'expansion_only_skip_expand1'}, verbose=False)
+        opt = rmsprop.RMSprop(model.parameters(), lr=0.01, alpha=0.9, momentum=0.9, eps=1e-3, eps_inside_sqrt=True)
+        ema = aopt.ExponentialMovingAverage(0.99)
+        for n, p in model.named_parameters():
+            ema.register(n, p)
+        for n, b in model.named_buffers():
+            if "running" in n:
+                ema.register(n, b)
+        ts = engine.TrainStep(model, opt, ema, pinfo, batch_size=8, image_size=64, use_graph=True, world_size=world)
+        g = torch.Generator().manual_seed(100 + rank)
+        ts.set_batch(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 10, (8,), generator=g).cuda())
+        for _ in range(3):
+            ts.step(lr=0.003, rho=1e-4)
+        torch.cuda.synchronize()
+        assert ts.comm_mode == "graph", ts.comm_mode      # (i) the collectives were captured into the step graph
+        # (ii) the bucketed reduction issued from inside backward == ONE all-reduce of the whole arena over the same per-rank gradients
+        ts._fwd_bwd()
+        torch.cuda.synchronize()
+        ref = ts.mgr.G.detach().clone()
+        dist.all_reduce(ref)
+        ts._fwd_bwd_overlapped()
+        torch.cuda.synchronize()
+        assert len(ts._buckets) >= 1 and ts._fired == len(ts._buckets)
+        assert torch.equal(ts.mgr.G, ref), float((ts.mgr.G - ref).abs().max())
+        # (iii) rank-identical parameters although every rank saw its own batch
+        mine = ts.mgr.P.detach().clone()
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        assert all(torch.equal(q, parts[0]) for q in parts), "ranks diverged: max diff %g" % float((parts[0] - parts[-1]).abs().max())
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (real RCCL between devices); the 1-GPU box skips")
+def test_rccl_two_devices_graph_step(gpu_lib):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(out.keys()) == list(range(world))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (real RCCL between devices); the 1-GPU box skips")
+def test_bench_gpus_2_rccl(gpu_lib):
+    """`python bench.py --gpus 2` as the driver's scaling run starts it (one rank per GPU, RCCL): rccl_ranks == 2, graph-mode collectives."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "32", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["comm_backend"] == "nccl" and j["comm_mode"] == "graph", j
+    assert len(j["rank_ms_per_step"]) == 2 and j["value"] > 0

@@ -82,6 +82,45 @@ def test_full_size_c_supernet_bf16_bs16_blockwise(gpu_lib):
         assert gp_e < 5e-3 and gp_cos > 0.9999, (name, gp_e, gp_cos)
 
 
+def _blockwise(model, n_blocks_min):
+    import parity_diag as pd
+    model.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(12)
+    N = 8
+    x, y = torch.randn(N, 3, 224, 224, generator=g), torch.randint(0, 1000, (N,), generator=g)
+    rows, _ = pd.teacher_forced(model, x, y, 1000, 0.0)
+    assert len(rows) >= n_blocks_min
+    for name, out_e, gin_e, gp_e, gp_cos in rows:
+        assert out_e < 1.5e-3, (name, out_e)
+        assert gin_e < 6e-3, (name, gin_e)
+        assert gp_e < 5e-3 and gp_cos > 0.9999, (name, gp_e, gp_cos)
+    return rows
+
+
+def test_cfg3_shrunk_atomnas_a_bf16_blockwise(gpu_lib):
+    """BASELINE config 3 in bf16, numerically: the AtomNAS-A supernet after the forced 30 % shrink (tests/test_configs_gpu.py's recipe:
+    hidden widths like 1, 2, 3, 13 ..., a dropped middle branch, an empty block -- where slab padding, the channel-pair fall-backs and the
+    narrow / column-stationary GEMM dispatch change), every block alone against `Bf16Storage` on the oracle's own input and output
+    gradient.  Measured worst (profiles/r04_parity_diag_cfg3_cfg5.txt): output 3.8e-4, input gradient 2.6e-3, parameter gradients
+    1.7e-3, cosine 0.999999 -- the bounds of the un-shrunk network hold unchanged."""
+    import parity_diag as pd
+    model = pd.shrunk_atomnas_a()
+    blocks = list(model.features.children())[1:-2]
+    widths = [c for b in blocks for c in b.channels]
+    assert any(len(b.channels) == 0 for b in blocks) and any(len(b.channels) == 2 for b in blocks)    # empty block, dropped branch
+    assert any(c % 16 for c in widths) and min(widths) <= 8                                            # ragged, very narrow segments
+    _blockwise(model, 20)
+
+
+def test_cfg5_atomnas_c_plus_bf16_blockwise(gpu_lib):
+    """BASELINE config 5 in bf16, numerically: full-size AtomNAS-C+ (fused blocks, Squeeze-and-Excitation, Swish), every block alone
+    against `Bf16Storage`.  Measured worst: output 5.2e-4, input gradient 2.3e-3, parameter gradients 9.4e-4, cosine 1.000000."""
+    import parity_diag as pd
+    model = pd.atomnas_c_plus()
+    assert all(hasattr(b, "depth_ops") for b in list(model.features.children())[1:-2])   # fused blocks
+    _blockwise(model, 22)
+
+
 def test_full_size_c_supernet_bf16_bs16_end_to_end(gpu_lib):
     """Same network end to end with dropout 0.2 (the kernel's mask fed to the oracle): what survives 22 blocks of random-init chaos.
     Measured: loss 6.918 vs 6.929, logits relative L2 8.0e-2, first block 1.4e-5, last block 0.29."""

@@ -63,7 +63,8 @@ def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32)
     training forward / backward once; then every block of the HIP model is run ALONE on the oracle's input of that block and on the
     oracle's gradient of its output.  Returns rows (name, out rel-L2, input-grad rel-L2, param-grad rel-L2, param-grad cosine)."""
     from atomnas_amd import runtime
-    sd0 = collections.OrderedDict((k, v.detach().clone().to(oracle_dtype) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items())
+    sd0 = collections.OrderedDict((k, v.detach().cpu().clone().to(oracle_dtype) if v.is_floating_point() else v.detach().cpu().clone())
+                                  for k, v in model.state_dict().items())
     spec = orc.spec_from_model(model)
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
     t0 = time.perf_counter()
@@ -97,6 +98,69 @@ def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32)
                      rel_l2(xin.grad.double().cpu(), feats[i].grad.double()), rel_l2(pg, pr),
                      float(torch.dot(pg, pr) / (pg.norm() * pr.norm()))))
     return rows, oracle_s
+
+
+def shrunk_atomnas_a(seed=7):
+    """BASELINE config 3 as tests/test_configs_gpu.py builds it: the full-size AtomNAS-A supernet with a seeded 30 % of its atoms (a whole
+    middle branch of one block and a whole block among them) forced dead, then train.shrink_model -- ragged hidden widths, a dropped
+    branch, an empty block.  Returns the shrunk model (fp32 storage, on the GPU)."""
+    import train as T
+    from atomnas_amd import configs, runtime
+    from atomnas_amd.models import mobilenet_base as mb
+    from atomnas_amd.models import mobilenet_supernet as ms
+    from atomnas_amd.utils import config, model_profiling as mp, optim as aopt, prune as aprune, rmsprop
+    from test_block_gpu import _randomize
+    torch.manual_seed(seed)
+    model = ms.Model(**dict(configs.model_kwparams("atomnas_a_supernet"), input_size=224))
+    model.set_compute_dtype(torch.float32)
+    model.apply(mb.init_weights_mnas)
+    _randomize(model, 9)
+    mp.model_profiling(model, 224, 224, verbose=False)
+    model.cuda().train()
+    pinfo = aprune.get_bn_to_prune(model, {"bn_prune_filter": "expansion_only_skip_expand1"}, verbose=False)
+    opt = rmsprop.RMSprop(model.parameters(), lr=0.002, alpha=0.9, momentum=0.9, eps=1e-3, eps_inside_sqrt=True)
+    ema = aopt.ExponentialMovingAverage(0.99)
+    for n, p in model.named_parameters():
+        ema.register(n, p)
+    for n, b in model.named_buffers():
+        if "running" in n:
+            ema.register(n, b)
+    mgr = runtime.manager_of(model)
+    mgr.attach_optimizer(opt)
+    opt._mgr = mgr
+    ema.attach(mgr)
+    mgr.ensure()
+    g = torch.Generator().manual_seed(11)
+    table = dict(model.named_parameters())
+    with torch.no_grad():
+        for name in pinfo.weight:
+            w = table[name]
+            dead = torch.rand(w.numel(), generator=g) < 0.3
+            if name.startswith("features.3.ops.1.") or name.startswith("features.5."):
+                dead[:] = True
+            w[dead.cuda()] = 0.0
+            ema.average(name)[dead.cuda()] = 0.0
+
+    class F(dict):
+        __getattr__ = dict.__getitem__
+    config.FLAGS.bind(F(image_size=224, use_distributed=False))
+    wrapper = torch.nn.Module()
+    wrapper.module = model
+    T.shrink_model(wrapper, ema, opt, pinfo, 1e-3, ema_only=False)
+    return model
+
+
+def atomnas_c_plus():
+    """BASELINE config 5: the searched AtomNAS-C architecture with SE (ratio 0.5), Swish and fused blocks, full size, random init"""
+    from atomnas_amd import configs
+    from atomnas_amd.models import mobilenet_base as mb
+    from atomnas_amd.models import searched_network as sn
+    from test_block_gpu import _randomize
+    torch.manual_seed(5)
+    model = sn.Model(**dict(configs.searched_kwparams("atomnas_c_plus"), input_size=224, dropout_ratio=0.0))
+    model.apply(mb.init_weights_mnas)
+    _randomize(model, 15)
+    return model
 
 
 def rel_l2(a, b):
@@ -172,6 +236,20 @@ def main():
         out("    %-12s out rel-L2 %.3e   input-grad rel-L2 %.3e   param-grad rel-L2 %.3e cosine %.6f" % r)
     out("    worst: out %.3e  input-grad %.3e  param-grad %.3e  min cosine %.6f" % (max(r[1] for r in rows), max(r[2] for r in rows),
         max(r[3] for r in rows), min(r[4] for r in rows)))
+    # (e) / (f): the same per-block statement for the other bf16 configurations (their bf16 legs were property-only)
+    g = torch.Generator().manual_seed(12)
+    N2 = int(os.environ.get("PARITY_N2", "8"))
+    x2, y2 = torch.randn(N2, 3, 224, 224, generator=g), torch.randint(0, 1000, (N2,), generator=g)
+    for tag, make in (("(e) AtomNAS-A supernet after the forced 30 %% shrink (ragged widths, dropped branch, empty block)", shrunk_atomnas_a),
+                      ("(f) full-size AtomNAS-C+ (fused blocks, SE, Swish)", atomnas_c_plus)):
+        model = make()
+        model.set_compute_dtype(torch.bfloat16)
+        rows, osec = teacher_forced(model, x2, y2, 1000, 0.0)
+        out("%s bf16 N=%d, every block alone on the oracle's input / output gradient (oracle fp32, %.1f s):" % (tag, N2, osec))
+        for r in rows:
+            out("    %-12s out rel-L2 %.3e   input-grad rel-L2 %.3e   param-grad rel-L2 %.3e cosine %.6f" % r)
+        out("    worst: out %.3e  input-grad %.3e  param-grad %.3e  min cosine %.6f" % (max(r[1] for r in rows), max(r[2] for r in rows),
+            max(r[3] for r in rows), min(r[4] for r in rows)))
     with open(os.path.join(ROOT, "gpurun_out", "parity_diag.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
 
