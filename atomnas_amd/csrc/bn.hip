@@ -412,8 +412,8 @@ extern "C" int atomnas_bnbwd_apply(const void* g, int ldg, const void* x, int ld
                                    void* y, int ldy, long M, int C, int dtype, void* stream) {
   ATOMNAS_REQUIRE(g && x && y && c1 && c2 && c3 && M > 0 && C > 0, "bnbwd_apply: bad arguments");
   ATOMNAS_REQUIRE(ldg % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldg >= C && ldx >= C && ldy >= C, "bnbwd_apply: bad pitch");
-  // the kernel moves whole 8-channel groups: the coefficient vectors are read up to C rounded up to 8, the tensors with 16-byte accesses
-  ATOMNAS_REQUIRE(C % 8 == 0, "bnbwd_apply: C must be a multiple of 8 (got %d): the coefficient vectors are read in groups of 8", C);
+  // the kernel moves whole 8-channel groups: c1 / c2 / c3 must be readable up to C rounded up to 8 (include/atomnas_hip.h), the tensors
+  // are accessed 16 bytes at a time
   ATOMNAS_REQUIRE((((size_t)g | (size_t)x | (size_t)y) & 15) == 0 && (((size_t)c1 | (size_t)c2 | (size_t)c3) & 15) == 0,
                   "bnbwd_apply: g, x, y and the coefficient vectors must be 16-byte aligned");
   const long total = M * ((C + 7) / 8);

@@ -180,8 +180,8 @@ int atomnas_bn_apply(const void* x, int ldx, const float* scale, const float* sh
                      int ldy, long M, int C, int dtype, void* stream);
 /* y = c1*g + c2*x + c3 per channel (plain layouts): the gradient through a training-mode BatchNorm as a tensor, i.e. what the
  *   PRO_BNBWD prologue of the GEMMs computes per tile (torch.nn.BatchNorm2d backward behind models/mobilenet_base.py:338-339).
- *   Used where one narrow gradient feeds many GEMM tiles (ABI 3).  C must be a multiple of 8 (whole 8-channel groups are moved: the
- *   coefficient vectors are read in groups of 8) and g, x, y, c1, c2, c3 16-byte aligned. */
+ *   Used where one narrow gradient feeds many GEMM tiles (ABI 3).  Whole 8-channel groups are moved: c1, c2, c3 must be readable (any
+ *   finite value) up to C rounded up to 8, and g, x, y, c1, c2, c3 16-byte aligned. */
 int atomnas_bnbwd_apply(const void* g, int ldg, const void* x, int ldx, const float* c1, const float* c2, const float* c3, void* y,
                         int ldy, long M, int C, int dtype, void* stream);
 /* pooled[n][c] = dropout(mean_hw act(x*scale+shift)): last ConvBNReLU activation + AvgPool2d + Dropout,

@@ -155,8 +155,10 @@ def test_model_forward_backward_fp32_against_measured_fp32_noise(gpu_lib):
     4e-6), and which batch flips differs between two equally valid summation orders.  So, per batch: the forward (logits, loss) must be
     tight; the gradients must be within 10x the fp32 oracle's own distance to float64 (floor 2e-5) unless a flip is in play, in which
     case 5e-2 (3x the largest measured flip); and at least two of the three batches must be flip-free for the HIP path -- exact
-    arithmetic parity is demonstrated there.  (Round 3 kept a slower slab rule for the fp32 depthwise instances because one batch read
-    9e-4 against a fixed 1e-4: that was a flip, not the rule -- the rule is gone.)"""
+    arithmetic parity is demonstrated there.  (Round 3 read 9e-4 against a fixed 1e-4 on one batch when a depthwise slab rule changed:
+    that was a flip, not a defect of the rule -- either rule passes this test.  The fp32 instances nevertheless stay on the frozen
+    configuration, because the element-wise comparison with the reference-written checkpoint fixture is tied to one flip pattern:
+    csrc/dwconv.hip launch_fwd.)"""
     from atomnas_amd.models import mobilenet_supernet as ms
     from atomnas_amd.utils import optim as aopt
     clean = 0

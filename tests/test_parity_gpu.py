@@ -98,8 +98,9 @@ def _blockwise(model, n_blocks_min):
 
 
 def test_cfg3_shrunk_atomnas_a_bf16_blockwise(gpu_lib):
-    """BASELINE config 3 in bf16, numerically: the AtomNAS-A supernet after the forced 30 % shrink (tests/test_configs_gpu.py's recipe:
-    hidden widths like 1, 2, 3, 13 ..., a dropped middle branch, an empty block -- where slab padding, the channel-pair fall-backs and the
+    """BASELINE config 3 in bf16, numerically: the AtomNAS-A supernet after the forced 30 % shrink (tests/test_configs_gpu.py's recipe
+    plus four branches cut down to 1 / 2 / 3 / 13 atoms: ragged hidden widths, a dropped middle branch, an empty block -- where slab
+    padding, the channel-pair fall-backs and the
     narrow / column-stationary GEMM dispatch change), every block alone against `Bf16Storage` on the oracle's own input and output
     gradient.  Measured worst (profiles/r04_parity_diag_cfg3_cfg5.txt): output 3.8e-4, input gradient 2.6e-3, parameter gradients
     1.7e-3, cosine 0.999999 -- the bounds of the un-shrunk network hold unchanged."""
@@ -108,7 +109,7 @@ def test_cfg3_shrunk_atomnas_a_bf16_blockwise(gpu_lib):
     blocks = list(model.features.children())[1:-2]
     widths = [c for b in blocks for c in b.channels]
     assert any(len(b.channels) == 0 for b in blocks) and any(len(b.channels) == 2 for b in blocks)    # empty block, dropped branch
-    assert any(c % 16 for c in widths) and min(widths) <= 8                                            # ragged, very narrow segments
+    assert any(c % 16 for c in widths) and {1, 2, 3, 13} <= set(widths)                                # ragged, very narrow segments
     _blockwise(model, 20)
 
 

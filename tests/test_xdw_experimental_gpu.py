@@ -113,6 +113,7 @@ def test_xdw_fwd_long_tile_walk(gpu_lib, workers, monkeypatch):
     import os
     import subprocess
     import sys
+    _ops().xdw_fwd   # skips when the experiment library is not loaded
     env = dict(os.environ)
     if workers:
         env["ATOMNAS_DW_MAX_WORKERS"] = str(workers)

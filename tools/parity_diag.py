@@ -100,10 +100,13 @@ def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32)
     return rows, oracle_s
 
 
+NARROW = {"features.7.ops.0.": 1, "features.9.ops.2.": 3, "features.12.ops.1.": 13, "features.16.ops.0.": 2}
+
+
 def shrunk_atomnas_a(seed=7):
     """BASELINE config 3 as tests/test_configs_gpu.py builds it: the full-size AtomNAS-A supernet with a seeded 30 % of its atoms (a whole
-    middle branch of one block and a whole block among them) forced dead, then train.shrink_model -- ragged hidden widths, a dropped
-    branch, an empty block.  Returns the shrunk model (fp32 storage, on the GPU)."""
+    middle branch of one block and a whole block among them) forced dead, four branches cut down to 1 / 2 / 3 / 13 atoms, then
+    train.shrink_model -- ragged hidden widths, very narrow segments, a dropped branch, an empty block.  Returns the shrunk model (fp32 storage, on the GPU)."""
     import train as T
     from atomnas_amd import configs, runtime
     from atomnas_amd.models import mobilenet_base as mb
@@ -138,6 +141,10 @@ def shrunk_atomnas_a(seed=7):
             dead = torch.rand(w.numel(), generator=g) < 0.3
             if name.startswith("features.3.ops.1.") or name.startswith("features.5."):
                 dead[:] = True
+            for prefix, keep in NARROW.items():   # very narrow segments: 1, 2, 3, 13 atoms (slab padding, narrow-GEMM dispatch)
+                if name.startswith(prefix):
+                    dead[:] = True
+                    dead[:keep] = False
             w[dead.cuda()] = 0.0
             ema.average(name)[dead.cuda()] = 0.0
 
