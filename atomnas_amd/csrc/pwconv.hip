@@ -18,6 +18,7 @@
 //     16 consecutive output channels of one pixel, i.e. whole 32-byte runs, with no LDS transpose.
 // fp32 storage uses mfma_f32_16x16x4f32 through the same code (exact f32; for parity tests, not for speed).
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1938,7 +1939,14 @@ __device__ unsigned long long g_tn_timing[8];
 #define TN_MARK(i)
 #endif
 
-template <int UMODE, int VMODE, int UTT, int VTT, int ROWS>
+struct TrFrag { bf16x4 lo, hi; };   // the two halves (k = 8 q .. + 3, + 4 .. + 7) of a transposing-read MFMA fragment
+
+// TR (round 4): the operands stay row-major in LDS -- [32-row chunk][16-column tile][32][16] subtiles, filled with ONE 16-byte store per
+// (row, 8 channels) piece -- and the k-major MFMA fragments are read with ds_read_b64_tr_b16, gfx950's transposing LDS read (two per
+// fragment; semantics checked with tools/probe/trread.hip: lane (c, g) element e <- the 8-byte segment the group's sub-lane 4 e + c / 4
+// points at, its element c % 4).  Without it every (row pair, 8 channels) unit is transposed by hand: eight packs and eight 4-byte LDS
+// stores, which -- with the loads -- was where the kernel's wave cycles went (profiles/r03_tn_phase_timing.txt).
+template <int UMODE, int VMODE, int UTT, int VTT, int ROWS, bool TR>
 __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj, long M,
                                                   long rows_per_block, int nchunks, int vt, int uz, int xcd_aware, float* __restrict__ ws) {
   using T = bf16_t;
@@ -1947,8 +1955,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
                                     // wider V tiles halve that traffic where U is not narrow)
   constexpr int RP = ROWS + 8;      // transposed row pitch (elements): 16 consecutive columns land on 16 distinct 16-byte slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* s_v = reinterpret_cast<T*>(smem_raw);          // [VW][RP]
-  T* s_u = s_v + VW * RP;                           // [16*UTT][RP]
+  T* s_v = reinterpret_cast<T*>(smem_raw);          // [VW][RP]   (TR: [ROWS / 32][VW / 16][32][16])
+  T* s_u = s_v + VW * RP;                           // [16*UTT][RP]   (TR: [ROWS / 32][UTT][32][16]; the region is the same size or smaller)
   float* s_cv = reinterpret_cast<float*>(s_u + 16 * UTT * RP);       // [3][VW]      prologue coefficients of the V tile
   float* s_cu = s_cv + 3 * VW;                                       // [3][16*UTT]  ... of the U tile
 
@@ -2105,12 +2113,19 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       xform(std::integral_constant<int, VMODE>{}, V, rva[i][1], rvx[V2 ? i : 0][1], kv && (r0 + 2 * rp + 1) < r_end, lc, lc + VW, lc + 2 * VW, bb);
       const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
       if (active) {
+        if constexpr (TR) {
+          // row-major subtiles [2 rp / 32][cg / 2][32][16]: one 16-byte store per row
+          T* d = s_v + (((2 * rp) >> 5) * (VW / 16) + (cg >> 1)) * 512 + ((2 * rp) & 31) * 16 + (cg & 1) * 8;
+          *reinterpret_cast<bf16x8*>(d) = MM::pack(a);
+          *reinterpret_cast<bf16x8*>(d + 16) = MM::pack(bb);
+        } else {
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) {
-          const int e = (ii + rot) & 7;
-          bf16x2 pk;
-          pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)bb[e];
-          *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * RP + 2 * rp]) = pk;
+          for (int ii = 0; ii < 8; ++ii) {
+            const int e = (ii + rot) & 7;
+            bf16x2 pk;
+            pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)bb[e];
+            *reinterpret_cast<bf16x2*>(&s_v[(cg * 8 + e) * RP + 2 * rp]) = pk;
+          }
         }
       }
     }
@@ -2127,15 +2142,31 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       xform(std::integral_constant<int, UMODE>{}, U, rua[i][1], rux[U2 ? i : 0][1], kv && (r0 + 2 * rp + 1) < r_end, lc, lc + 16 * UTT, lc + 32 * UTT, bb);
       const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
       if (active) {
+        if constexpr (TR) {
+          T* d = s_u + (((2 * rp) >> 5) * UTT + (cg >> 1)) * 512 + ((2 * rp) & 31) * 16 + (cg & 1) * 8;
+          *reinterpret_cast<bf16x8*>(d) = MM::pack(a);
+          *reinterpret_cast<bf16x8*>(d + 16) = MM::pack(bb);
+        } else {
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) {
-          const int e = (ii + rot) & 7;
-          bf16x2 pk;
-          pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)bb[e];
-          *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * RP + 2 * rp]) = pk;
+          for (int ii = 0; ii < 8; ++ii) {
+            const int e = (ii + rot) & 7;
+            bf16x2 pk;
+            pk[0] = (bf16_t)a[e]; pk[1] = (bf16_t)bb[e];
+            *reinterpret_cast<bf16x2*>(&s_u[(cg * 8 + e) * RP + 2 * rp]) = pk;
+          }
         }
       }
     }
+  };
+  // TR: fragment of subtile `st` (a [32][16] row-major block, 1 KB) -- k = 8 q + e along the rows, column j: two transposing reads
+  // (rows 8 q .. 8 q + 3 and 8 q + 4 .. 8 q + 7); every lane passes the address of its 8-byte segment: row 8 q + j / 4, columns 4 (j % 4) ..
+  const unsigned tr_lane = (unsigned)(((8 * q + (j >> 2)) * 16 + 4 * (j & 3)) * 2);
+  auto tr_frag = [&](const T* sub) {
+    const unsigned a0 = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)sub) + tr_lane;
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(hi) : "v"(a0) : "memory");
+    return TrFrag{lo, hi};
   };
   issue(r_beg);
   for (long r0 = r_beg; r0 < r_end; r0 += ROWS) {
@@ -2148,15 +2179,38 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
     TN_MARK(2)
 #pragma unroll TN2_KS_UNROLL   // full unrolling hoists all fragment reads: 162 VGPRs for 6 accumulator tiles, 2 waves per SIMD
     for (int ks = 0; ks < ROWS / 32; ++ks) {
-      bf16x8 bf[VTT];
+      if constexpr (TR) {
+        // all fragment reads of the k-step are issued, ONE wait (the asm reads are invisible to the compiler's counters), then the MFMAs
+        TrFrag bfp[VTT], afp[UTT];
 #pragma unroll
-      for (int v = 0; v < VTT; ++v) bf[v] = *reinterpret_cast<const bf16x8*>(&s_v[(64 * v + 16 * wave + j) * RP + 32 * ks + 8 * q]);
+        for (int v = 0; v < VTT; ++v) bfp[v] = tr_frag(s_v + (ks * (VW / 16) + 4 * v + wave) * 512);
 #pragma unroll
-      for (int t = 0; t < UTT; ++t) {
-        if (t < ut) {
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(&s_u[(16 * t + j) * RP + 32 * ks + 8 * q]);
+        for (int t = 0; t < UTT; ++t)
+          if (t < ut) afp[t] = tr_frag(s_u + (ks * UTT + t) * 512);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 bf[VTT];
 #pragma unroll
-          for (int v = 0; v < VTT; ++v) acc[v][t] = MM::mma(af, bf[v], acc[v][t]);
+        for (int v = 0; v < VTT; ++v) bf[v] = __builtin_shufflevector(bfp[v].lo, bfp[v].hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int t = 0; t < UTT; ++t) {
+          if (t < ut) {
+            const bf16x8 af = __builtin_shufflevector(afp[t].lo, afp[t].hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int v = 0; v < VTT; ++v) acc[v][t] = MM::mma(af, bf[v], acc[v][t]);
+          }
+        }
+      } else {
+        bf16x8 bf[VTT];
+#pragma unroll
+        for (int v = 0; v < VTT; ++v) bf[v] = *reinterpret_cast<const bf16x8*>(&s_v[(64 * v + 16 * wave + j) * RP + 32 * ks + 8 * q]);
+#pragma unroll
+        for (int t = 0; t < UTT; ++t) {
+          if (t < ut) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(&s_u[(16 * t + j) * RP + 32 * ks + 8 * q]);
+#pragma unroll
+            for (int v = 0; v < VTT; ++v) acc[v][t] = MM::mma(af, bf[v], acc[v][t]);
+          }
         }
       }
     }
@@ -2403,9 +2457,10 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
   const size_t lds = (size_t)(64 * VTT + 16 * UTT) * (ROWS + 8) * sizeof(bf16_t) + (size_t)3 * (64 * VTT + 16 * UTT) * sizeof(float);
   // row chunks so that the grid is one round of resident workgroups (at least two slabs per workgroup)
   static const int xcd_env = getenv("ATOMNAS_TN_XCD") ? atoi(getenv("ATOMNAS_TN_XCD")) : 1;
+  static const int tr_on = getenv("ATOMNAS_TN_TR") ? atoi(getenv("ATOMNAS_TN_TR")) : 1;   // experiment switch: transposing LDS reads (round 4)
 #define TN2_CASE(UM, VM)                                                                                                      \
   {                                                                                                                           \
-    auto kern = k_gemm_tn2<UM, VM, UTT, VTT, ROWS>;                                                                           \
+    auto kern = tr_on ? k_gemm_tn2<UM, VM, UTT, VTT, ROWS, true> : k_gemm_tn2<UM, VM, UTT, VTT, ROWS, false>;                 \
     const long resident = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                  \
     long chunks = resident / ((long)vt * uz);                                                                                 \
     if (chunks > M / (2 * ROWS)) chunks = M / (2 * ROWS);                                                                     \
@@ -2455,8 +2510,270 @@ static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const O
   return launch_tn2_cfg<UTT, 1, 128>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_tn, LDS-DMA form (round 4)
+// Out[i][j] (+)= sum_m U[m][i] * pro(V)[m][j] for the single-stream weight gradients of the late stages (U: plain, no prologue -- the
+// block input x or the differentiated BatchNorm output dP; V: a hidden tensor with no prologue or the BNRELU one).  k_gemm_tn2 stages both
+// operands through registers: a slab's loads are issued one slab ahead, so every slab waits out what is left of an HBM round trip, and
+// the staging itself (loads, prologue, LDS stores) was 36-51 % of its wave cycles; its matrix pipe is 6 % busy.  Here:
+//   * global_load_lds_dwordx4 copies 32-row x 16-column subtiles ([32][16] row-major, 1 KB = one wave instruction, lane-linear) straight
+//     into a ring of TN3_DEPTH stage buffers: no staging registers, no LDS store instructions, TN3_DEPTH - 1 stages in flight behind
+//     the MFMAs, waited for with a COUNTED vmcnt (every wave issues the same number of copies per stage);
+//   * the k-major MFMA fragments come out of those row-major subtiles with ds_read_b64_tr_b16;
+//   * V's prologue (scale / shift / activation, per COLUMN, i.e. per lane of a B fragment) is applied to the fragment registers;
+//   * rows beyond M are cut off in U's fragments (the copies of such rows read row M - 1: finite garbage times zero).
+// A workgroup owns every U column of a U tile (<= 192) and 128 V columns (wave w: V tiles w and w + 4), and a row chunk; partial
+// outputs per row chunk go to the workspace and are summed in chunk order (reduce_parts), as in k_gemm_tn2.
+//   * UC: U is a dense [M][NU] matrix (pitch == NU, one U tile): a stage's 32 rows are ONE contiguous run of 64 NU bytes, copied as is
+//     (whole 128-byte lines per copy instead of 32-byte pieces of 32 lines) and read by the transposing reads with the row pitch NU.
+template <int UTT, bool VPRO, int TN3_DEPTH, bool UC>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn3(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj, long M,
+                                                  long rows_per_block, int nchunks, int vt, int uz, float* __restrict__ ws) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  constexpr int NSUB = 8 + UTT;              // subtiles of a stage: 8 V tiles, UTT U tiles (UC: UTT KB for the rows of U, NU <= 16 UTT)
+  constexpr int DPS = (NSUB + 3) / 4;        // copies per wave and stage
+  constexpr int STAGE = NSUB * 512;          // elements per stage buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* s_st = reinterpret_cast<T*>(smem_raw);  // [TN3_DEPTH][NSUB][32][16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int ntile = vt * uz;
+  // all column tiles of one row chunk are consecutive workgroups of ONE XCD (block b runs on XCD b % 8): they share the chunk's U rows in L2
+  const int b_xcd = blockIdx.x & 7, b_local = blockIdx.x >> 3;
+  const int tile = b_local % ntile;
+  const long chunk = (long)(b_local / ntile) * 8 + b_xcd;
+  if (chunk >= nchunks) return;
+  const int u0 = (tile / vt) * (16 * UTT);
+  const int nu = min(NU - u0, 16 * UTT);
+  const int ut = (nu + 15) / 16;
+  const int v0 = (tile % vt) * 128;
+  const long r_beg = chunk * rows_per_block;
+  const long r_end = min(M, r_beg + rows_per_block);
+  const int nstages = (int)((r_end - r_beg + 31) / 32);
+
+  // per-lane source offsets (elements) of the subtiles this wave copies: lane -> (row lane / 2, 8-column half lane % 2)
+  const int r_l = lane >> 1, h_l = lane & 1;
+  long src_off[DPS], src_mul[DPS];      // element offset of (row 0) and the row multiplier
+  const T* src_base[DPS];
+  unsigned dst_off[DPS];                // byte offset of the subtile inside a stage buffer
+#pragma unroll
+  for (int i = 0; i < DPS; ++i) {
+    int sub = wave + 4 * i;
+    sub = sub < NSUB ? sub : NSUB - 1;   // surplus slot: the last subtile once more (identical bytes to the same place)
+    dst_off[i] = (unsigned)sub * 1024u;
+    if (sub < 8) {   // V tile `sub` of the workgroup's 128 columns
+      int c = v0 + 16 * sub + 8 * h_l;
+      c = c < ((NV + 7) & ~7) ? c : 0;   // a tile beyond NV: any valid column (its results are not stored)
+      src_base[i] = reinterpret_cast<const T*>(V.p1);
+      src_off[i] = lay_off(0, c, V.ld1, V.ss1);
+      src_mul[i] = V.ss1 ? 16 : V.ld1;
+    } else if (UC) {   // KB number sub - 8 of the stage's 64 NU contiguous bytes of U: this lane's 16 bytes
+      long e = ((long)(sub - 8) * 1024 + lane * 16) / 2;     // element offset inside the stage's rows
+      e = e < 32L * NU ? e : 0;                               // past the 32 rows (NU < 16 UTT): any valid bytes, never read
+      src_base[i] = reinterpret_cast<const T*>(U.p1);
+      src_off[i] = e - (long)r_l * NU;                        // copy_stage adds (row + r_l) * src_mul
+      src_mul[i] = NU;
+    } else {         // U tile sub - 8
+      int c = u0 + 16 * (sub - 8) + 8 * h_l;
+      c = c < ((NU + 7) & ~7) ? c : 0;
+      src_base[i] = reinterpret_cast<const T*>(U.p1);
+      src_off[i] = lay_off(0, c, U.ld1, U.ss1);
+      src_mul[i] = U.ss1 ? 16 : U.ld1;
+    }
+  }
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)s_st);
+  auto copy_stage = [&](int s) {   // stage s of this chunk -> ring slot s % TN3_DEPTH; rows clamped to M - 1
+    const int sc = s < nstages ? s : nstages - 1;   // past the chunk: re-copy its last stage (keeps the copy count per stage constant)
+    long row = r_beg + 32L * sc + r_l;
+    row = row < M ? row : M - 1;
+    long urow = r_beg + 32L * sc;                   // UC: first row of the contiguous run; a run that would pass the end of U starts
+    if (UC && urow + 32 > M) urow = M - 32;         // 32 rows before it (the fragment reads shift by the same amount)
+    const unsigned slot = lds0 + (unsigned)(s % TN3_DEPTH) * (unsigned)(STAGE * 2);
+#pragma unroll
+    for (int i = 0; i < DPS; ++i) {
+      const bool is_u = UC && (wave + 4 * i >= 8);
+      const T* g = src_base[i] + ((is_u ? urow + r_l : row) * src_mul[i] + src_off[i]);
+      const unsigned d = __builtin_amdgcn_readfirstlane(slot + dst_off[i]);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+    }
+  };
+
+  // V prologue coefficients of this lane's two columns (B fragment: lane j <-> column)
+  float vsc[2] = {1.f, 1.f}, vsh[2] = {0.f, 0.f};
+  if constexpr (VPRO) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int c = v0 + 64 * v + 16 * wave + j;
+      if (c < NV) { vsc[v] = V.c1[c]; vsh[v] = V.c2[c]; }
+    }
+  }
+  const Act vact = act_of(V.relu);
+
+  f32x4 acc[2][UTT];
+#pragma unroll
+  for (int v = 0; v < 2; ++v)
+#pragma unroll
+    for (int t = 0; t < UTT; ++t) acc[v][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned tr_lane = (unsigned)(((8 * q + (j >> 2)) * 16 + 4 * (j & 3)) * 2);
+  auto tr_frag = [&](unsigned sub_addr) {
+    const unsigned a0 = sub_addr + tr_lane;
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(hi) : "v"(a0) : "memory");
+    return TrFrag{lo, hi};
+  };
+
+  // prologue: TN3_DEPTH - 1 stages in flight
+#pragma unroll
+  for (int s = 0; s < TN3_DEPTH - 1; ++s) copy_stage(s);
+  for (int s = 0; s < nstages; ++s) {
+    // stage s has landed when at most (TN3_DEPTH - 2) later stages' copies of this wave are outstanding; the barrier extends that to
+    // the copies of the other waves
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TN3_DEPTH - 2) * DPS) : "memory");
+    __syncthreads();
+    copy_stage(s + TN3_DEPTH - 1);   // into the slot stage s - 1 was read from (every wave is past it: the barrier above)
+    const unsigned slot = lds0 + (unsigned)(s % TN3_DEPTH) * (unsigned)(STAGE * 2);
+    TrFrag bfp[2], afp[UTT];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) bfp[v] = tr_frag(slot + (unsigned)(4 * v + wave) * 1024u);
+    // UC: rows of pitch NU; in a run shifted to end at the tensor's last row the stage's first row sits `ushift` rows into the image
+    const long ustart = r_beg + 32L * s;
+    const int ushift = (UC && ustart + 32 > M) ? (int)(ustart - (M - 32)) : 0;
+#pragma unroll
+    for (int t = 0; t < UTT; ++t) {
+      if (t < ut) {
+        if constexpr (UC) {
+          // lane's 8-byte segments: rows ushift + 8 q + j / 4 (+ 4), columns 16 t + 4 (j % 4) ..; rows past the image (ushift > 0) are
+          // clamped to its last row and cut off by the row mask below
+          int r0 = ushift + 8 * q + (j >> 2), r1 = r0 + 4;
+          r0 = r0 < 32 ? r0 : 31; r1 = r1 < 32 ? r1 : 31;
+          const unsigned ub = slot + 8u * 1024u + (unsigned)((16 * t + 4 * (j & 3)) * 2);
+          bf16x4 lo, hi;
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ub + (unsigned)(r0 * NU * 2)) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ub + (unsigned)(r1 * NU * 2)) : "memory");
+          afp[t] = TrFrag{lo, hi};
+        } else {
+          afp[t] = tr_frag(slot + (unsigned)(8 + t) * 1024u);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 bf[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      bf[v] = __builtin_shufflevector(bfp[v].lo, bfp[v].hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      if constexpr (VPRO) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)bf[v][e] * vsc[v] + vsh[v];
+        act_apply_v<8>(x, vact);
+        bf[v] = MM::pack(x);
+      }
+    }
+    const long rows_left = r_end - (r_beg + 32L * s);   // < 32 only in the chunk's last stage
+#pragma unroll
+    for (int t = 0; t < UTT; ++t) {
+      if (t < ut) {
+        bf16x8 af = __builtin_shufflevector(afp[t].lo, afp[t].hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (rows_left < 32) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (8 * q + e >= rows_left) af[e] = (bf16_t)0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[v][t] = MM::mma(af, bf[v], acc[v][t]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus copies of the last stages must not outlive the workgroup's LDS
+
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int vc = v0 + 64 * v + 16 * wave + j;
+    if (vc < NV) {
+#pragma unroll
+      for (int t = 0; t < UTT; ++t) {
+        if (t < ut) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int uc = u0 + 16 * t + 4 * q + r;
+            if (uc < NU) {
+              if (ws) ws[(chunk * NU + uc) * NV + vc] = acc[v][t][r];
+              else out[uc * si + vc * sj] += acc[v][t][r];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// -1: not one of this kernel's cases
+template <int UTT>
+static int launch_tn3_cfg(const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M, float* ws,
+                          long ws_floats, hipStream_t st) {
+  const int vt = (NV + 127) / 128, uz = (NU + 16 * UTT - 1) / (16 * UTT);
+  // ring depth: as many stages in flight as leave room for two workgroups per CU (ATOMNAS_TN3_DEPTH: experiment switch)
+  static const int depth_env = getenv("ATOMNAS_TN3_DEPTH") ? atoi(getenv("ATOMNAS_TN3_DEPTH")) : 0;
+  const int depth = depth_env ? depth_env : ((size_t)4 * (8 + UTT) * 1024 * 2 + 4096 <= max_lds_bytes() ? 4 : 3);
+  const size_t lds = (size_t)depth * (8 + UTT) * 1024;
+  if (lds > max_lds_bytes()) return -1;
+  static const bool dbg = getenv("ATOMNAS_TN3_DEBUG") != nullptr;
+  static const int uc_env = getenv("ATOMNAS_TN3_UC") ? atoi(getenv("ATOMNAS_TN3_UC")) : 1;   // experiment switch
+  // dense U (pitch == NU), one U tile, rows 16-byte aligned and whole 8-byte segments per row, at least one full stage of rows
+  const bool uc = uc_env && U.ss1 == 0 && U.ld1 == NU && uz == 1 && NU % 8 == 0 && M >= 32 && 32L * NU * 2 <= (long)UTT * 1024;
+  const long max_chunks = (ws && (long)NU * NV > 0) ? ws_floats / ((long)NU * NV) : 1;
+  long nparts = 1;
+#define TN3_CASE(VP)                                                                                                          \
+  {                                                                                                                           \
+    auto kern = uc ? (depth == 4 ? k_gemm_tn3<UTT, VP, 4, true> : (depth == 3 ? k_gemm_tn3<UTT, VP, 3, true> : k_gemm_tn3<UTT, VP, 2, true>)) \
+                   : (depth == 4 ? k_gemm_tn3<UTT, VP, 4, false> : (depth == 3 ? k_gemm_tn3<UTT, VP, 3, false> : k_gemm_tn3<UTT, VP, 2, false>)); \
+    const long resident = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                  \
+    if (dbg) fprintf(stderr, "tn3: M %ld NU %d NV %d UTT %d depth %d lds %zu per_cu %ld\n", M, NU, NV, UTT, depth, lds, resident / num_cus()); \
+    long chunks = resident / ((long)vt * uz);                                                                                 \
+    if (chunks > M / 128) chunks = M / 128;   /* at least four stages per workgroup */                                        \
+    if (chunks > max_chunks) chunks = max_chunks;                                                                             \
+    chunks = chunks / 8 * 8;   /* equal work per XCD */                                                                       \
+    if (chunks < 8) return -1;                                                                                                \
+    long rows = (M + chunks - 1) / chunks;                                                                                    \
+    rows = (rows + 31) / 32 * 32;   /* whole stages: only the tensor's last chunk has a ragged one */                         \
+    chunks = (M + rows - 1) / rows;                                                                                           \
+    nparts = chunks;                                                                                                          \
+    dim3 grid((unsigned)((chunks + 7) / 8 * 8 * vt * uz)), block(256);                                                        \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, U, NU, V, NV, out, si, sj, M, rows, (int)chunks, vt, uz, ws);              \
+  }
+  if (vmode == PRO_BNRELU) TN3_CASE(true) else TN3_CASE(false)
+#undef TN3_CASE
+  if (int rc = check_launch("gemm_tn3")) return rc;
+  return reduce_parts(ws, (long)NU * NV, (int)nparts, (long)NU * NV, out, NV, si, sj, st);
+}
+
+static int launch_tn3(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
+                      float* ws, long ws_floats, hipStream_t st) {
+  static const int on = getenv("ATOMNAS_TN_DMA") ? atoi(getenv("ATOMNAS_TN_DMA")) : 1;   // experiment switch
+  // single-stream weight gradients of wide hidden tensors: U without prologue, V none / BNRELU, a workspace for >= 8 row chunks
+  if (!on || umode != PRO_NONE || (vmode != PRO_NONE && vmode != PRO_BNRELU) || !ws || NV < 256 || NU < 32 || M < 1024) return -1;
+  if (vmode == PRO_BNRELU && !(V.c1 && V.c2)) return -1;
+  const int ut = (NU + 15) / 16;
+  if (ut <= 4) return launch_tn3_cfg<4>(U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  if (ut <= 6) return launch_tn3_cfg<6>(U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  if (ut <= 12) return launch_tn3_cfg<12>(U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+  if (ut <= 20) return launch_tn3_cfg<10>(U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);   // two U tiles of <= 160 columns
+  return -1;
+}
+
 static int launch_tn2(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
                       float* ws, long ws_floats, hipStream_t st) {
+  {
+    const int rc = launch_tn3(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);
+    if (rc >= 0) return rc;
+  }
   // accumulator tiles per wave (= U tiles of 16 columns): fewer tiles -> fewer AGPRs -> more waves per SIMD
   const int ut = (NU + 15) / 16;
   if (ut <= 2) return launch_tn2_ut<2>(umode, U, NU, vmode, V, NV, out, si, sj, M, ws, ws_floats, st);

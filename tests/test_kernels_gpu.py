@@ -236,6 +236,39 @@ def test_gemm_tn(gpu_lib, dtype, M, NU, NV, variant):
         assert_close("out", view(out), ref, rtol=2e-3 if dtype == torch.bfloat16 else 2e-4, atol=2e-3 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("slab", [False, True])
+@pytest.mark.parametrize("variant", ["none_none", "none_bnrelu"])
+@pytest.mark.parametrize("M,NU,NV", [(12544, 192, 3456), (5001, 80, 1440), (6000, 320, 1280), (2500, 96, 1000), (1024, 40, 720), (3333, 36, 257)])
+def test_gemm_tn_dma_form(gpu_lib, M, NU, NV, variant, slab):
+    """k_gemm_tn3 (round 4): the single-stream weight gradients of the late stages -- LDS-DMA copies, transposing fragment reads, V's
+    prologue on the fragments.  The supernet's 7 x 7 / 14 x 14 / 28 x 28 shapes, two U tiles (320), ragged NU / NV / M (a last stage of
+    fewer than 32 rows, V tiles beyond NV), plain and slab-major V."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M + 7 * NU + 13 * NV)
+    r = lambda *s: torch.randn(*s, generator=g)
+    U, V = r(M, NU), r(M, NV)
+    vc = [torch.rand(NV, generator=g) + 0.5, r(NV) * 0.2]
+    rd = lambda t: t.to(dtype).double()
+    act2d = lambda t, c: torch.cat([t.to(dtype), torch.zeros(t.shape[0], pad8(c) - c, dtype=dtype)], 1).cuda()
+    Ue, Ve = rd(U), rd(V)
+    kw = {}
+    if variant == "none_bnrelu":
+        Ve = torch.relu(rd(V) * vc[0].double() + vc[1].double()).to(dtype).double()
+        kw = dict(v_mode=ops.PRO_BNRELU, vc1=cvec(vc[0]), vc2=cvec(vc[1]), v_relu=True)
+    ref = Ue.t() @ Ve
+    Vb = ops.Slab.from_plain(act2d(V, NV), NV) if slab else act2d(V, NV)
+    out = torch.zeros(NU, NV, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(act2d(U, NU), NU, Vb, NV, out, NV, 1, M, **kw)
+    torch.cuda.synchronize()
+    assert_close("out", out, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    # bit-reproducible (fixed-order partial sums) and accumulating (+=)
+    out2 = out.clone()
+    ops.gemm_tn(act2d(U, NU), NU, Vb, NV, out2, NV, 1, M, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, 2 * out)
+
+
 # ---------------------------------------------------------------------------------------------- channel-pair-per-wave depthwise kernels
 # csrc/dwconv_cw.hip: stride 1, slab-major tensors, width a multiple of 7 -- the instances the hidden tensors of the expanding
 # blocks take.  Cases: several whole images per tile (7x7, 14x14; the last tile partly empty), one whole image per tile (30x14),
