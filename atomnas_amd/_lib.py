@@ -24,19 +24,19 @@ SIGNATURES = {
                            vp],
     "atomnas_project_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, i32, vp, i64, i64, vp, i64, i64,
                             i32, i32, i32, vp],
-    "atomnas_bn_finalize_fwd": [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
-    "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
-    "atomnas_bn_finalize_bwd": [vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "atomnas_bn_finalize_fwd": [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
+    "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp, vp],
+    "atomnas_bn_finalize_bwd": [vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
     "atomnas_bn_apply": [vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
     "atomnas_bnbwd_apply": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i64, i32, i32, vp],
     "atomnas_bn_act_pool": [vp, i32, vp, vp, i32, vp, i32, vp, f32, u64, vp, i32, i32, i32, i32, vp],
     "atomnas_pool_act_bwd": [vp, i32, vp, f32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "atomnas_act_bwd_stats": [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
-    "atomnas_se_squeeze": [vp, i32, i64, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp],
-    "atomnas_se_mlp_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "atomnas_se_squeeze": [vp, i32, i64, vp, vp, i32, vp, i32, i32, i64, i32, i32, i32, i32, vp],
+    "atomnas_se_mlp_fwd": [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
     "atomnas_se_scale": [vp, i32, i64, vp, vp, i32, vp, i32, vp, i32, i64, i64, i32, i32, i32, vp],
-    "atomnas_se_bwd_gate": [vp, i32, i64, vp, i32, i64, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32,
-                            i32, i32, i32, i32, vp],
+    "atomnas_se_bwd_gate": [vp, i32, i64, vp, i32, i64, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32,
+                            i32, i32, i32, i32, i32, vp],
     "atomnas_se_bwd_apply": [vp, i32, i64, vp, i32, i64, vp, vp, i32, vp, vp, i32, vp, i32, i64, vp, i32, i64, i32, i32, i32, vp],
     "atomnas_im2col_stem": [vp, vp, i32, i32, i32, i32, i32, vp],
     "atomnas_ce_smooth": [vp, i32, vp, f32, i32, i32, vp, vp, i32, f32, vp, i32, vp],
@@ -60,9 +60,10 @@ NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version":
              "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32]),
              "atomnas_project_bwd_supported": (i32, [i32, i32, i32]),
              "atomnas_project_bwd_dp_supported": (i32, [i64, i32, i32, i32, i32, i64, i32, i64, i32, i32]),
-             "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32])}
+             "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+             "atomnas_se_pool_parts": (i32, [i32, i32, i32])}
 
-ABI_VERSION = 4   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
+ABI_VERSION = 5   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None
 
 

@@ -50,13 +50,16 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                   float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ scale,
                                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int C,
-                                  int Cpad) {
+                                  int Cpad, const int* __restrict__ cmap) {
   __shared__ float s_red[2][64][17];
   const int c = blockIdx.x * 16 + threadIdx.x;
   float a0, a1;
   stat_row_sum(stats, rows, stat_ld, Cpad, s_red, a0, a1);
   if (threadIdx.x >= 16 || c >= Cpad) return;
-  if (c >= C) {  // padding lanes of the channel vectors stay neutral
+  // cmap (fused block: the kernels' padded branch segments against the module's contiguous parameter vectors): statistics and
+  // coefficients are indexed by the padded channel c, the parameters by p = cmap[c]; -1 marks padding inside the range
+  const int p = (c >= C) ? -1 : (cmap ? cmap[c] : c);
+  if (p < 0) {  // padding lanes of the channel vectors stay neutral
     scale[c] = 0.f; shift[c] = 0.f;
     if (save_mean) { save_mean[c] = 0.f; save_invstd[c] = 0.f; }
     return;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
   float var = a1 * inv_count - mean * mean;
   var = fmaxf(var, 0.f);
   const float invstd = 1.0f / sqrtf(var + eps);
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float g = gamma ? gamma[p] : 1.f, b = beta ? beta[p] : 0.f;
   const float s = g * invstd;
   scale[c] = s;
   shift[c] = b - mean * s;
@@ -73,21 +76,22 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
   if (running_mean) {
     float m = momentum;
     if (m < 0.f) m = 1.0f / (float)(nbt[0] + 1);  // cumulative moving average; the caller bumps the counter afterwards
-    running_mean[c] = (1.f - m) * running_mean[c] + m * mean;
-    running_var[c] = (1.f - m) * running_var[c] + m * var * unbias;
+    running_mean[p] = (1.f - m) * running_mean[p] + m * mean;
+    running_var[p] = (1.f - m) * running_var[p] + m * var * unbias;
   }
 }
 
 __global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                  const float* __restrict__ rv, float eps, float* __restrict__ scale, float* __restrict__ shift, int C,
-                                 int Cpad) {
+                                 int Cpad, const int* __restrict__ cmap) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cpad) return;
-  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; return; }
-  const float invstd = 1.0f / sqrtf(rv[c] + eps);
-  const float s = (gamma ? gamma[c] : 1.f) * invstd;
+  const int p = (c >= C) ? -1 : (cmap ? cmap[c] : c);
+  if (p < 0) { scale[c] = 0.f; shift[c] = 0.f; return; }
+  const float invstd = 1.0f / sqrtf(rv[p] + eps);
+  const float s = (gamma ? gamma[p] : 1.f) * invstd;
   scale[c] = s;
-  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
+  shift[c] = (beta ? beta[p] : 0.f) - rm[p] * s;
 }
 
 // stats2 = [sum g, sum g*x];  dgamma = invstd*(sum g*x - mean*sum g), dbeta = sum g,
@@ -97,15 +101,16 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
                                   const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                   const float* __restrict__ rho_ptr, const float* __restrict__ penalty, float* __restrict__ dgamma,
                                   float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
-                                  int C, int Cpad) {
+                                  int C, int Cpad, const int* __restrict__ cmap) {
   __shared__ float s_red[2][64][17];
   const int c = blockIdx.x * 16 + threadIdx.x;
   float sg, sgx;
   stat_row_sum(stats2, rows, stat_ld, Cpad, s_red, sg, sgx);
   if (threadIdx.x >= 16 || c >= Cpad) return;
-  if (c >= C) { c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
+  const int p = (c >= C) ? -1 : (cmap ? cmap[c] : c);   // parameter index (see k_bn_finalize_fwd)
+  if (p < 0) { c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
   const float mean = save_mean[c], r = save_invstd[c];
-  const float g = gamma ? gamma[c] : 1.f;
+  const float g = gamma ? gamma[p] : 1.f;
   const float dg = r * (sgx - mean * sg);
   const float db = sg;
   c1[c] = g * r;
@@ -115,11 +120,11 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
     float l1 = 0.f;
     if (rho_ptr && penalty) {
       const float s = (g > 0.f) ? 1.f : ((g < 0.f) ? -1.f : 0.f);
-      l1 = rho_ptr[0] * penalty[c] * s;
+      l1 = rho_ptr[0] * penalty[p] * s;
     }
-    dgamma[c] += dg + l1;  // gradients accumulate into the (zeroed) arena, like autograd's AccumulateGrad
+    dgamma[p] += dg + l1;  // gradients accumulate into the (zeroed) arena, like autograd's AccumulateGrad
   }
-  if (dbeta) dbeta[c] += db;
+  if (dbeta) dbeta[p] += db;
 }
 
 // y = act(x*scale + shift) (+ res), 8 channels per thread
@@ -358,7 +363,8 @@ using namespace atomnas;
 
 extern "C" int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, int stat_ld, double count, const float* gamma, const float* beta, float eps,
                                        float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
-                                       float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
+                                       float* scale, float* shift, float* save_mean, float* save_invstd, int C, const int* cmap,
+                                       void* stream) {
   ATOMNAS_REQUIRE(stats && stat_rows > 0 && scale && shift && C > 0 && count > 0, "bn_finalize_fwd: bad arguments");
   ATOMNAS_REQUIRE(stat_ld >= (C + 7) / 8 * 8 && stat_ld % 4 == 0 && ((size_t)stats & 15) == 0, "bn_finalize_fwd: the statistics rows must be 16-byte aligned with a pitch of at least C rounded up to 8 (stat_ld=%d)", stat_ld);
   ATOMNAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_fwd: running stats must come together");
@@ -367,27 +373,27 @@ extern "C" int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, int st
   const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((Cpad + 15) / 16), dim3(256), 0, st, stats, stat_rows, stat_ld, (float)(1.0 / count), unbias, gamma, beta,
-                     eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C, Cpad);
+                     eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C, Cpad, cmap);
   return check_launch("bn_finalize_fwd");
 }
 
 extern "C" int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                                      float eps, float* scale, float* shift, int C, void* stream) {
+                                      float eps, float* scale, float* shift, int C, const int* cmap, void* stream) {
   ATOMNAS_REQUIRE(running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad arguments");
   const int Cpad = (C + 7) / 8 * 8;
   hipLaunchKernelGGL(k_bn_eval_coeffs, dim3((Cpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
-                     running_var, eps, scale, shift, C, Cpad);
+                     running_var, eps, scale, shift, C, Cpad, cmap);
   return check_launch("bn_eval_coeffs");
 }
 
 extern "C" int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, int stat_ld, double count, const float* gamma, const float* save_mean,
                                        const float* save_invstd, const float* rho_ptr, const float* penalty, float* dgamma,
-                                       float* dbeta, float* c1, float* c2, float* c3, int C, void* stream) {
+                                       float* dbeta, float* c1, float* c2, float* c3, int C, const int* cmap, void* stream) {
   ATOMNAS_REQUIRE(stats2 && stat_rows > 0 && save_mean && save_invstd && c1 && c2 && c3 && C > 0 && count > 0, "bn_finalize_bwd: bad arguments");
   ATOMNAS_REQUIRE(stat_ld >= (C + 7) / 8 * 8 && stat_ld % 4 == 0 && ((size_t)stats2 & 15) == 0, "bn_finalize_bwd: the statistics rows must be 16-byte aligned with a pitch of at least C rounded up to 8 (stat_ld=%d)", stat_ld);
   const int Cpad = (C + 7) / 8 * 8;
   hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((Cpad + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats2, stat_rows, stat_ld, (float)(1.0 / count),
-                     gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, Cpad);
+                     gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, Cpad, cmap);
   return check_launch("bn_finalize_bwd");
 }
 

@@ -94,28 +94,24 @@ def bn_forward_coeffs(bn, stats, count, dev):
     """bn: dict of arena views (gamma, beta, rm, rv, C, mods).  Uses batch statistics when the BN modules are in training
     mode (updating running statistics with their momentum; momentum None = cumulative average), running statistics otherwise."""
     C = bn["C"]
-    segs = bn.get("segs")   # fused block: contiguous [total] parameter vectors, padded-segment kernel layout (runtime.py)
-    Cp = pad8(bn["Cpad"] if segs else C)
+    cmap = bn.get("cmap")   # fused block: contiguous [total] parameter vectors against the padded-segment kernel layout (runtime.py)
+    Ck = bn["Cpad"] if cmap is not None else C   # channels of the kernel layout: one launch covers them, padding gets zeros
+    Cp = pad8(Ck)
     st = BNState()
-    zero = segs is not None   # the finalize launches of the segments leave the padding between segments untouched
-    st.scale, st.shift = _f32(Cp, dev, zero), _f32(Cp, dev, zero)
+    st.scale, st.shift = _f32(Cp, dev), _f32(Cp, dev)
     mod = bn["mods"][0]
     eps = mod.eps
-    pieces = segs if segs else [(0, 0, C)]
     if mod.training or not mod.track_running_stats:
-        st.mean, st.invstd = _f32(Cp, dev, zero), _f32(Cp, dev, zero)
+        st.mean, st.invstd = _f32(Cp, dev), _f32(Cp, dev)
         track = mod.track_running_stats
-        for po, co, c in pieces:
-            ops.bn_finalize_fwd(stats.t[po:], count, bn["gamma"][co:], bn["beta"][co:], eps, mod.momentum,
-                                bn["rm"][co:] if track else None, bn["rv"][co:] if track else None,
-                                mod.num_batches_tracked if track else None, st.scale[po:], st.shift[po:], st.mean[po:], st.invstd[po:],
-                                c, stat_rows=stats.rows, stat_ld=stats.c)
+        ops.bn_finalize_fwd(stats.t, count, bn["gamma"], bn["beta"], eps, mod.momentum, bn["rm"] if track else None,
+                            bn["rv"] if track else None, mod.num_batches_tracked if track else None, st.scale, st.shift, st.mean,
+                            st.invstd, Ck, stat_rows=stats.rows, stat_ld=stats.c, cmap=cmap)
         if track:
             bn["mgr"].bn_trained = True
     else:
         st.mean = st.invstd = None
-        for po, co, c in pieces:
-            ops.bn_eval_coeffs(bn["gamma"][co:], bn["beta"][co:], bn["rm"][co:], bn["rv"][co:], eps, st.scale[po:], st.shift[po:], c)
+        ops.bn_eval_coeffs(bn["gamma"], bn["beta"], bn["rm"], bn["rv"], eps, st.scale, st.shift, Ck, cmap=cmap)
     return st
 
 
@@ -127,15 +123,14 @@ def bn_uses_batch_stats(bn):
 def bn_backward_coeffs(bn, st, stats2, count, dev):
     """-> (c1, c2, c3) with dx = c1*g + c2*x + c3; writes dgamma / dbeta into the gradient arena."""
     C = bn["C"]
-    segs = bn.get("segs")
-    Cp = pad8(bn["Cpad"] if segs else C)
-    zero = segs is not None
-    c1, c2, c3 = _f32(Cp, dev, zero), _f32(Cp, dev, zero), _f32(Cp, dev, zero)
+    cmap = bn.get("cmap")
+    Ck = bn["Cpad"] if cmap is not None else C
+    Cp = pad8(Ck)
+    c1, c2, c3 = _f32(Cp, dev), _f32(Cp, dev), _f32(Cp, dev)
     if st.mean is None:
         raise RuntimeError("backward through a BatchNorm in eval mode is not supported")
-    for po, co, c in (segs if segs else [(0, 0, C)]):
-        ops.bn_finalize_bwd(stats2.t[po:], count, bn["gamma"][co:], st.mean[po:], st.invstd[po:], None, None, bn["dgamma"][co:],
-                            bn["dbeta"][co:], c1[po:], c2[po:], c3[po:], c, stat_rows=stats2.rows, stat_ld=stats2.c)
+    ops.bn_finalize_bwd(stats2.t, count, bn["gamma"], st.mean, st.invstd, None, None, bn["dgamma"], bn["dbeta"], c1, c2, c3, Ck,
+                        stat_rows=stats2.rows, stat_ld=stats2.c, cmap=cmap)
     return c1, c2, c3
 
 
@@ -265,9 +260,10 @@ def block_forward(pl, x2d, N, H, W, need_grad):
         # squeeze -> two tiny dense layers -> gate; the gated tensor S is the projection's operand
         HWo = Ho * Wo
         se = dict(pooled=_f32(N * HT, dev).view(N, HT), gate=_f32(N * HT, dev).view(N, HT), hpre=_f32(N * pl.se_hid, dev).view(N, pl.se_hid))
-        ops.se_squeeze(D, bD.scale, bD.shift, int(act), se["pooled"], N, HWo, HT)
-        ops.se_mlp_fwd(se["pooled"], pl.cmap, pl.se_w1, pl.se_b1, pl.se_w2, pl.se_b2, pl.se_act, se["hpre"], se["gate"], N, HT, pl.total,
-                       pl.se_hid)
+        parts = ops.se_pool_parts(N, HWo, HT)
+        pooled_parts = _f32(parts * N * HT, dev).view(parts, N, HT)
+        ops.se_squeeze(D, bD.scale, bD.shift, int(act), pooled_parts, N, HWo, HT)
+        ops.se_mlp_fwd(pooled_parts, se["pooled"], pl.cmap, pl.se_w1p, pl.se_b1, pl.se_w2t, pl.se_b2p, pl.se_act, se["hpre"], se["gate"], N, HT, pl.se_hid)
         Sx = _hidden(pl, M2, HT, T, dev)
         ops.se_scale(D, bD.scale, bD.shift, int(act), se["gate"], Sx, M2, HWo, HT)
         se["S"] = Sx
@@ -329,10 +325,12 @@ def block_backward(pl, sv, G):
         dS = _hidden(pl, M2, HT, T, dev)
         ops.gemm_nt(G, pl.WpT_pack, dS, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3)
         nh = N * pl.se_hid
-        dgate, dz2, dpooled = (_f32(N * HT, dev).view(N, HT) for _ in range(3))
+        dz2, dpooled = (_f32(N * HT, dev).view(N, HT) for _ in range(2))
+        parts = ops.se_pool_parts(N, HWo, HT)
+        dgate = _f32(parts * N * HT, dev).view(parts, N, HT)
         dz1 = _f32(nh, dev).view(N, pl.se_hid)
-        ops.se_bwd_gate(dS, D, bD.scale, bD.shift, int(act), se["gate"], se["pooled"], pl.cmap, pl.se_w1, pl.se_w2, se["hpre"], dgate, dz2,
-                        dz1, dpooled, pl.se_dw1, pl.se_db1, pl.se_dw2, pl.se_db2, N, HWo, HT, pl.total, pl.se_hid)
+        ops.se_bwd_gate(dS, D, bD.scale, bD.shift, int(act), se["gate"], se["pooled"], pl.cmap, pl.se_w1p, pl.se_w2t, se["hpre"], dgate, dz2,
+                        dz1, dpooled, pl.se_dw1, pl.se_db1, pl.se_dw2, pl.se_db2, N, HWo, HT, pl.total, pl.se_hid, se_act=pl.se_act)
         ops.se_bwd_apply(dS, D, bD.scale, bD.shift, int(act), se["gate"], dpooled, g, st2D.t, M2, HWo, HT, stat_rows=st2D.rows)
     elif fused_pb and _DP_TENSOR and ops.project_bwd_dp_supported(M2, pl.oup, HT, G, D, g, st2D.rows):
         # dP once (a narrow tensor), then the streaming form of the fused kernel: no prologue, nothing behind a branch

@@ -252,21 +252,21 @@ def project_bwd(g, p, c1, c2, c3, wpt_pack, z, zscale, zshift, act, gh, stats, d
 
 
 def bn_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, save_mean,
-                    save_invstd, C, stat_rows=None, stat_ld=None):
+                    save_invstd, C, stat_rows=None, stat_ld=None, cmap=None):
     call("atomnas_bn_finalize_fwd", _p(stats), _rows(stats, stat_rows), pad8(C) if stat_ld is None else stat_ld, float(count), _p(gamma), _p(beta), eps,
          -1.0 if momentum is None else momentum,
-         _p(running_mean), _p(running_var), _p(nbt), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), C, _stream())
+         _p(running_mean), _p(running_var), _p(nbt), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), C, _p(cmap), _stream())
 
 
-def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, scale, shift, C):
-    call("atomnas_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(scale), _p(shift), C, _stream())
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, scale, shift, C, cmap=None):
+    call("atomnas_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(scale), _p(shift), C, _p(cmap), _stream())
 
 
 def bn_finalize_bwd(stats2, count, gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, stat_rows=None,
-                    stat_ld=None):
+                    stat_ld=None, cmap=None):
     call("atomnas_bn_finalize_bwd", _p(stats2), _rows(stats2, stat_rows), pad8(C) if stat_ld is None else stat_ld, float(count), _p(gamma), _p(save_mean), _p(save_invstd),
          _p(rho_ptr), _p(penalty),
-         _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), C, _stream())
+         _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), C, _p(cmap), _stream())
 
 
 def bn_apply(x, scale, shift, relu, res, y, M, C):
@@ -295,14 +295,23 @@ def act_bwd_stats(dy, z, scale, shift, relu, g, stats2, M, C, stat_rows=None):
          _ld(g) if g is not None else 0, _p(stats2), _rows(stats2, stat_rows), M, C, dt_code(dy.dtype), _stream())
 
 
-def se_squeeze(d, scale, shift, act, pooled, N, HW, C):
-    call("atomnas_se_squeeze", _p(d), _ld(d), _ss(d), _p(scale), _p(shift), int(act), _p(pooled), pooled.stride(0), N, HW, C,
-         dt_code(d.dtype), _stream())
+def se_pool_parts(N, HW, C):
+    """planes [parts][N][C] the per-image sums of se_squeeze / se_bwd_gate's dgate pass are produced in (include/atomnas_hip.h)"""
+    return int(_lib.load().atomnas_se_pool_parts(int(N), int(HW), int(C)))
 
 
-def se_mlp_fwd(pooled, cmap, w1, b1, w2, b2, act, hpre, gate, N, HT, total, hid):
-    call("atomnas_se_mlp_fwd", _p(pooled), pooled.stride(0), _p(cmap), _p(w1), _p(b1), _p(w2), _p(b2), int(act), _p(hpre), _p(gate), N, HT,
-         total, hid, _stream())
+def se_squeeze(d, scale, shift, act, pooled_parts, N, HW, C):
+    """pooled_parts: fp32 [parts][N][C], parts = se_pool_parts(N, HW, C)"""
+    parts = pooled_parts.shape[0]
+    call("atomnas_se_squeeze", _p(d), _ld(d), _ss(d), _p(scale), _p(shift), int(act), _p(pooled_parts), pooled_parts.stride(1), parts,
+         pooled_parts.stride(0), N, HW, C, dt_code(d.dtype), _stream())
+
+
+def se_mlp_fwd(pooled_parts, pooled, cmap, w1p, b1, w2t, b2p, act, hpre, gate, N, HT, hid):
+    """w1p [hid][HT], w2t [hid][HT], b2p [HT]: the gate's dense layers packed over the padded channel layout (runtime.py);
+    pooled [N][HT] receives the sum of the planes of pooled_parts"""
+    call("atomnas_se_mlp_fwd", _p(pooled_parts), pooled_parts.stride(1), pooled_parts.shape[0], pooled_parts.stride(0), _p(pooled), _p(cmap),
+         _p(w1p), _p(b1), _p(w2t), _p(b2p), int(act), _p(hpre), _p(gate), N, HT, hid, _stream())
 
 
 def se_scale(d, scale, shift, act, gate, out, M, HW, C):
@@ -310,11 +319,12 @@ def se_scale(d, scale, shift, act, gate, out, M, HW, C):
          HW, C, dt_code(d.dtype), _stream())
 
 
-def se_bwd_gate(ds, d, scale, shift, act, gate, pooled, cmap, w1, w2, hpre, dgate, dz2, dz1, dpooled, dw1, db1, dw2, db2, N, HW, HT, total,
-                hid):
+def se_bwd_gate(ds, d, scale, shift, act, gate, pooled, cmap, w1p, w2t, hpre,  # dgate: fp32 [parts][N][HT] workspace
+                dgate, dz2, dz1, dpooled, dw1, db1, dw2, db2, N, HW, HT, total,
+                hid, se_act=None):
     call("atomnas_se_bwd_gate", _p(ds), _ld(ds), _ss(ds), _p(d), _ld(d), _ss(d), _p(scale), _p(shift), int(act), _p(gate), _p(pooled),
-         gate.stride(0), _p(cmap), _p(w1), _p(w2), _p(hpre), _p(dgate), _p(dz2), _p(dz1), _p(dpooled), _p(dw1), _p(db1), _p(dw2), _p(db2), N,
-         HW, HT, total, hid, dt_code(d.dtype), _stream())
+         gate.stride(0), _p(cmap), _p(w1p), _p(w2t), _p(hpre), _p(dgate), dgate.shape[0], dgate.stride(0), _p(dz2), _p(dz1), _p(dpooled), _p(dw1), _p(db1), _p(dw2), _p(db2),
+         int(act if se_act is None else se_act), N, HW, HT, total, hid, dt_code(d.dtype), _stream())
 
 
 def se_bwd_apply(ds, d, scale, shift, act, gate, dpooled, g, stats2, M, HW, C, stat_rows=None):

@@ -299,6 +299,14 @@ class ArenaManager:
                         reg_slots.append(("dense", so[key + "w"], conv_.weight.numel()))
                         bind_param(conv_, "weight", so[key + "w"], tuple(conv_.weight.shape))
                         bind_param(conv_, "bias", so[key + "b"], tuple(conv_.bias.shape))
+                    # fp32 copies of the gate's dense layers over the padded channel layout, both with the channels contiguous:
+                    # W1p[j][sg + c] = W1[j][st + c], W2t[j][sg + c] = W2[st + c][j], b2p[sg + c] = b2[st + c] (csrc/se.hip k_se_mlp)
+                    o1, o2, o3 = lpf.take(pl.se_hid * HT), lpf.take(pl.se_hid * HT), lpf.take(HT)
+                    for sg, stt, h in zip(pl.seg, pl.start, pl.hid):
+                        pack_jobs_f.append((so["se1w"] + stt, o1, pl.se_hid, h, total, HT, sg, 0))
+                        pack_jobs_f.append((so["se2w"] + stt * pl.se_hid, o2, h, pl.se_hid, pl.se_hid, HT, sg, 2))
+                        pack_jobs_f.append((so["se2b"] + stt, o3, 1, h, total, HT, sg, 0))
+                    pk["se"] = (o1, o2, o3)
                 pl.g_hi = lp.size; plans.append((m, pl, dict(so=so, pk=pk)))
             elif isinstance(m, mb.ConvBNReLU) and id(m) not in handled:
                 conv, bn, _ = list(m.children())
@@ -587,12 +595,17 @@ class ArenaManager:
         HT, total = pl.HT, pl.total
         pl.valid = True
         segs = [(sg, st, h) for sg, st, h in zip(pl.seg, pl.start, pl.hid)]   # (padded offset, contiguous offset, channels)
+        # padded kernel channel -> index into the module's contiguous [total] vectors, -1 for the padding between branch segments
+        cmap = torch.full((HT,), -1, dtype=torch.int32)
+        for sg, st, h in segs:
+            cmap[sg:sg + h] = torch.arange(st, st + h, dtype=torch.int32)
+        pl.cmap = cmap.to(P.device)
 
         def bnv(sl, C, mods, segmented):
             d = dict(gamma=P[sl["g"]:sl["g"] + C], beta=P[sl["b"]:sl["b"] + C], dgamma=G[sl["g"]:sl["g"] + C],
                      dbeta=G[sl["b"]:sl["b"] + C], rm=S[sl["rm"]:sl["rm"] + C], rv=S[sl["rv"]:sl["rv"] + C], C=C, mods=mods, mgr=self)
             if segmented:   # contiguous [total] vectors, padded [HT] kernel layout
-                d["segs"], d["Cpad"] = segs, HT
+                d["cmap"], d["Cpad"] = pl.cmap, HT
             return d
 
         idx = 1 if pl.expand else 0
@@ -613,16 +626,15 @@ class ArenaManager:
             for sg, h in zip(pl.seg, pl.hid):
                 rv[sg + h:sg + pl.segpad(h)] = 1.0
         if pl.se:
-            cmap = torch.full((HT,), -1, dtype=torch.int32)
-            for sg, st, h in segs:
-                cmap[sg:sg + h] = torch.arange(st, st + h, dtype=torch.int32)
-            pl.cmap = cmap.to(P.device)
             n1, n2 = pl.se_hid * total, total * pl.se_hid
             pl.se_w1, pl.se_b1 = P[so["se1w"]:so["se1w"] + n1], P[so["se1b"]:so["se1b"] + pl.se_hid]
             pl.se_w2, pl.se_b2 = P[so["se2w"]:so["se2w"] + n2], P[so["se2b"]:so["se2b"] + total]
             pl.se_dw1, pl.se_db1 = G[so["se1w"]:so["se1w"] + n1], G[so["se1b"]:so["se1b"] + pl.se_hid]
             pl.se_dw2, pl.se_db2 = G[so["se2w"]:so["se2w"] + n2], G[so["se2b"]:so["se2b"] + total]
             pl.se_act = act_code(m.se_op.active_fn)
+            o1, o2, o3 = pk["se"]
+            nh = pl.se_hid * HT
+            pl.se_w1p, pl.se_w2t, pl.se_b2p = self.packF[o1:o1 + nh], self.packF[o2:o2 + nh], self.packF[o3:o3 + HT]
 
     def _packview(self, t):
         off, rows, ld = t

@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 4   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL */
+#define ATOMNAS_ABI_VERSION 5   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -166,15 +166,19 @@ int atomnas_project_bwd(const void* g, int ldg, const void* p, int ldp, const fl
  *   average 1/(counter+1); the caller bumps the counter). */
 int atomnas_bn_finalize_fwd(const float* stats, int stat_rows, int stat_ld, double count, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* scale, float* shift,
-                            float* save_mean, float* save_invstd, int C, void* stream);
+                            float* save_mean, float* save_invstd, int C, const int* cmap, void* stream);
+/* ABI 5, cmap (may be NULL = identity), all three entry points: the statistics and coefficient vectors are indexed by the kernel
+ *   channel c < C (a fused block's padded branch segments), the module's parameter / running-statistics / gradient vectors by
+ *   cmap[c]; cmap[c] = -1 marks padding inside the range, whose coefficients are written as zeros.  One launch then covers the
+ *   whole padded width of a fused block's expand BatchNorm (models/mobilenet_base.py:236-247) instead of one per branch segment. */
 /* eval mode: scale/shift from the running statistics */
 int atomnas_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
-                           float* scale, float* shift, int C, void* stream);
+                           float* scale, float* shift, int C, const int* cmap, void* stream);
 /* finalize backward: stats2=[sum g, sum g*x] -> dgamma (+ rho*penalty*sign(gamma), utils/prune.py:161-167), dbeta and the
  *   coefficients of dx = c1*g + c2*x + c3.  rho is read from device memory (rho_ptr, may be NULL). */
 int atomnas_bn_finalize_bwd(const float* stats2, int stat_rows, int stat_ld, double count, const float* gamma, const float* save_mean, const float* save_invstd,
                             const float* rho_ptr, const float* penalty, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
-                            int C, void* stream);
+                            int C, const int* cmap, void* stream);
 /* y = act(x*scale+shift) (+ res): the shared pw_bn + residual of a block, models/mobilenet_base.py:379-381 */
 int atomnas_bn_apply(const void* x, int ldx, const float* scale, const float* shift, int relu, const void* res, int ldres, void* y,
                      int ldy, long M, int C, int dtype, void* stream);
@@ -199,20 +203,30 @@ int atomnas_act_bwd_stats(const void* dy, int lddy, const void* z, int ldz, cons
 /* ---- Squeeze-and-Excitation of the fused block (AtomNAS+): models/mobilenet_base.py:93-117 inside :256-267.
  *   A = act(D*scale+shift) is the activated depthwise output (never materialised), D the raw depthwise output [M = N*HW][C];
  *   cmap[c]: row / column of the reference's SE weights (w1 [hid][total], w2 [total][hid]) for padded channel c, -1 for padding;
+ *   ABI 5: the kernels read fp32 copies of the weights packed over the block's padded channels, channels contiguous in both:
+ *   w1p[j][c] = w1[j][cmap c], w2t[j][c] = w2[cmap c][j], b2p[c] = b2[cmap c], zeros at padding (atomnas_pack_weights jobs);
+ *   the weight GRADIENTS are written in the reference's layouts through cmap;
  *   pooled / gate / dgate / dz2 / dpooled: fp32 [N][ldg];  hpre / dz1: fp32 [N][hid].
  * forward:  pooled = mean_hw A;  hpre = w1*pooled + b1;  gate = sigmoid(w2*act(hpre) + b2);  out = A * gate[n] */
-int atomnas_se_squeeze(const void* d, int ldd, long d_ss, const float* scale, const float* shift, int act, float* pooled, int ldp, int N,
-                       int HW, int C, int dtype, void* stream);
-int atomnas_se_mlp_fwd(const float* pooled, int ldp, const int* cmap, const float* w1, const float* b1, const float* w2, const float* b2,
-                       int act, float* hpre, float* gate, int N, int HT, int total, int hid, void* stream);
+/* ABI 5: the per-image sums leave atomnas_se_squeeze (and the dgate pass inside atomnas_se_bwd_gate) as `parts` planes
+ *   [parts][N][ld] (plane pitch part_stride floats), each over a share of the image's pixels, parts = atomnas_se_pool_parts(N, HW, C)
+ *   in 1..16; the dense-layer kernels add the planes in plane order and atomnas_se_mlp_fwd stores the sum in `pooled`. */
+int atomnas_se_pool_parts(int N, int HW, int C);
+int atomnas_se_squeeze(const void* d, int ldd, long d_ss, const float* scale, const float* shift, int act, float* pooled_parts, int ldp,
+                       int parts, long part_stride, int N, int HW, int C, int dtype, void* stream);
+int atomnas_se_mlp_fwd(const float* pooled_parts, int ldp, int parts, long part_stride, float* pooled, const int* cmap, const float* w1p,
+                       const float* b1, const float* w2t, const float* b2p, int act, float* hpre, float* gate, int N, int HT, int hid,
+                       void* stream);
 int atomnas_se_scale(const void* d, int ldd, long d_ss, const float* scale, const float* shift, int act, const float* gate, int ldg,
                      void* out, int ldo, long o_ss, long M, int HW, int C, int dtype, void* stream);
 /* backward of the gate: dgate = sum_hw dS*A;  dz2 = dgate*gate*(1-gate);  dz1 = act'(hpre) * w2^T dz2;  dpooled = w1^T dz1;
- *   dw1 += dz1^T pooled, db1 += sum dz1, dw2 += dz2^T act(hpre), db2 += sum dz2 (batch loops in image order: bit-reproducible) */
+ *   dw1 += dz1^T pooled, db1 += sum dz1, dw2 += dz2^T act(hpre), db2 += sum dz2 (batch loops in image order: bit-reproducible);
+ *   act: the block's activation (A), se_act: the activation between the two dense layers (ABI 5: separate arguments) */
 int atomnas_se_bwd_gate(const void* ds, int ldds, long ds_ss, const void* d, int ldd, long d_ss, const float* scale, const float* shift,
-                        int act, const float* gate, const float* pooled, int ldg, const int* cmap, const float* w1, const float* w2,
-                        const float* hpre, float* dgate, float* dz2, float* dz1, float* dpooled, float* dw1, float* db1, float* dw2,
-                        float* db2, int N, int HW, int HT, int total, int hid, int dtype, void* stream);
+                        int act, const float* gate, const float* pooled, int ldg, const int* cmap, const float* w1p, const float* w2t,
+                        const float* hpre, float* dgate, int parts, long part_stride, float* dz2, float* dz1, float* dpooled, float* dw1,
+                        float* db1, float* dw2,
+                        float* db2, int se_act, int N, int HW, int HT, int total, int hid, int dtype, void* stream);
 /* g = act'(D*scale+shift) * (dS*gate[n] + dpooled[n]/HW): the gradient wrt the depthwise BatchNorm output;  stats2 rows [sum g, sum g*D] */
 int atomnas_se_bwd_apply(const void* ds, int ldds, long ds_ss, const void* d, int ldd, long d_ss, const float* scale, const float* shift,
                          int act, const float* gate, const float* dpooled, int ldg, void* g, int ldgo, long g_ss, float* stats2,
