@@ -50,6 +50,8 @@ SIGNATURES = {
     "atomnas_reg_grad": [vp, vp, vp, i32, i32, vp, vp, vp],
     "atomnas_reg_value": [vp, vp, i32, i32, vp, f32, vp, vp, vp],
     "atomnas_pack_weights": [vp, vp, vp, i32, i32, vp],
+    "atomnas_reduce_defer": [i32, vp],
+    "atomnas_reduce_flush": [vp],
     "atomnas_gamma_mask": [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp],
     "atomnas_mask_index": [vp, i32, vp, vp, vp],
     "atomnas_gather_dim": [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp],

@@ -40,6 +40,31 @@ def _rows(stats, stat_rows):
 _TN_WS_FLOATS = int(os.environ.get("ATOMNAS_TN_WS_MB", "32")) << 18   # experiment switch: cap of the partial-output scratch
 
 
+# ---- deferred fixed-order reductions (csrc/reduce.hip): while on, the weight-gradient kernels leave their per-workgroup partials in
+# their workspaces and only RECORD the reduction; reduce_flush() then sums all recorded jobs with one launch per 56 jobs.  The
+# workspaces are kept alive here until the flush.  Flush before anything reads the gradient arena.
+_DEFER = [False]
+_DEFER_KEEP = []
+
+
+def reduce_defer(on):
+    call("atomnas_reduce_defer", int(bool(on)), _stream())
+    _DEFER[0] = bool(on)
+    if not on:
+        del _DEFER_KEEP[:]
+
+
+def reduce_flush():
+    call("atomnas_reduce_flush", _stream())
+    del _DEFER_KEEP[:]
+
+
+def _keep(ws):
+    if _DEFER[0] and ws is not None:
+        _DEFER_KEEP.append(ws)
+    return ws
+
+
 def tn_workspace(nu, nv, dev):
     """scratch for the per-row-chunk partial outputs of atomnas_pw_gemm_tn (at most 32 MiB)"""
     return torch.empty(max(2 * nu * nv, min(256 * nu * nv, _TN_WS_FLOATS)), dtype=torch.float32, device=dev)
@@ -153,6 +178,7 @@ def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, d
     rows = _rows(stats, stat_rows) if stats is not None else stat_rows_for(C)
     if dw is not None and dw_ws is None:
         dw_ws = torch.empty(rows * C * k * k, dtype=torch.float32, device=x.device)
+    _keep(dw_ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
     call("atomnas_dwconv_bwd", _p(g), _ld(g), _ss(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _ss(yraw), _p(c1), _p(c2), _p(c3),
@@ -197,6 +223,7 @@ def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc
         ws = tn_workspace(NU, NV, u.device)
     elif ws is False:
         ws = None
+    _keep(ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d NU%d NV%d pro%d,%d" % (M, NU, NV, u_mode, v_mode))
     call("atomnas_pw_gemm_tn", u_mode, _p(u), _ld(u), _ss(u), _p(u2), _ld(u2) if u2 is not None else 0, _ss(u2), _p(uc1), _p(uc2), _p(uc3),
@@ -220,6 +247,7 @@ def expand_bwd(h, e, c1, c2, c3, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None,
     wt, ldw = wt_pack, wt_pack.stride(0)
     if ws is None:
         ws = expand_bwd_workspace(inp, hid, x.device)
+    _keep(ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d fusedbwd" % (M, inp, hid))
     call("atomnas_expand_bwd", _p(h), _ld(h), _ss(h), _p(e), _ld(e) if e is not None else 0, _ss(e), _p(c1), _p(c2), _p(c3), _p(x), _ld(x), _p(wt), ldw,
@@ -244,6 +272,7 @@ def project_bwd(g, p, c1, c2, c3, wpt_pack, z, zscale, zshift, act, gh, stats, d
     _chk_cuda(g, z, gh, dwp, wpt_pack)
     if ws is None:
         ws = torch.empty(min(512 * oup * hid, 16 << 20), dtype=torch.float32, device=g.device)
+    _keep(ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d fusedbwd%s" % (M, hid, oup, "" if p is not None else "+dP"))
     call("atomnas_project_bwd", _p(g), _ld(g), _p(p), _ld(p) if p is not None else 0, _p(c1), _p(c2), _p(c3), _p(wpt_pack), wpt_pack.stride(0), _p(z), _ld(z), _ss(z),

@@ -271,6 +271,17 @@ int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_a
  *   struct { long src_off, dst_off; int rows, cols, src_ld, dst_ld, c_off, mode; }  (mode 0 [N][K], 1 transposed, 2 depthwise taps) */
 int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream);
 
+/* ---- deferred fixed-order reductions (ABI 5).  The weight-gradient entry points (atomnas_pw_gemm_tn, atomnas_dwconv_bwd,
+ *   atomnas_expand_bwd, atomnas_project_bwd) write per-workgroup partials to their workspace and sum them in a fixed order with one
+ *   small launch each: ~110 launches of a few microseconds per supernet step, every one a ~5 us node of the step's hipGraph.
+ *   atomnas_reduce_defer(1): from now on those sums are only RECORDED (process-wide; backward may run on another thread);
+ *   atomnas_reduce_flush(stream): sums all recorded jobs with one launch per 56 jobs (the job table travels in the kernel arguments,
+ *   so the launch is capturable), same per-element order of additions: bit-identical results.  The caller keeps the workspaces of
+ *   the recorded calls alive and unmodified until the flush, and flushes before anything reads the gradients (collective,
+ *   optimizer).  atomnas_reduce_defer(0) flushes what is recorded and returns to immediate reductions. */
+int atomnas_reduce_defer(int on, void* stream);
+int atomnas_reduce_flush(void* stream);
+
 /* ---- dynamic shrink
  * alive masks |gamma| > thr (train.py:46-63, utils/prune.py:190-195): mode 0 current, 1 current|EMA, 2 EMA only.
  *   jobs_dev: struct { long off; int count; int out_off; };  outputs: mask bytes, ascending kept-channel indices, kept counts */

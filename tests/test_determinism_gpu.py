@@ -102,6 +102,22 @@ def test_training_iterations_bit_identical(gpu_lib, dtype):
             assert torch.equal(arenas[k], a0[k]), k
 
 
+def test_deferred_reductions_bit_identical_to_immediate(gpu_lib, monkeypatch):
+    """The batched form of the weight-gradient reductions (csrc/reduce.hip atomnas_reduce_defer / _flush, one launch per 56
+    recorded jobs at the end of backward) adds every element's partials in the same order as the per-call launches: three
+    iterations are bit-identical with the switch on and off, eagerly and through the graphs."""
+    from atomnas_amd import engine
+    runs = []
+    for defer in (False, True):
+        monkeypatch.setattr(engine, "_DEFER_REDUCE", defer)
+        runs += [_run_steps(torch.bfloat16, False), _run_steps(torch.bfloat16, True)]
+    a0, l0 = runs[0]
+    for arenas, loss in runs[1:]:
+        assert torch.equal(loss, l0), (loss, l0)
+        for k in a0:
+            assert torch.equal(arenas[k], a0[k]), k
+
+
 def _run_full_size(use_graph, steps=3):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, ROOT)
