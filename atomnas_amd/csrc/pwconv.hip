@@ -2523,14 +2523,14 @@ static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const O
 //   * rows beyond M are cut off in U's fragments (the copies of such rows read row M - 1: finite garbage times zero).
 // A workgroup owns every U column of a U tile (<= 192) and 128 V columns (wave w: V tiles w and w + 4), and a row chunk; partial
 // outputs per row chunk go to the workspace and are summed in chunk order (reduce_parts), as in k_gemm_tn2.
-//   * UC: U is a dense [M][NU] matrix (pitch == NU, one U tile): a stage's 32 rows are ONE contiguous run of 64 NU bytes, copied as is
-//     (whole 128-byte lines per copy instead of 32-byte pieces of 32 lines) and read by the transposing reads with the row pitch NU.
-template <int UTT, bool VPRO, int TN3_DEPTH, bool UC>
+// (Tried and removed: copying a dense U's 32 stage rows as ONE contiguous run of 64 NU bytes, read back with the row pitch NU --
+//  whole 128-byte lines per copy instead of 32-byte pieces of 32 lines.  1.355 against 1.235 ms over the step's 16 launches.)
+template <int UTT, bool VPRO, int TN3_DEPTH>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn3(Operand U, int NU, Operand V, int NV, float* __restrict__ out, long si, long sj, long M,
                                                   long rows_per_block, int nchunks, int vt, int uz, float* __restrict__ ws) {
   using T = bf16_t;
   using MM = Mma<T>;
-  constexpr int NSUB = 8 + UTT;              // subtiles of a stage: 8 V tiles, UTT U tiles (UC: UTT KB for the rows of U, NU <= 16 UTT)
+  constexpr int NSUB = 8 + UTT;              // subtiles of a stage: 8 V tiles, UTT U tiles
   constexpr int DPS = (NSUB + 3) / 4;        // copies per wave and stage
   constexpr int STAGE = NSUB * 512;          // elements per stage buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2569,12 +2569,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn3(Operand U, int NU, Operand 
       src_base[i] = reinterpret_cast<const T*>(V.p1);
       src_off[i] = lay_off(0, c, V.ld1, V.ss1);
       src_mul[i] = V.ss1 ? 16 : V.ld1;
-    } else if (UC) {   // KB number sub - 8 of the stage's 64 NU contiguous bytes of U: this lane's 16 bytes
-      long e = ((long)(sub - 8) * 1024 + lane * 16) / 2;     // element offset inside the stage's rows
-      e = e < 32L * NU ? e : 0;                               // past the 32 rows (NU < 16 UTT): any valid bytes, never read
-      src_base[i] = reinterpret_cast<const T*>(U.p1);
-      src_off[i] = e - (long)r_l * NU;                        // copy_stage adds (row + r_l) * src_mul
-      src_mul[i] = NU;
     } else {         // U tile sub - 8
       int c = u0 + 16 * (sub - 8) + 8 * h_l;
       c = c < ((NU + 7) & ~7) ? c : 0;
@@ -2588,13 +2582,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn3(Operand U, int NU, Operand 
     const int sc = s < nstages ? s : nstages - 1;   // past the chunk: re-copy its last stage (keeps the copy count per stage constant)
     long row = r_beg + 32L * sc + r_l;
     row = row < M ? row : M - 1;
-    long urow = r_beg + 32L * sc;                   // UC: first row of the contiguous run; a run that would pass the end of U starts
-    if (UC && urow + 32 > M) urow = M - 32;         // 32 rows before it (the fragment reads shift by the same amount)
     const unsigned slot = lds0 + (unsigned)(s % TN3_DEPTH) * (unsigned)(STAGE * 2);
 #pragma unroll
     for (int i = 0; i < DPS; ++i) {
-      const bool is_u = UC && (wave + 4 * i >= 8);
-      const T* g = src_base[i] + ((is_u ? urow + r_l : row) * src_mul[i] + src_off[i]);
+      const T* g = src_base[i] + (row * src_mul[i] + src_off[i]);
       const unsigned d = __builtin_amdgcn_readfirstlane(slot + dst_off[i]);
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -2641,27 +2632,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn3(Operand U, int NU, Operand 
     TrFrag bfp[2], afp[UTT];
 #pragma unroll
     for (int v = 0; v < 2; ++v) bfp[v] = tr_frag(slot + (unsigned)(4 * v + wave) * 1024u);
-    // UC: rows of pitch NU; in a run shifted to end at the tensor's last row the stage's first row sits `ushift` rows into the image
-    const long ustart = r_beg + 32L * s;
-    const int ushift = (UC && ustart + 32 > M) ? (int)(ustart - (M - 32)) : 0;
 #pragma unroll
-    for (int t = 0; t < UTT; ++t) {
-      if (t < ut) {
-        if constexpr (UC) {
-          // lane's 8-byte segments: rows ushift + 8 q + j / 4 (+ 4), columns 16 t + 4 (j % 4) ..; rows past the image (ushift > 0) are
-          // clamped to its last row and cut off by the row mask below
-          int r0 = ushift + 8 * q + (j >> 2), r1 = r0 + 4;
-          r0 = r0 < 32 ? r0 : 31; r1 = r1 < 32 ? r1 : 31;
-          const unsigned ub = slot + 8u * 1024u + (unsigned)((16 * t + 4 * (j & 3)) * 2);
-          bf16x4 lo, hi;
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ub + (unsigned)(r0 * NU * 2)) : "memory");
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ub + (unsigned)(r1 * NU * 2)) : "memory");
-          afp[t] = TrFrag{lo, hi};
-        } else {
-          afp[t] = tr_frag(slot + (unsigned)(8 + t) * 1024u);
-        }
-      }
-    }
+    for (int t = 0; t < UTT; ++t)
+      if (t < ut) afp[t] = tr_frag(slot + (unsigned)(8 + t) * 1024u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 bf[2];
@@ -2725,15 +2698,11 @@ static int launch_tn3_cfg(const Operand& U, int NU, int vmode, const Operand& V,
   const size_t lds = (size_t)depth * (8 + UTT) * 1024;
   if (lds > max_lds_bytes()) return -1;
   static const bool dbg = getenv("ATOMNAS_TN3_DEBUG") != nullptr;
-  static const int uc_env = getenv("ATOMNAS_TN3_UC") ? atoi(getenv("ATOMNAS_TN3_UC")) : 1;   // experiment switch
-  // dense U (pitch == NU), one U tile, rows 16-byte aligned and whole 8-byte segments per row, at least one full stage of rows
-  const bool uc = uc_env && U.ss1 == 0 && U.ld1 == NU && uz == 1 && NU % 8 == 0 && M >= 32 && 32L * NU * 2 <= (long)UTT * 1024;
   const long max_chunks = (ws && (long)NU * NV > 0) ? ws_floats / ((long)NU * NV) : 1;
   long nparts = 1;
 #define TN3_CASE(VP)                                                                                                          \
   {                                                                                                                           \
-    auto kern = uc ? (depth == 4 ? k_gemm_tn3<UTT, VP, 4, true> : (depth == 3 ? k_gemm_tn3<UTT, VP, 3, true> : k_gemm_tn3<UTT, VP, 2, true>)) \
-                   : (depth == 4 ? k_gemm_tn3<UTT, VP, 4, false> : (depth == 3 ? k_gemm_tn3<UTT, VP, 3, false> : k_gemm_tn3<UTT, VP, 2, false>)); \
+    auto kern = depth == 4 ? k_gemm_tn3<UTT, VP, 4> : (depth == 3 ? k_gemm_tn3<UTT, VP, 3> : k_gemm_tn3<UTT, VP, 2>);          \
     const long resident = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                  \
     if (dbg) fprintf(stderr, "tn3: M %ld NU %d NV %d UTT %d depth %d lds %zu per_cu %ld\n", M, NU, NV, UTT, depth, lds, resident / num_cus()); \
     long chunks = resident / ((long)vt * uz);                                                                                 \
