@@ -2838,6 +2838,278 @@ static int launch_project_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, co
   return reduce_parts(ws, (long)K * N, (int)nranges, (long)K * N, dwp, N, si, sj, st);
 }
 
+// ------------------------------------------------------------------------------------------------ streaming expand backward (e == NULL)
+// The one-stream form of the expand backward (dE = c1 * h, atomnas_expand_bwd with e == NULL) as a pure stream of h:
+//   gx[m][n]  = sum_k h[m][k] * (c1[k] We[k][n])  (+ x M + v + add)          -- c1 folded into the RESIDENT weights, once per workgroup
+//   R[n][k]   = c1[k] * sum_m x[m][n] h[m][k]                                 -- c1 applied to the accumulators, once per workgroup
+// so the loop body has no prologue arithmetic at all: a stage (64 rows x 64 hidden channels of h = 8 row-major [32][16] subtiles, each
+// 1 KB CONTIGUOUS in the slab-major tensor) is copied HBM -> LDS by global_load_lds_dwordx4 into a ring of DEPTH stages, DEPTH - 1
+// stages ahead of the MFMAs, and waited for with a COUNTED vmcnt (the structure of k_gemm_tn3).  The fragments of gx's product are
+// plain 16-byte LDS reads of those subtiles, the k-major fragments of the weight-gradient product come out of the same bytes with
+// ds_read_b64_tr_b16.  The block's x rows (and the residual rows) ride in the same queue, one small tile per row block.
+// k_expand_bwd kept ONE 64-channel chunk of h per wave in flight in registers behind conditional loads: 16 KB per CU in flight, which at
+// ~2 us of loaded HBM latency is the 2.0 TB/s it measured (Little's law), whatever its instruction count.  Here: 48 KB per CU.
+// Every vector-memory operation of the loop is issued by this code (the compiler knows of none but the epilogue's stores, which need
+// no wait), so the only vmcnt waits are the counted ones.
+template <int UT, int NCH, int DEPTH>
+__global__ __launch_bounds__(256, 2) void k_expand_bwd_s(const bf16_t* __restrict__ h, long hss, const float* __restrict__ c1,
+                                                         const bf16_t* __restrict__ Wt, int ldw, const bf16_t* __restrict__ x, int ldx,
+                                                         const bf16_t* __restrict__ add, int ldadd, bf16_t* __restrict__ gx, int ldgx,
+                                                         const bf16_t* __restrict__ mpk, int ldm, const float* __restrict__ vb,
+                                                         float* __restrict__ ws, long M, int N, int K) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  constexpr int KP = NCH * 64 + 8;   // pitch of the resident weights (elements): 16-byte aligned rows, 4 banks apart
+  constexpr int STAGE_B = 8 * 1024;  // bytes of a stage: 8 subtiles [32 rows][16 channels]
+  constexpr int XT_B = 2 * UT * 1024;   // bytes of an x (or residual) tile: 2 row halves x UT channel tiles
+  constexpr int XPASS = (2 * UT + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_xs[];
+  T* s_w = reinterpret_cast<T*>(smem_xs);                                  // [16 UT][KP]  c1[k] * We[k][n], row n
+  unsigned char* s_st = smem_xs + (size_t)16 * UT * KP * sizeof(T);       // [DEPTH] stages
+  unsigned char* s_x = s_st + DEPTH * STAGE_B;                             // [2] x tiles
+  unsigned char* s_a = s_x + 2 * XT_B;                                     // [2] residual tiles
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int nchunk = (K + 63) / 64, nslabs = (K + 15) / 16;
+  const long rblocks = (M + 63) / 64;
+  const int rs = blockIdx.x, R = gridDim.x;
+  const long nb = (rblocks - rs + R - 1) / R;   // row blocks of this workgroup (rs < rblocks)
+
+  // resident weights, scaled by c1 (zero rows / columns past N / K: whatever a clamped copy brings in there meets zeros)
+  for (int idx = tid; idx < 16 * UT * NCH * 8; idx += 256) {
+    const int n = idx / (NCH * 8), k = (idx % (NCH * 8)) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)0.f;
+    if (n < N && k < K) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(Wt + (long)n * ldw + k);
+      float c[8];
+      VecIO<float, 8>::load(c1 + k, c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((k + e < K) ? (float)w[e] * c[e] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(s_w + n * KP + k) = o;
+  }
+  // x M correction (A fragments of M, rows = output channels) and the bias, in registers for the whole kernel
+  constexpr int MKS = (UT + 1) / 2;   // k-steps (32 x channels each) of the x M product
+  bf16x8 mf[MKS][UT];
+  float vbv[UT][4];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) {
+#pragma unroll
+    for (int ks = 0; ks < MKS; ++ks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mf[ks][t][e] = (bf16_t)0.f;
+      if (mpk && 32 * ks + 8 * q < ldm) mf[ks][t] = *reinterpret_cast<const bf16x8*>(mpk + (long)(16 * t + j) * ldm + 32 * ks + 8 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vbv[t][r] = (vb && 16 * t + 4 * q + r < N) ? vb[16 * t + 4 * q + r] : 0.f;
+  }
+  __syncthreads();   // (also: the loads above are complete before the counted waits below start counting)
+
+  const unsigned lds_st = (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char*)s_st);
+  const unsigned lds_x = (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char*)s_x);
+  const unsigned lds_a = (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char*)s_a);
+  auto dma = [&](const T* g, unsigned dst) {   // 64 lanes x 16 bytes -> LDS bytes dst .. dst + 1023, lane-linear
+    const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+  };
+  // issue side of the queue: item = (row block ib of this workgroup, chunk ic); past the end the last item is copied again
+  long ib = 0;
+  int ic = 0, islot = 0;
+  auto issue_next = [&]() {
+    const bool live = ib < nb;
+    const long rb = rs + (live ? ib : nb - 1) * R;
+    const int c = live ? ic : nchunk - 1;
+    if (live && ic == 0) {   // the row block's x rows (and residual rows): sub = (row half, channel tile), lane -> (row, 8-channel half)
+#pragma unroll
+      for (int i = 0; i < XPASS; ++i) {
+        int sub = wave + 4 * i;
+        sub = sub < 2 * UT ? sub : 2 * UT - 1;
+        const int rh = sub / UT, ct = sub % UT;
+        long row = rb * 64 + rh * 32 + (lane >> 1);
+        row = row < M ? row : M - 1;
+        const int ch = 16 * ct + 8 * (lane & 1);
+        dma(x + row * ldx + (ch < ldx - 8 ? ch : ldx - 8), lds_x + (unsigned)(ib & 1) * XT_B + (unsigned)sub * 1024u);
+        if (add) dma(add + row * ldadd + (ch < ldadd - 8 ? ch : ldadd - 8), lds_a + (unsigned)(ib & 1) * XT_B + (unsigned)sub * 1024u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // subtiles wave, wave + 4 of the stage: (row half, channel tile) = (i, wave)
+      int slab = 4 * c + wave;
+      slab = slab < nslabs ? slab : nslabs - 1;
+      long row = rb * 64 + 32 * i + (lane >> 1);
+      row = row < M ? row : M - 1;
+      dma(h + slab * hss + row * 16 + 8 * (lane & 1), lds_st + (unsigned)islot * STAGE_B + (unsigned)(4 * i + wave) * 1024u);
+    }
+    islot = islot + 1 == DEPTH ? 0 : islot + 1;
+    if (++ic == nchunk) { ic = 0; ++ib; }
+  };
+
+  const unsigned tr_lane = (unsigned)(((8 * q + (j >> 2)) * 16 + 4 * (j & 3)) * 2);
+  auto tr_frag = [&](unsigned sub_addr) {
+    const unsigned a0 = sub_addr + tr_lane;
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(hi) : "v"(a0) : "memory");
+    return TrFrag{lo, hi};
+  };
+
+  f32x4 racc[NCH][UT];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < UT; ++t) racc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s) issue_next();
+  int slot = 0;
+  // this wave's rows of a block: 16 wave + j, i.e. row half wave / 2, row (wave % 2) * 16 + j of the half
+  const unsigned row_off = (unsigned)(((wave & 1) * 16 + j) * 32);
+  for (long n = 0; n < nb; ++n) {
+    const long rb = rs + n * R;
+    const long row = rb * 64 + wave * 16 + j;
+    f32x4 acc[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[2][UT];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c < nchunk) {
+        // stage (n, c) has landed when at most the copies of the DEPTH - 2 later stages are outstanding (anything else issued since
+        // only makes the wait stricter); the barrier extends that to the other waves' copies and frees the slot of the stage before
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 2) * 2) : "memory");
+        __syncthreads();
+        issue_next();
+        const unsigned base = lds_st + (unsigned)slot * STAGE_B;
+        if (c == 0) {   // x^T fragments of the row block (rows past M cut off: their copies read row M - 1)
+          const unsigned xb = lds_x + (unsigned)(n & 1) * XT_B;
+          TrFrag xf[2][UT];
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int t = 0; t < UT; ++t) xf[k2][t] = tr_frag(xb + (unsigned)(k2 * UT + t) * 1024u);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const long rows_left = M - (rb * 64 + 32 * k2);
+#pragma unroll
+            for (int t = 0; t < UT; ++t) {
+              xa[k2][t] = __builtin_shufflevector(xf[k2][t].lo, xf[k2][t].hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              if (rows_left < 32) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  if (8 * q + e >= rows_left) xa[k2][t][e] = (bf16_t)0.f;
+              }
+            }
+          }
+        }
+        TrFrag hf[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) hf[k2] = tr_frag(base + (unsigned)(4 * k2 + wave) * 1024u);
+        bf16x8 hb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned a = base + (unsigned)(4 * (wave >> 1) + 2 * ks + (q >> 1)) * 1024u + row_off + (unsigned)(q & 1) * 16u;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(hb[ks]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < UT; ++t) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(s_w + (16 * t + j) * KP + 64 * c + 32 * ks + 8 * q);
+            acc[t] = MM::mma(wf, hb[ks], acc[t]);
+          }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const bf16x8 hv = __builtin_shufflevector(hf[k2].lo, hf[k2].hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int t = 0; t < UT; ++t) racc[c][t] = MM::mma(xa[k2][t], hv, racc[c][t]);
+        }
+        slot = slot + 1 == DEPTH ? 0 : slot + 1;
+      }
+    }
+    // + x M (the c2 term of the BatchNorm backward), bias, residual; rows past M and channels past N are not stored
+    const unsigned xrow = lds_x + (unsigned)(n & 1) * XT_B + (unsigned)((wave >> 1) * UT) * 1024u + row_off;
+    if (mpk) {
+#pragma unroll
+      for (int ks = 0; ks < MKS; ++ks) {
+        bf16x8 xv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = (bf16_t)0.f;
+        const int ct = 2 * ks + (q >> 1);   // the lane's 8 x channels 32 ks + 8 q ..: tile ct, half q & 1
+        if (ct < UT) {
+          const unsigned a = xrow + (unsigned)ct * 1024u + (unsigned)(q & 1) * 16u;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(xv) : "v"(a) : "memory");
+        }
+#pragma unroll
+        for (int t = 0; t < UT; ++t) acc[t] = MM::mma(mf[ks][t], xv, acc[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const int c0 = 16 * t + 4 * q;
+      bf16x4 av;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = (bf16_t)0.f;
+      if (add) {
+        const unsigned a = lds_a + (unsigned)(n & 1) * XT_B + (unsigned)((wave >> 1) * UT + t) * 1024u + row_off + (unsigned)(8 * q);
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(av) : "v"(a) : "memory");
+      }
+      if (row < M && c0 < N) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[t][r] + vbv[t][r] + (float)av[r]);
+        *reinterpret_cast<bf16x4*>(gx + row * ldgx + c0) = o;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus copies of the last stages must not outlive the workgroup's LDS
+
+  // this workgroup's partial of R = c1 * x^T h: element (x channel uc, hidden channel vc) at ws[(rs * N + uc) * K + vc]
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int vc = c * 64 + 16 * wave + j;
+    if (c < nchunk && vc < K) {
+      const float cv = c1[vc];
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int uc = 16 * t + 4 * q + r;
+          if (uc < N) ws[((long)rs * N + uc) * K + vc] = racc[c][t][r] * cv;
+        }
+    }
+  }
+}
+
+template <int UT, int NCH>
+static int launch_expand_bwd_s(const bf16_t* h, long hss, const float* c1, const bf16_t* W, int ldw, const bf16_t* x, int ldx,
+                               const bf16_t* add, int ldadd, bf16_t* gx, int ldgx, const bf16_t* mpk, int ldm, const float* vb, float* dwe,
+                               float* ws, long ws_floats, long M, int N, int K, hipStream_t st) {
+  const size_t fixed = (size_t)16 * UT * (NCH * 64 + 8) * sizeof(bf16_t) + (size_t)4 * 2 * UT * 1024;   // weights + x and residual tiles
+  const int depth = 2 * (fixed + 4 * 8192) + 4096 <= max_lds_bytes() ? 4 : 3;   // deepest ring that leaves room for two workgroups per CU
+  const size_t lds = fixed + (size_t)depth * 8192;
+  if (lds > max_lds_bytes()) return -1;
+  auto kern = depth == 4 ? k_expand_bwd_s<UT, NCH, 4> : k_expand_bwd_s<UT, NCH, 3>;
+  const long rblocks = (M + 63) / 64;
+  long R = (long)num_cus() * resident_per_cu(kern, 256, lds);   // one round of resident workgroups
+  if (R > rblocks) R = rblocks;
+  const long max_parts = ws_floats / ((long)N * K);   // every workgroup owns one partial of the weight gradient
+  if (R > max_parts) R = max_parts;
+  ATOMNAS_REQUIRE(R >= 1, "expand_bwd: workspace too small for one partial (%ld floats)", (long)N * K);
+  hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(256), lds, st, h, hss, c1, W, ldw, x, ldx, add, ldadd, gx, ldgx, mpk, ldm, vb, ws, M, N, K);
+  if (int rc = check_launch("expand_bwd(stream)")) return rc;
+  return reduce_parts(ws, (long)N * K, (int)R, (long)N * K, dwe, K, 1, N, st);
+}
+
 // fused expand backward: supported shapes and launch
 static inline int xb_nch(int HT) {
   const int n = (HT + WS_KC - 1) / WS_KC;
@@ -2972,6 +3244,18 @@ extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void*
   const bf16_t* W = (const bf16_t*)wt;
   const bf16_t* X = (const bf16_t*)x;
   const int wrows = (inp + 63) / 64 * 64;
+  // e == NULL on slab-major h: the streaming kernel (ATOMNAS_XB_STREAM=0: experiment switch back to k_expand_bwd)
+  static const int xs_on = getenv("ATOMNAS_XB_STREAM") ? atoi(getenv("ATOMNAS_XB_STREAM")) : 1;
+  if (xs_on && !e && h_ss > 0 && M >= 64 && ldx >= 8 && (!add || ldadd >= 8)) {
+#define XS_CASE(UTV, NCHV)                                                                                                             \
+  if (ut == UTV && nch == NCHV) {                                                                                                      \
+    const int rc = launch_expand_bwd_s<UTV, NCHV>((const bf16_t*)h, h_ss, c1, W, ldw, X, ldx, (const bf16_t*)add, ldadd, (bf16_t*)gx, ldgx, \
+                                                  (const bf16_t*)mp, ldm, mp ? vb : nullptr, dwe, ws, ws_floats, M, inp, hid, st);     \
+    if (rc >= 0) return rc;                                                                                                            \
+  }
+    XS_CASE(1, 5) XS_CASE(1, 7) XS_CASE(1, 12) XS_CASE(2, 5) XS_CASE(2, 7) XS_CASE(3, 5)
+#undef XS_CASE
+  }
 #define XB_CASE(UTV, NCHV) \
   if (ut == UTV && nch == NCHV) return launch_expand_bwd_cfg<UTV, NCHV>(A, W, ldw, wrows, X, ldx, ep, dwe, ws, ws_floats, M, inp, hid, (const bf16_t*)mp, ldm, st);
   XB_CASE(1, 5) XB_CASE(1, 7) XB_CASE(1, 12) XB_CASE(2, 5) XB_CASE(2, 7) XB_CASE(3, 5)

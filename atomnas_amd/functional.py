@@ -204,7 +204,7 @@ _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # ex
 # bf16 only).  Same-box A/B of the bs-256 step (profiles/r04_expand_bwd_noe_ab.txt): 31.40 ms with the two-stream form everywhere,
 # 31.15 with inp <= 24 (the 112 x 112 and 56 x 56 stages, fused kernel: x M + v added inside it), 31.41 with inp <= 48 (the 28 x 28
 # stage has no fused instance: its extra narrow GEMM and Gram pass cost what the second hidden stream did).
-_EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "24"))
+_EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "48"))
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
 _DP_TENSOR = bool(int(os.environ.get("ATOMNAS_DP_TENSOR", "1")))   # experiment switch: 0 = the BatchNorm-backward prologue in every GEMM tile
 TAIL_TAP = None   # set to a list by tests to receive the dropout keep mask of every tail forward
@@ -436,6 +436,17 @@ def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
     if inp <= _FUSED_EXPAND_BWD and ops.expand_bwd_supported(inp, HT, T):
         # one pass over h: both gradients, x M + v added inside the kernel
         ops.expand_bwd(h, None, e1, None, None, x2d, pl.WeT_pack, res, Gx, pl.We_grad, M, inp, HT, mp=mp, vb=vb)
+        _join_side()
+        return Gx
+    if (inp <= _FUSED_EXPAND_BWD and not pl.fused and pl.nb > 1 and isinstance(h, ops.Slab)
+            and all(ops.expand_bwd_supported(inp, pl.segpad(hh), T) for hh in pl.hid)):
+        # 40 -> 720: the accumulators of the whole hidden width do not fit, those of one branch segment (240 channels) do: one launch
+        # of the streaming kernel per segment; the input gradient accumulates through `add` (a launch reads and writes its own rows of
+        # Gx only), x M + v rides in the first launch
+        for i in range(pl.nb):
+            o, c = pl.seg[i], pl.segpad(pl.hid[i])
+            ops.expand_bwd(_seg(h, o), None, e1[o:], None, None, x2d, pl.WeT_pack[:, o:], res if i == 0 else Gx, Gx, pl.We_grad[o * inp:], M, inp,
+                           c, mp=mp if i == 0 else None, vb=vb if i == 0 else None)
         _join_side()
         return Gx
     gx1 = torch.empty(M, inp, dtype=T, device=dev)

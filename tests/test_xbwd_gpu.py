@@ -61,10 +61,16 @@ def test_gram_and_coeffs(gpu_lib, M, inp, C):
     assert_close("dwe", dwe, dref, rtol=1e-4, atol=1e-3 * float(dref.abs().max()))
 
 
-def test_expand_bwd_without_e(gpu_lib):
-    """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add (+ x M + v), dwe += (c1*h)^T x"""
+@pytest.mark.parametrize("M,inp,hid", [(3000, 24, 432),      # ragged last row block
+                                       (70001, 24, 432),     # several row blocks per workgroup, one row in the last block
+                                       (66000, 16, 288),     # the 112 x 112 stage's shape (one x-channel tile, 5 chunks)
+                                       (40000, 16, 720),     # 12 chunks
+                                       (36000, 32, 304),     # hidden width not a multiple of 64: the last chunk ends inside the tensor
+                                       (35000, 40, 240)])    # three x-channel tiles
+def test_expand_bwd_without_e(gpu_lib, M, inp, hid):
+    """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add (+ x M + v), dwe += (c1*h)^T x (slab-major h: the streaming kernel
+    k_expand_bwd_s; the same cases through k_expand_bwd with ATOMNAS_XB_STREAM=0)"""
     ops = _ops()
-    M, inp, hid = 3000, 24, 432
     if not ops.expand_bwd_supported(inp, hid, BF):
         pytest.skip("no instance")
     g = torch.Generator().manual_seed(5)
@@ -84,13 +90,13 @@ def test_expand_bwd_without_e(gpu_lib):
     xb = x.to(BF).cuda().contiguous()
     dE = (c1.double().view(1, -1) * h.to(BF).double()).to(BF).double()   # the kernel rounds dE to the MFMA input type
     dref = dE.t() @ x.to(BF).double()
-    for with_m in (False, True):
-        gx = torch.empty(M, inp, dtype=BF, device="cuda")
+    for with_m, with_add in ((False, True), (True, True), (True, False)):
+        gx = torch.full((M, inp), 7.0, dtype=BF, device="cuda")
         dwe = torch.zeros(hid, inp, dtype=torch.float32, device="cuda")
-        ops.expand_bwd(hb, None, cvec(c1), None, None, xb, wt, add.to(BF).cuda().contiguous(), gx, dwe, M, inp, hid,
+        ops.expand_bwd(hb, None, cvec(c1), None, None, xb, wt, add.to(BF).cuda().contiguous() if with_add else None, gx, dwe, M, inp, hid,
                        mp=mp if with_m else None, vb=cvec(vb) if with_m else None)
         torch.cuda.synchronize()
-        gref = dE @ we.to(BF).double() + add.to(BF).double()
+        gref = dE @ we.to(BF).double() + (add.to(BF).double() if with_add else 0.0)
         if with_m:
             gref = gref + x.to(BF).double() @ mm.to(BF).double() + vb.double().view(1, -1)
         assert_close("gx", gx, gref, rtol=1.2e-2, atol=2e-2 * float(gref.abs().max()))
