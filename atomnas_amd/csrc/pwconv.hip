@@ -2367,8 +2367,213 @@ static int launch_nt_ws(int mode, const Operand& A, const void* Wp, int ldw, con
   return check_launch("gemm_nt_ws");
 }
 
+// ------------------------------------------------------------------------------------------------ streaming wide-input GEMM
+// C[M][N] = act(A * scale + shift) W^T for a NARROW output (N <= 48) of a wide slab-major input (K <= 448): the projection of the
+// early stages (models/mobilenet_base.py:338,378), with the statistics of the output's BatchNorm.  The structure of k_expand_bwd_s:
+// the weights are resident in LDS, A is copied HBM -> LDS by global_load_lds_dwordx4 in 64-row x 64-channel stages (8 contiguous 1 KB
+// subtiles of the slab-major tensor) DEPTH - 1 stages ahead and waited for with a counted vmcnt; the B fragments are 16-byte LDS reads,
+// the prologue runs on the fragment registers.  16 UT output channels per lane group instead of the 64 k_gemm_nt_ws always computes.
+template <int UT, int NCH, int DEPTH>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_sw(const bf16_t* __restrict__ a, long ass, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int act, const bf16_t* __restrict__ W, int ldw,
+                                                       bf16_t* __restrict__ cout, int ldc, float* __restrict__ stats, int stat_rows, long M,
+                                                       int N, int K) {
+  using T = bf16_t;
+  using MM = Mma<T>;
+  constexpr int KP = NCH * 64 + 8;
+  constexpr int STAGE_B = 8 * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_sw[];
+  T* s_w = reinterpret_cast<T*>(smem_sw);                                                   // [16 UT][KP]
+  float* s_co = reinterpret_cast<float*>(smem_sw + (size_t)16 * UT * KP * sizeof(T));      // [2][NCH * 64] scale, shift (zeros past K)
+  float* s_stat = s_co + 2 * NCH * 64;                                                      // [4 waves][2][16 UT]
+  unsigned char* s_st = reinterpret_cast<unsigned char*>(s_stat + 4 * 2 * 16 * UT);        // [DEPTH] stages
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int nchunk = (K + 63) / 64, nslabs = (K + 15) / 16;
+  const long rblocks = (M + 63) / 64;
+  const int rs = blockIdx.x, R = gridDim.x;
+  const long nb = (rblocks - rs + R - 1) / R;
+
+  for (int idx = tid; idx < 16 * UT * NCH * 8; idx += 256) {
+    const int n = idx / (NCH * 8), k = (idx % (NCH * 8)) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)0.f;
+    if (n < N && k < K) {
+      o = *reinterpret_cast<const bf16x8*>(W + (long)n * ldw + k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (k + e >= K) o[e] = (bf16_t)0.f;
+    }
+    *reinterpret_cast<bf16x8*>(s_w + n * KP + k) = o;
+  }
+  for (int i = tid; i < 2 * NCH * 64; i += 256) {
+    const int v = i / (NCH * 64), k = i % (NCH * 64);
+    s_co[i] = k < K ? (v ? shift[k] : scale[k]) : 0.f;
+  }
+  __syncthreads();
+
+  const unsigned lds_st = (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char*)s_st);
+  auto dma = [&](const T* g, unsigned dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+  };
+  long ib = 0;
+  int ic = 0, islot = 0;
+  auto issue_next = [&]() {
+    const bool live = ib < nb;
+    const long rb = rs + (live ? ib : nb - 1) * R;
+    const int c = live ? ic : nchunk - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // subtiles (row half i, channel tile wave) of the stage
+      int slab = 4 * c + wave;
+      slab = slab < nslabs ? slab : nslabs - 1;
+      long row = rb * 64 + 32 * i + (lane >> 1);
+      row = row < M ? row : M - 1;
+      dma(a + slab * ass + row * 16 + 8 * (lane & 1), lds_st + (unsigned)islot * STAGE_B + (unsigned)(4 * i + wave) * 1024u);
+    }
+    islot = islot + 1 == DEPTH ? 0 : islot + 1;
+    if (++ic == nchunk) { ic = 0; ++ib; }
+  };
+
+  const Act am = act_of(act);
+  float ssum[UT][4], ssq[UT][4];
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ssum[t][r] = ssq[t][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s) issue_next();
+  int slot = 0;
+  const unsigned row_off = (unsigned)(((wave & 1) * 16 + j) * 32);
+  for (long n = 0; n < nb; ++n) {
+    const long rb = rs + n * R;
+    const long row = rb * 64 + wave * 16 + j;
+    f32x4 acc[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c < nchunk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 2) * 2) : "memory");
+        __syncthreads();
+        issue_next();
+        const unsigned base = lds_st + (unsigned)slot * STAGE_B;
+        bf16x8 hb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned ad = base + (unsigned)(4 * (wave >> 1) + 2 * ks + (q >> 1)) * 1024u + row_off + (unsigned)(q & 1) * 16u;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(hb[ks]) : "v"(ad) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int kl = 64 * c + 32 * ks + 8 * q;
+          float sc[8], sh[8], v[8];
+          VecIO<float, 8>::load(s_co + kl, sc);
+          VecIO<float, 8>::load(s_co + NCH * 64 + kl, sh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (float)hb[ks][e] * sc[e] + sh[e];
+          act_apply_v<8>(v, am);
+          const bf16x8 af = MM::pack(v);
+#pragma unroll
+          for (int t = 0; t < UT; ++t) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(s_w + (16 * t + j) * KP + kl);
+            acc[t] = MM::mma(wf, af, acc[t]);
+          }
+        }
+        slot = slot + 1 == DEPTH ? 0 : slot + 1;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const int c0 = 16 * t + 4 * q;
+      if (row < M && c0 < N) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (bf16_t)acc[t][r];
+          const float f = (float)o[r];   // statistics see the stored value
+          ssum[t][r] += f;
+          ssq[t][r] += f * f;
+        }
+        *reinterpret_cast<bf16x4*>(cout + row * ldc + c0) = o;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stats) {
+    // rows of the wave (16 lanes j) by butterfly, the four waves in wave order; row rs of the partial-row buffer
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = ssum[t][r], s2 = ssq[t][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (j == 0) {
+          s_stat[(wave * 2 + 0) * 16 * UT + 16 * t + 4 * q + r] = s1;
+          s_stat[(wave * 2 + 1) * 16 * UT + 16 * t + 4 * q + r] = s2;
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < 2 * 16 * UT; i += 256) {
+      const int pl = i / (16 * UT), c = i % (16 * UT);
+      if (c < N) {
+        float v = s_stat[(0 * 2 + pl) * 16 * UT + c];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += s_stat[(w * 2 + pl) * 16 * UT + c];
+        const long elem = (long)pl * N + c;
+        stats[(long)rs * 2 * N + elem] = v;
+        stat_zero_tail(stats, 2L * N, rs + R, R, stat_rows, elem);
+      }
+    }
+  }
+}
+
+// -1: not this kernel's case (the caller goes on), otherwise the launch status
+static int launch_nt_sw(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
+  static const int on = getenv("ATOMNAS_NT_SW") ? atoi(getenv("ATOMNAS_NT_SW")) : 1;   // experiment switch
+  const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
+  if (!on || mode != PRO_BNRELU || A.ss1 <= 0 || N > 48 || N % 8 != 0 || K > 448 || K < 97 || M < 16384 || ep.out_f32 || ep.css != 0 ||
+      ep.add || ep.z || ep.mask || ep.bias || (do_stats && ep.stat_mode != STAT_SQ))
+    return -1;
+  const int ut = (N + 15) / 16, nch = (K + 63) / 64 <= 5 ? 5 : 7;
+  const size_t fixed = (size_t)16 * ut * (nch * 64 + 8) * sizeof(bf16_t) + (size_t)2 * nch * 64 * sizeof(float) + (size_t)4 * 2 * 16 * ut * sizeof(float);
+  const int depth = 2 * (fixed + 4 * 8192) + 4096 <= max_lds_bytes() ? 4 : 3;
+  const size_t lds = fixed + (size_t)depth * 8192;
+  if (2 * lds + 2048 > max_lds_bytes()) return -1;
+  const long rblocks = (M + 63) / 64;
+#define SW_CASE(UTV, NCHV)                                                                                                              \
+  if (ut == UTV && nch == NCHV) {                                                                                                       \
+    auto kern = depth == 4 ? k_gemm_nt_sw<UTV, NCHV, 4> : k_gemm_nt_sw<UTV, NCHV, 3>;                                                   \
+    long R = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                                         \
+    if (R > rblocks) R = rblocks;                                                                                                       \
+    if (do_stats && R > ep.stat_rows) R = ep.stat_rows;                                                                                 \
+    hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(256), lds, st, (const bf16_t*)A.p1, A.ss1, A.c1, A.c2, A.relu, (const bf16_t*)Wp, ldw, \
+                       (bf16_t*)ep.c, ep.ldc, do_stats ? ep.stats : nullptr, ep.stat_rows, M, N, K);                                    \
+    return check_launch("gemm_nt_sw");                                                                                                  \
+  }
+  SW_CASE(1, 5) SW_CASE(1, 7) SW_CASE(2, 5) SW_CASE(2, 7) SW_CASE(3, 5) SW_CASE(3, 7)
+#undef SW_CASE
+  return -1;
+}
+
 template <typename T>
 static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    const int rc = launch_nt_sw(mode, A, Wp, ldw, ep, M, N, K, st);   // narrow output of a wide slab-major input: the streaming kernel
+    if (rc >= 0) return rc;
+  }
   if constexpr (sizeof(T) == 2) {
     // column-stationary form when the output is the wide operand
     static const int cs_maxk = getenv("ATOMNAS_NT_CS_MAXK") ? atoi(getenv("ATOMNAS_NT_CS_MAXK")) : 192;

@@ -465,6 +465,49 @@ def test_gemm_slab_layout_is_bit_identical_to_plain(gpu_lib, M, N, K):
 
 
 @pytest.mark.parametrize("act", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(20000, 24, 432), (70001, 24, 432), (66000, 16, 288), (40000, 40, 432), (36000, 32, 304),
+                                   (17000, 48, 120)])
+def test_gemm_nt_streaming_wide_input(gpu_lib, M, N, K, act):
+    """k_gemm_nt_sw (bf16, BNRELU prologue, slab-major A with K <= 448, N <= 48, M >= 16384): the projection of the early stages with
+    and without the output statistics; several row blocks per workgroup, ragged M, K not a multiple of 64, all three activations;
+    against fp64 and against the LDS-weights kernel on the plain layout."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K + act)
+    r = lambda *s: torch.randn(*s, generator=g)
+    A, W = r(M, K), r(N, K) / K ** 0.5
+    c1, c2 = torch.rand(K, generator=g) + 0.5, r(K) * 0.3
+    rd = lambda t: t.to(dtype).double()
+    pre = rd(A) * c1.double() + c2.double()
+    if act == 3:
+        Aeff = pre * torch.sigmoid(pre)
+    else:
+        Aeff = pre.clamp(min=0.0, max=6.0 if act == 2 else float("inf"))
+    Cref = Aeff.to(dtype).double() @ rd(W).t()
+    scale = float(Cref.abs().max())
+    Ap = torch.cat([A.to(dtype), torch.zeros(M, pad8(K) - K, dtype=dtype)], 1).cuda()
+    Wp = pack_w(W, dtype)
+    outs = []
+    for slab, with_stats in ((True, True), (True, False), (False, True)):
+        C = fresh(M, N, dtype)
+        st = poisoned_stats(512, N) if with_stats else None
+        ops.gemm_nt(_slab(Ap, K) if slab else Ap, Wp, C, M, N, K, a_mode=ops.PRO_BNRELU, ac1=cvec(c1), ac2=cvec(c2), a_relu=act, stats=st,
+                    stat_mode=ops.STAT_SQ if with_stats else 0)
+        torch.cuda.synchronize()
+        Cg = C[:, :N].double().cpu()
+        assert_close("C", Cg, Cref, tol(dtype)["rtol"], tol(dtype)["atol"] * max(1.0, scale))
+        if with_stats:
+            assert not torch.isnan(st).any()
+            sm = st.sum(0)
+            assert_close("s1", sm[0], Cg.sum(0), rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale))
+            assert_close("s2", sm[1], (Cg * Cg).sum(0), rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale) ** 2)
+        outs.append(C[:, :N].float())
+    assert torch.equal(outs[0], outs[1])   # the statistics do not change the output
+    # other kernel, other summation order: agreement to the rounding of the bf16 result
+    assert torch.allclose(outs[0], outs[2], rtol=2e-2, atol=2e-2 * max(1.0, scale))
+
+
+@pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(2000, 432, 24), (1500, 288, 16), (4111, 720, 40), (3000, 203, 80), (2500, 1440, 96), (1029, 400, 192),
                                    (30000, 432, 24)])
 def test_gemm_nt_streaming_kernel(gpu_lib, M, N, K, act):
