@@ -2,7 +2,7 @@
 # Builds the round-4 E-elimination experiment: the product library's objects + dwconv_cw.hip recompiled with the recomputing backward
 # kernel (-DATOMNAS_EXPERIMENTAL_XDW) + csrc/experimental/xdw_fused.hip  ->  atomnas_amd/csrc/build/variants/libxdw.so (git-ignored).
 #   usage: tools/build_xdw_experiment.sh [NAME [extra hipcc flags for xdw_fused.hip]]      e.g.  tools/build_xdw_experiment.sh xdt -DXD_TIMING=1
-# Load it with ATOMNAS_HIP_LIB=atomnas_amd/csrc/build/variants/libxdw.so (tests/test_xdw_experimental_gpu.py, tools/xdwbench.py).
+# Load it with ATOMNAS_HIP_LIB=atomnas_amd/csrc/build/variants/libxdw.so (tools/experiments/test_xdw_experimental_gpu.py, tools/xdwbench.py).
 set -e
 cd "$(dirname "$0")/.."
 python -m atomnas_amd.build > /dev/null

@@ -2,9 +2,16 @@
 BatchNorm + activation computed on chip in front of the depthwise convolution, forward and backward; not part of the product
 library) against a float64 torch restatement of models/mobilenet_base.py:316-336 on inputs rounded to bf16.  Runs only when the
 experiment library is loaded:
-    tools/build_xdw_experiment.sh && ATOMNAS_HIP_LIB=atomnas_amd/csrc/build/variants/libxdw.so python -m pytest tests/test_xdw_experimental_gpu.py -m gpu
+    tools/build_xdw_experiment.sh && ATOMNAS_HIP_LIB=atomnas_amd/csrc/build/variants/libxdw.so \
+        python -m pytest tools/experiments/test_xdw_experimental_gpu.py -m gpu -p no:cacheprovider
+(kept out of tests/: the product suite has no test that can only skip)
 """
 import itertools
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(_ROOT, "tests"))   # kutil, conftest fixtures
 
 import pytest
 import torch
@@ -26,7 +33,7 @@ class _Ops:
     def __getattr__(self, name):
         import os
         import sys
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments"))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import xdw_ops
         from atomnas_amd import ops
         if not xdw_ops.available():
