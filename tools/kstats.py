@@ -14,8 +14,8 @@ d = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else None
 rows = list(csv.DictReader(open(glob.glob(d + "/*kernel_trace.csv")[0])))
 names = collections.Counter(r["Kernel_Name"] for r in rows)
-# steps the process ran = launches of a once-per-step kernel
-steps = min((c for n, c in names.items() if "k_rmsprop_ema" in n), default=1)
+# forward-backward passes the process ran (timed + warm-up + the eager passes before the capture) = launches of the loss kernel
+steps = min((c for n, c in names.items() if "k_ce_smooth" in n), default=1)
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in rows:
     n = re.sub(r"\(.*", "", r["Kernel_Name"])
