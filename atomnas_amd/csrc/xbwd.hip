@@ -18,94 +18,114 @@
 namespace atomnas {
 
 // ------------------------------------------------------------------------------------------------- Gram matrix of the block input
-// G = X^T X (inp x inp) and sx = sum_m x_m of the narrow block input x [M][ldx] (bf16): per-workgroup partials [G | sx] over a range
-// of 128-pixel tiles.  A tile is staged in LDS as fp32 with one more column of ones (so that sx is column inp of the product); a
-// thread owns a 4 x 4 block of the product and one of `nsplit` pixel subsets of the tile (two 16-byte LDS reads per 16 FMAs); the
-// subsets are added in order at the end, the workgroup partials in workgroup order by k_gram_reduce -- fixed order, no atomics.
-// inp <= 64, a multiple of 8.
+// G = X^T X (inp x inp) and sx = sum_m x_m of the narrow block input x [M][ldx] (bf16, inp <= 64, a multiple of 8), as per-WAVE
+// partials [G | sx] (added per workgroup in wave order where they fit the LDS) summed in order by k_gram_reduce -- fixed order, no atomics.
+// A wave owns 32-row units of x, strided over all waves of the launch.  A unit (UT = inp / 16 rounded up row-major [32][16] subtiles
+// of 1 KB) is copied HBM -> LDS by global_load_lds_dwordx4 into the wave's PRIVATE ring, DEPTH - 1 units ahead, and waited for
+// with a counted vmcnt: no barrier anywhere.  Both MFMA operands of G's (ti, tj) tile are transposing reads (ds_read_b64_tr_b16) of
+// subtiles ti and tj; sx is one more MFMA per subtile against a fragment of ones.  Rows past M are cut off in the A fragments.
+// (The first version staged fp32 tiles and multiplied 4 x 4 register blocks on the VALU: 1.1 .. 1.5 TB/s on a tensor of 16 .. 100 MB.)
+template <int UT, int DEPTH>
 __global__ __launch_bounds__(256) void k_gram_part(const bf16_t* __restrict__ x, int ldx, long M, int inp, float* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) float s_t[];   // [128][inp + 4], then the reduction buffer [nsplit][nitems][16]
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_gr[];   // [4 waves][DEPTH][UT] subtiles of 1 KB
   const int tid = threadIdx.x;
-  const int pitch = inp + 4, nr = inp >> 2, nc = nr + 1, nitems = nr * nc;
-  const int nsplit = 256 / nitems > 0 ? (256 / nitems > 16 ? 16 : 256 / nitems) : 1;   // inp <= 56: 256 / nitems >= 1; inp = 64: 272 items, two passes
-  const int npass = (nitems * nsplit + 255) / 256;
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const long ntiles = (M + 127) / 128;
-  const long t_beg = blockIdx.x * ntiles / gridDim.x, t_end = (blockIdx.x + 1) * ntiles / gridDim.x;
-  const int npc = 128 * (inp >> 3);   // 16-byte pieces per tile
-  // the pieces of a tile (at most 4 per thread: inp <= 64) are fetched one tile ahead
-  bf16x8 pf[4];
-  auto fetch = [&](long t) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pc = tid + 256 * u;
-      const int r = pc / (inp >> 3), cg = pc - r * (inp >> 3);
-      const long row = t * 128 + r;
-      const bool ok = pc < npc && row < M;
-      pf[u] = *reinterpret_cast<const bf16x8*>(x + (ok ? row * ldx + cg * 8 : 0));
-    }
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const long nunits = (M + 31) / 32;
+  const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  const long mine = wid < nunits ? (nunits - wid + nw - 1) / nw : 0;   // units wid, wid + nw, ...
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char*)s_gr) + (unsigned)wave * (DEPTH * UT * 1024u);
+  auto dma = [&](const bf16_t* g, unsigned dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(d) : "memory");
   };
-  if (t_beg < t_end) fetch(t_beg);
-  for (long t = t_beg; t < t_end; ++t) {
-    __syncthreads();
+  long iu = 0;
+  int islot = 0;
+  auto issue_next = [&]() {   // unit iu of this wave (past the end: the last one again, keeps the copy count per unit constant)
+    const long u = wid + (iu < mine ? iu : (mine > 0 ? mine - 1 : 0)) * nw;
+    long row = (u < nunits ? u : nunits - 1) * 32 + (lane >> 1);
+    row = row < M ? row : M - 1;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pc = tid + 256 * u;
-      if (pc < npc) {
-        const int r = pc / (inp >> 3), cg = pc - r * (inp >> 3);
-        const bool ok = t * 128 + r < M;
-        float v[8];
+    for (int ct = 0; ct < UT; ++ct) {
+      const int ch = 16 * ct + 8 * (lane & 1);
+      dma(x + row * ldx + (ch < ldx - 8 ? ch : ldx - 8), lds0 + (unsigned)(islot * UT + ct) * 1024u);
+    }
+    islot = islot + 1 == DEPTH ? 0 : islot + 1;
+    ++iu;
+  };
+  const unsigned tr_lane = (unsigned)(((8 * q + (j >> 2)) * 16 + 4 * (j & 3)) * 2);
+  f32x4 gacc[UT][UT], sacc[UT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ok ? (float)pf[u][e] : 0.f;
-        VecIO<float, 8>::store(s_t + r * pitch + cg * 8, v);
-        if (cg == 0) *reinterpret_cast<f32x4*>(s_t + r * pitch + inp) = f32x4{ok ? 1.f : 0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < UT; ++a) {
+    sacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < UT; ++b) gacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.f;
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s) issue_next();
+  int slot = 0;
+  for (long n = 0; n < mine; ++n) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 2) * UT) : "memory");
+    const long rows_left = M - (wid + n * nw) * 32;
+    bf16x4 lo[UT], hi[UT];
+#pragma unroll
+    for (int ct = 0; ct < UT; ++ct) {
+      const unsigned a0 = lds0 + (unsigned)(slot * UT + ct) * 1024u + tr_lane;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[ct]) : "v"(a0) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(hi[ct]) : "v"(a0) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    issue_next();   // into the slot of the unit before this one (this wave alone reads and writes its ring)
+    bf16x8 f[UT], fm[UT];
+#pragma unroll
+    for (int ct = 0; ct < UT; ++ct) {
+      f[ct] = __builtin_shufflevector(lo[ct], hi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
+      fm[ct] = f[ct];
+      if (rows_left < 32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (8 * q + e >= rows_left) fm[ct][e] = (bf16_t)0.f;
       }
     }
-    __syncthreads();
-    fetch(t + 1 < t_end ? t + 1 : t);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int w = tid + 256 * u;
-      if (u < npass && w < nitems * nsplit) {
-        const int it = w % nitems, sp = w / nitems;
-        const int bi = it / nc, bj = it - bi * nc;
-        const float* pa = s_t + 4 * bi;
-        const float* pb = s_t + 4 * bj;
-        for (int pp = sp; pp < 128; pp += nsplit) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(pa + pp * pitch);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(pb + pp * pitch);
+    for (int a = 0; a < UT; ++a) {
+      sacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[a], ones, sacc[a], 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[u][r] += f32x4{a[r], a[r], a[r], a[r]} * b;
-        }
+      for (int b = 0; b < UT; ++b) gacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[a], f[b], gacc[a][b], 0, 0, 0);
+    }
+    slot = slot + 1 == DEPTH ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus copies must not outlive the workgroup's LDS
+  // partial [G | sx]: G[i][jj] at [i * inp + jj], sx[i] at [inp * inp + i]; lane (q, j) of tile (a, b) holds i = 16 a + 4 q + r, jj = 16 b + j.
+  // UT <= 3: the four waves' partials are added in wave order through the (now idle) ring and the WORKGROUP writes one partial;
+  // UT = 4 (inp > 48: 4 x 16.6 KB do not fit the ring): one partial per wave.
+  constexpr bool BLOCK_RED = UT <= 3;
+  const long ps = (long)inp * inp + inp;
+  float* o = BLOCK_RED ? reinterpret_cast<float*>(s_gr) + wave * ps : ws + wid * ps;
+  if (BLOCK_RED) __syncthreads();   // every wave is done with its ring
+#pragma unroll
+  for (int a = 0; a < UT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * a + 4 * q + r;
+      if (i < inp) {
+#pragma unroll
+        for (int b = 0; b < UT; ++b)
+          if (16 * b + j < inp) o[(long)i * inp + 16 * b + j] = gacc[a][b][r];
+        if (j == 0) o[(long)inp * inp + i] = sacc[a][r];
       }
     }
-  }
-  // the pixel subsets of an item are added in subset order
-  __syncthreads();
-  float* red = s_t;   // [nsplit][nitems][16] <= 256 * 2 * 16 floats <= the tile buffer (128 * (inp + 4), inp >= 8: host side checks)
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int w = tid + 256 * u;
-    if (u < npass && w < nitems * nsplit) {
-      const int it = w % nitems, sp = w / nitems;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(red + ((long)sp * nitems + it) * 16 + 4 * r) = acc[u][r];
-    }
-  }
-  __syncthreads();
-  float* o = ws + (long)blockIdx.x * (inp * inp + inp);
-  for (int e = tid; e < nitems * 16; e += 256) {
-    const int it = e >> 4, r = (e >> 2) & 3, c = e & 3;
-    float a = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) a += red[((long)sp * nitems + it) * 16 + 4 * r + c];
-    const int bi = it / nc, bj = it - bi * nc;
-    const int i = 4 * bi + r, jj = 4 * bj + c;
-    if (jj < inp) o[i * inp + jj] = a;
-    else if (jj == inp) o[inp * inp + i] = a;
+  if (BLOCK_RED) {
+    __syncthreads();
+    const float* sp = reinterpret_cast<const float*>(s_gr);
+    float* og = ws + (long)blockIdx.x * ps;
+    for (int e = tid; e < ps; e += 256) og[e] = ((sp[e] + sp[ps + e]) + sp[2 * ps + e]) + sp[3 * ps + e];
   }
 }
 // one wave per output element: lane l adds the partials l, l + 64, ... in order, then a fixed-order butterfly over the lanes
@@ -115,7 +135,13 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const float* __restrict__ w
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (e >= n) return;
   float a = 0.f;
-  for (int r = lane; r < parts; r += 64) a += ws[(long)r * n + e];
+  const int nit = (parts + 63) >> 6;
+#pragma unroll 8
+  for (int i = 0; i < nit; ++i) {   // unconditional loads (clamped), eight in flight
+    const int r = lane + 64 * i;
+    const float v = ws[(long)(r < parts ? r : parts - 1) * n + e];
+    a += r < parts ? v : 0.f;
+  }
   a = wave_sum(a);
   if (lane == 0) {
     if (e < inp * inp) gram[e] = a; else sx[e - inp * inp] = a;
@@ -133,18 +159,25 @@ __global__ __launch_bounds__(256) void k_xb_coeffs(const float* __restrict__ c2,
                                                    int inp, int C, bf16_t* __restrict__ mp, int ldm,
                                                    float* __restrict__ vb, float* __restrict__ dwe) {
   __shared__ float s_p[256 + 64];
+  extern __shared__ float s_g[];   // [inp][inp] Gram matrix + [inp] column sums (the dwe workgroups)
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < inp) {
     const int n = blockIdx.x;
     int KP = 8;
     while (KP < inp) KP *= 2;   // 8 .. 64
     const int S = 256 / KP;
-    const int k = tid % KP, sub = tid / KP;
+    const int k = tid % KP, sub = tid / KP, kl = k < inp ? k : inp - 1;
     float a = 0.f, va = 0.f;
-    for (int c = sub; c < C; c += S) {
-      const float wn = (float)wexp[(long)c * ldwe + n];
-      if (k < inp) a += c2[c] * wn * (float)wexp[(long)c * ldwe + k];
-      if (k == 0) va += c3[c] * wn;
+    // unconditional loads at clamped indices, four channels in flight (behind a branch every load was waited for on its own: 73 us
+    // for the 40 x 40 matrix of the 28 x 28 stage)
+    const int nit = (C + S - 1) / S;
+#pragma unroll 4
+    for (int i = 0; i < nit; ++i) {
+      const int c = sub + i * S, cl = c < C ? c : C - 1;
+      const float wn = (float)wexp[(long)cl * ldwe + n], wk = (float)wexp[(long)cl * ldwe + kl];
+      const float q2 = c < C ? c2[cl] : 0.f, q3 = c < C ? c3[cl] : 0.f;
+      a += q2 * wn * wk;
+      va += q3 * wn;
     }
     s_p[sub * KP + k] = a;
     if (k == 0) s_p[256 + sub] = va;
@@ -161,12 +194,27 @@ __global__ __launch_bounds__(256) void k_xb_coeffs(const float* __restrict__ c2,
     }
     return;
   }
+  for (int i = tid; i < inp * inp + inp; i += 256) s_g[i] = i < inp * inp ? gram[(i / inp) * ldg + i % inp] : sx[i - inp * inp];
+  __syncthreads();
   const long e = (long)(blockIdx.x - inp) * 256 + tid;
   if (e >= (long)C * inp) return;
   const int c = (int)(e / inp), k = (int)(e % inp);
+  // the channel's weight row in 16-byte pieces (ldwe >= inp rounded up to 32: whole pieces), all in flight, then the products from LDS
   float a = 0.f;
-  for (int jj = 0; jj < inp; ++jj) a += (float)wexp[(long)c * ldwe + jj] * gram[jj * ldg + k];
-  dwe[e] += c2[c] * a + c3[c] * sx[k];
+  const bf16_t* wr = wexp + (long)c * ldwe;
+  for (int j0 = 0; j0 < inp; j0 += 32) {
+    bf16x8 w8[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w8[u] = *reinterpret_cast<const bf16x8*>(wr + j0 + 8 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int jj = j0 + 8 * u + q;
+        if (jj < inp) a += (float)w8[u][q] * s_g[jj * inp + k];
+      }
+  }
+  dwe[e] += c2[c] * a + c3[c] * s_g[inp * inp + k];
 }
 
 }  // namespace atomnas
@@ -179,15 +227,20 @@ extern "C" int atomnas_gram(const void* x, int ldx, long M, int inp, float* ws, 
   ATOMNAS_REQUIRE(x && ws && gram && sx && M > 0 && inp >= 8 && inp <= 64 && inp % 8 == 0 && ldx >= inp && ldx % 8 == 0 && dtype == DT_BF16,
                   "gram: bad arguments (bf16, inp <= 64 and a multiple of 8)");
   const long ps = (long)inp * inp + inp;
-  long parts = 2L * num_cus();
-  const long ntiles = (M + 127) / 128;
-  if (parts > ntiles) parts = ntiles;
-  if (parts > ws_floats / ps) parts = ws_floats / ps;
-  ATOMNAS_REQUIRE(parts >= 1, "gram: workspace too small for one partial (%ld floats)", ps);
+  // one partial per WAVE; two workgroups of four waves per CU, at least four 32-row units per wave
+  const long nunits = (M + 31) / 32;
+  long blocks = 2L * num_cus();
+  if (blocks > (nunits + 15) / 16) blocks = (nunits + 15) / 16;
+  if (blocks > ws_floats / (4 * ps)) blocks = ws_floats / (4 * ps);
+  ATOMNAS_REQUIRE(blocks >= 1, "gram: workspace too small for four partials (%ld floats)", 4 * ps);
+  const long parts = (inp + 15) / 16 <= 3 ? blocks : 4 * blocks;   // k_gram_part: one partial per workgroup (UT <= 3) or per wave
   hipStream_t st = (hipStream_t)stream;
-  size_t lds = (size_t)128 * (inp + 4) * sizeof(float);
-  if (lds < (size_t)512 * 16 * sizeof(float)) lds = (size_t)512 * 16 * sizeof(float);   // the end-of-kernel reduction buffer
-  hipLaunchKernelGGL(k_gram_part, dim3((unsigned)parts), dim3(256), lds, st, (const bf16_t*)x, ldx, M, inp, ws);
+  const int ut = (inp + 15) / 16;
+  const bf16_t* xp = (const bf16_t*)x;
+#define GRAM_CASE(UTV) \
+  if (ut == UTV) hipLaunchKernelGGL((k_gram_part<UTV, 4>), dim3((unsigned)blocks), dim3(256), (size_t)4 * 4 * UTV * 1024, st, xp, ldx, M, inp, ws);
+  GRAM_CASE(1) GRAM_CASE(2) GRAM_CASE(3) GRAM_CASE(4)
+#undef GRAM_CASE
   hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((ps + 3) / 4)), dim3(256), 0, st, ws, (int)parts, inp, gram, sx);
   return check_launch("gram");
 }
@@ -197,8 +250,9 @@ extern "C" int atomnas_xb_coeffs(const float* c2, const float* c3, const void* w
                                  int inp, int C, void* mp, int ldm, float* vb, float* dwe, void* stream) {
   ATOMNAS_REQUIRE(c2 && c3 && wexp && gram && sx && mp && vb && dwe && inp > 0 && inp <= 64 && C > 0 && ldg >= inp && ldwe >= inp && ldm >= inp,
                   "xb_coeffs: bad arguments");
+  ATOMNAS_REQUIRE(ldwe >= (inp + 31) / 32 * 32 && ldwe % 8 == 0 && ((size_t)wexp & 15) == 0, "xb_coeffs: the packed weight rows are read in 16-byte pieces (ldwe=%d)", ldwe);
   const long blocks = inp + ((long)C * inp + 255) / 256;
-  hipLaunchKernelGGL(k_xb_coeffs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c2, c3, (const bf16_t*)wexp, ldwe, gram, ldg, sx,
+  hipLaunchKernelGGL(k_xb_coeffs, dim3((unsigned)blocks), dim3(256), (size_t)(inp * inp + inp) * sizeof(float), (hipStream_t)stream, c2, c3, (const bf16_t*)wexp, ldwe, gram, ldg, sx,
                      inp, C, (bf16_t*)mp, ldm, vb, dwe);
   return check_launch("xb_coeffs");
 }

@@ -428,7 +428,7 @@ def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
     inp = pl.inp
     gram = torch.empty(inp * inp, dtype=torch.float32, device=dev)
     sx = torch.empty(inp, dtype=torch.float32, device=dev)
-    ops.gram(x2d, M, inp, gram, sx, ws=_plan_buffer(pl, "gram_ws", lambda: torch.empty(512 * (inp * inp + inp), dtype=torch.float32, device=dev)))
+    ops.gram(x2d, M, inp, gram, sx, ws=_plan_buffer(pl, "gram_ws", lambda: torch.empty(2048 * (inp * inp + inp), dtype=torch.float32, device=dev)))
     # M packed as a gemm_nt weight (padding stays zero: the buffer is created zeroed once and only its inp x inp corner is rewritten)
     mp = _plan_buffer(pl, "xb_mp", lambda: ops.zeros((inp + 63) // 64 * 64, (inp + 31) // 32 * 32, dtype=T, device=dev))
     vb = torch.empty(pad8(inp), dtype=torch.float32, device=dev)

@@ -191,7 +191,7 @@ def gram(x, M, inp, gram_out, sx_out, ws=None):
     """G = X^T X [inp][inp] and column sums sx [inp] of the block input x [M, ld] (include/atomnas_hip.h)"""
     _chk_cuda(x, gram_out, sx_out)
     if ws is None:
-        ws = torch.empty(512 * (inp * inp + inp), dtype=torch.float32, device=x.device)
+        ws = torch.empty(2048 * (inp * inp + inp), dtype=torch.float32, device=x.device)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d inp%d" % (M, inp))
     call("atomnas_gram", _p(x), _ld(x), M, inp, _p(ws), ws.numel(), _p(gram_out), _p(sx_out), dt_code(x.dtype), _stream())
