@@ -3299,6 +3299,10 @@ template <int UT, int NCH>
 static int launch_expand_bwd_s(const bf16_t* h, long hss, const float* c1, const bf16_t* W, int ldw, const bf16_t* x, int ldx,
                                const bf16_t* add, int ldadd, bf16_t* gx, int ldgx, const bf16_t* mpk, int ldm, const float* vb, float* dwe,
                                float* ws, long ws_floats, long M, int N, int K, hipStream_t st) {
+  // The x / residual tiles are double-buffered per row block: the copy for block b + 2 is issued DEPTH - 1 stages ahead of that block's
+  // first stage, which lies inside block b + 1 only if a block has at least DEPTH - 1 = 3 stages.  Narrower hidden tensors (K <= 128:
+  // one or two 64-channel chunks) take k_expand_bwd.
+  if ((K + 63) / 64 < 3) return -1;
   const size_t fixed = (size_t)16 * UT * (NCH * 64 + 8) * sizeof(bf16_t) + (size_t)4 * 2 * UT * 1024;   // weights + x and residual tiles
   const int depth = 2 * (fixed + 4 * 8192) + 4096 <= max_lds_bytes() ? 4 : 3;   // deepest ring that leaves room for two workgroups per CU
   const size_t lds = fixed + (size_t)depth * 8192;

@@ -66,7 +66,9 @@ def test_gram_and_coeffs(gpu_lib, M, inp, C):
                                        (66000, 16, 288),     # the 112 x 112 stage's shape (one x-channel tile, 5 chunks)
                                        (40000, 16, 720),     # 12 chunks
                                        (36000, 32, 304),     # hidden width not a multiple of 64: the last chunk ends inside the tensor
-                                       (35000, 40, 240)])    # three x-channel tiles
+                                       (35000, 40, 240),     # three x-channel tiles
+                                       (100000, 16, 96),     # two chunks only, many row blocks per workgroup: k_expand_bwd (the streaming
+                                       (90000, 24, 64)])     # kernel's tile double-buffering needs three stages per row block)
 def test_expand_bwd_without_e(gpu_lib, M, inp, hid):
     """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add (+ x M + v), dwe += (c1*h)^T x (slab-major h: the streaming kernel
     k_expand_bwd_s; the same cases through k_expand_bwd with ATOMNAS_XB_STREAM=0)"""
