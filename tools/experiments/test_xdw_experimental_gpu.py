@@ -124,9 +124,9 @@ def test_xdw_fwd_long_tile_walk(gpu_lib, workers, monkeypatch):
     env = dict(os.environ)
     if workers:
         env["ATOMNAS_DW_MAX_WORKERS"] = str(workers)
-    code = ("import sys; sys.path.insert(0, 'tests'); import torch, test_xdw_experimental_gpu as t; "
+    code = ("import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, 'tools/experiments'); import torch, test_xdw_experimental_gpu as t; "
             "[t.test_xdw_fwd(None, 9, 28, 28, 40, 48, k, 1) for k in (3, 7)]; [t.test_xdw_bwd(None, 9, 28, 28, 40, 48, k, 1) for k in (3, 7)]; print('ok')")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=_ROOT)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
