@@ -15,24 +15,28 @@
 
 namespace atomnas {
 
-template <int UT, int DEPTH, int WGPC>
-__global__ __launch_bounds__(256, WGPC) void k_gemm_nt_swg(const bf16_t* __restrict__ a, long ass, const float* __restrict__ scale,
+// NWV = 4: 64-row stages (two workgroups per CU where the LDS allows); NWV = 8: 128-row stages, one weight chunk per 128 rows (half the
+// weight traffic from L2 per activation byte), one workgroup of eight waves per CU.
+template <int UT, int DEPTH, int WGPC, int NWV>
+__global__ __launch_bounds__(NWV * 64, WGPC) void k_gemm_nt_swg(const bf16_t* __restrict__ a, long ass, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int act, const bf16_t* __restrict__ W, int ldw,
                                                            bf16_t* __restrict__ cout, int ldc, float* __restrict__ stats, int stat_rows,
                                                            long M, int N, int K) {
+  constexpr int NT = NWV * 64, RB = NWV * 16;   // threads, rows of a stage
+  constexpr int AT = 2 * NWV;                   // activation subtiles [32 rows][16 channels] of a stage: (row group of 32, channel tile)
   constexpr int WT = 2 * UT;                    // weight tiles (8 rows x 64 channels) of a stage
-  constexpr int WPW = (WT + 3) / 4;             // ... per wave
+  constexpr int WPW = (WT + NWV - 1) / NWV;     // ... per wave
   constexpr int CPS = 2 + WPW + 1;              // copies per wave and stage
-  constexpr int STAGE_B = (8 + WT + 1) * 1024;  // bytes of a stage
+  constexpr int STAGE_B = (AT + WT + 1) * 1024;  // bytes of a stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_swg[];
-  float* s_stat = reinterpret_cast<float*>(smem_swg);                      // [4 waves][2][16 UT]
-  unsigned char* s_st = smem_swg + (size_t)4 * 2 * 16 * UT * sizeof(float);   // [DEPTH] stages
+  float* s_stat = reinterpret_cast<float*>(smem_swg);                      // [NWV waves][2][16 UT]
+  unsigned char* s_st = smem_swg + (size_t)NWV * 2 * 16 * UT * sizeof(float);   // [DEPTH] stages
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, j = lane & 15;
   const int nchunk = (K + 63) / 64, nslabs = (K + 15) / 16;
-  const long rblocks = (M + 63) / 64;
+  const long rblocks = (M + RB - 1) / RB;
   const int rs = blockIdx.x, R = gridDim.x;
   const long nb = (rblocks - rs + R - 1) / R;
 
@@ -51,27 +55,28 @@ __global__ __launch_bounds__(256, WGPC) void k_gemm_nt_swg(const bf16_t* __restr
     const int c = live ? ic : nchunk - 1;
     const unsigned sb = lds_st + (unsigned)islot * STAGE_B;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {   // activation subtiles (row half i, channel tile wave)
-      int slab = 4 * c + wave;
+    for (int i = 0; i < 2; ++i) {   // activation subtiles wave, wave + NWV: (row group sub / 4, channel tile sub % 4)
+      const int sub = wave + NWV * i;
+      int slab = 4 * c + (sub & 3);
       slab = slab < nslabs ? slab : nslabs - 1;
-      long row = rb * 64 + 32 * i + (lane >> 1);
+      long row = rb * RB + 32 * (sub >> 2) + (lane >> 1);
       row = row < M ? row : M - 1;
-      dma(a + slab * ass + row * 16 + 8 * (lane & 1), sb + (unsigned)(4 * i + wave) * 1024u);
+      dma(a + slab * ass + row * 16 + 8 * (lane & 1), sb + (unsigned)sub * 1024u);
     }
 #pragma unroll
-    for (int i = 0; i < WPW; ++i) {   // weight tiles wave, wave + 4, ...: lane -> (row 8 tile + lane / 8, LDS piece lane % 8 <- source piece xor row)
-      int wt = wave + 4 * i;
+    for (int i = 0; i < WPW; ++i) {   // weight tiles wave, wave + NWV, ...: lane -> (row 8 tile + lane / 8, LDS piece lane % 8 <- source piece xor row)
+      int wt = wave + NWV * i;
       wt = wt < WT ? wt : WT - 1;
       const int row = 8 * wt + (lane >> 3);
       int col = 64 * c + 8 * ((lane & 7) ^ (row & 7));
       col = col < ldw - 8 ? col : ldw - 8;   // past the packed pitch: any valid piece (meets activations zeroed by their coefficients)
-      dma(W + (long)row * ldw + col, sb + (unsigned)(8 + wt) * 1024u);
+      dma(W + (long)row * ldw + col, sb + (unsigned)(AT + wt) * 1024u);
     }
     {   // coefficients of the chunk: lanes 0..15 scale, 16..31 shift (32..63 repeat them), 4 floats each
       int k = 64 * c + 4 * (lane & 15);
       const int kmax = ((K + 3) & ~3) - 4;
       k = k < kmax ? k : kmax;
-      dma(((lane >> 4) & 1 ? shift : scale) + k, sb + (unsigned)(8 + WT) * 1024u);
+      dma(((lane >> 4) & 1 ? shift : scale) + k, sb + (unsigned)(AT + WT) * 1024u);
     }
     islot = islot + 1 == DEPTH ? 0 : islot + 1;
     if (++ic == nchunk) { ic = 0; ++ib; }
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, WGPC) void k_gemm_nt_swg(const bf16_t* __restr
   const unsigned row_off = (unsigned)(((wave & 1) * 16 + j) * 32);
   for (long n = 0; n < nb; ++n) {
     const long rb = rs + n * R;
-    const long row = rb * 64 + wave * 16 + j;
+    const long row = rb * RB + wave * 16 + j;
     f32x4 acc[UT];
 #pragma unroll
     for (int t = 0; t < UT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256, WGPC) void k_gemm_nt_swg(const bf16_t* __restr
       for (int ks = 0; ks < 2; ++ks) {
         const unsigned ad = base + (unsigned)(4 * (wave >> 1) + 2 * ks + (q >> 1)) * 1024u + row_off + (unsigned)(q & 1) * 16u;
         asm volatile("ds_read_b128 %0, %1" : "=v"(hb[ks]) : "v"(ad) : "memory");
-        const unsigned cb = base + (unsigned)(8 + WT) * 1024u + (unsigned)(32 * ks + 8 * q) * 4u;
+        const unsigned cb = base + (unsigned)(AT + WT) * 1024u + (unsigned)(32 * ks + 8 * q) * 4u;
         asm volatile("ds_read_b128 %0, %1" : "=v"(cf[ks][0]) : "v"(cb) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(cf[ks][1]) : "v"(cb) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(cf[ks][2]) : "v"(cb) : "memory");
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256, WGPC) void k_gemm_nt_swg(const bf16_t* __restr
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
           const int wr = 16 * t + j, p = 4 * ks + q;
-          const unsigned wa = base + 8u * 1024u + (unsigned)wr * 128u + (unsigned)((p ^ (wr & 7)) << 4);
+          const unsigned wa = base + (unsigned)AT * 1024u + (unsigned)wr * 128u + (unsigned)((p ^ (wr & 7)) << 4);
           asm volatile("ds_read_b128 %0, %1" : "=v"(wf[t]) : "v"(wa) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -177,12 +182,12 @@ __global__ __launch_bounds__(256, WGPC) void k_gemm_nt_swg(const bf16_t* __restr
         }
       }
     __syncthreads();
-    for (int i = tid; i < 2 * 16 * UT; i += 256) {
+    for (int i = tid; i < 2 * 16 * UT; i += NT) {
       const int pl = i / (16 * UT), ch = i % (16 * UT);
       if (ch < N) {
         float v = s_stat[(0 * 2 + pl) * 16 * UT + ch];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += s_stat[(w * 2 + pl) * 16 * UT + ch];
+        for (int w = 1; w < NWV; ++w) v += s_stat[(w * 2 + pl) * 16 * UT + ch];
         const long elem = (long)pl * N + ch;
         stats[(long)rs * 2 * N + elem] = v;
         stat_zero_tail(stats, 2L * N, rs + R, R, stat_rows, elem);
@@ -191,18 +196,18 @@ __global__ __launch_bounds__(256, WGPC) void k_gemm_nt_swg(const bf16_t* __restr
   }
 }
 
-template <int UT, int WGPC>
+template <int UT, int WGPC, int NWV>
 static int launch_swg(const bf16_t* a, long ass, const float* scale, const float* shift, int act, const bf16_t* W, int ldw, bf16_t* c, int ldc,
                       float* stats, int stat_rows, long M, int N, int K, hipStream_t st) {
   constexpr int DEPTH = 3;
-  const size_t lds = (size_t)4 * 2 * 16 * UT * sizeof(float) + (size_t)DEPTH * (8 + 2 * UT + 1) * 1024;
+  const size_t lds = (size_t)NWV * 2 * 16 * UT * sizeof(float) + (size_t)DEPTH * (2 * NWV + 2 * UT + 1) * 1024;
   if (lds > max_lds_bytes()) return 1;
-  auto kern = k_gemm_nt_swg<UT, DEPTH, WGPC>;
-  const long rblocks = (M + 63) / 64;
-  long R = (long)num_cus() * resident_per_cu(kern, 256, lds);
+  auto kern = k_gemm_nt_swg<UT, DEPTH, WGPC, NWV>;
+  const long rblocks = (M + NWV * 16 - 1) / (NWV * 16);
+  long R = (long)num_cus() * resident_per_cu(kern, NWV * 64, lds);
   if (R > rblocks) R = rblocks;
   if (stats && R > stat_rows) R = stat_rows;
-  hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(256), lds, st, a, ass, scale, shift, act, W, ldw, c, ldc, stats, stat_rows, M, N, K);
+  hipLaunchKernelGGL(kern, dim3((unsigned)R), dim3(NWV * 64), lds, st, a, ass, scale, shift, act, W, ldw, c, ldc, stats, stat_rows, M, N, K);
   return check_launch("exp_nt_swg");
 }
 
@@ -218,8 +223,12 @@ extern "C" int atomnas_exp_nt_swg(const void* a, long a_ss, const float* scale, 
                       ldw >= 64 && ldw % 8 == 0 && ldc >= N, "exp_nt_swg: bad arguments");
   const int ut = (N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-#define SWG_CASE(UTV, WG) \
-  if (ut == UTV) return launch_swg<UTV, WG>((const bf16_t*)a, a_ss, scale, shift, act, (const bf16_t*)w, ldw, (bf16_t*)c, ldc, stats, stat_rows, M, N, K, st);
+  static const int nwv = getenv("ATOMNAS_SWG_WAVES") ? atoi(getenv("ATOMNAS_SWG_WAVES")) : 4;   // 4: 64-row stages, 8: 128-row stages
+#define SWG_CASE(UTV, WG)                                                                                                              \
+  if (ut == UTV) {                                                                                                                     \
+    if (nwv == 8) return launch_swg<UTV, 1, 8>((const bf16_t*)a, a_ss, scale, shift, act, (const bf16_t*)w, ldw, (bf16_t*)c, ldc, stats, stat_rows, M, N, K, st); \
+    return launch_swg<UTV, WG, 4>((const bf16_t*)a, a_ss, scale, shift, act, (const bf16_t*)w, ldw, (bf16_t*)c, ldc, stats, stat_rows, M, N, K, st); \
+  }
   SWG_CASE(3, 2) SWG_CASE(5, 2) SWG_CASE(6, 2) SWG_CASE(12, 1)
 #undef SWG_CASE
   set_error("exp_nt_swg: no instance for N=%d", N);

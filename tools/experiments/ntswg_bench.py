@@ -73,5 +73,5 @@ for (M, N, K) in [(200704, 40, 720), (50176, 80, 1440), (50176, 96, 1728), (1254
     ds = float(((s0 - s1).abs() / (s0.abs() + 1e-3 * s0.abs().max())).max())
     ok = float(d.max()) <= 2e-2 * max(1.0, scale) and ds < 2e-2
     t0, t1 = bench(ref), bench(new)
-    print("M%-7d N%-4d K%-5d: product %6.1f us (%4.0f GB/s)   prototype %6.1f us (%4.0f GB/s)   max |diff| %.3g of %.3g, stats rel %.2g  %s"
-          % (M, N, K, t0, M * K * 2 / t0 / 1e3, t1, M * K * 2 / t1 / 1e3, float(d.max()), scale, ds, "OK" if ok else "MISMATCH"), flush=True)
+    print("waves %s  M%-7d N%-4d K%-5d: product %6.1f us (%4.0f GB/s)   prototype %6.1f us (%4.0f GB/s)   max |diff| %.3g of %.3g, stats rel %.2g  %s"
+          % (os.environ.get("ATOMNAS_SWG_WAVES", "4"), M, N, K, t0, M * K * 2 / t0 / 1e3, t1, M * K * 2 / t1 / 1e3, float(d.max()), scale, ds, "OK" if ok else "MISMATCH"), flush=True)
