@@ -286,6 +286,37 @@ def test_asm_loads_are_waited_for_before_use():
     import subprocess
     if not os.environ.get("ATOMNAS_ISA_CHECK"):
         pytest.skip("set ATOMNAS_ISA_CHECK=1 (about 3 minutes of hipcc -S on first use)")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_waits.py"), os.path.join(ROOT, "atomnas_amd", "csrc", "dwconv_cw.hip"),
-                        os.path.join(ROOT, "atomnas_amd", "csrc", "dwconv.hip")], capture_output=True, text=True)
+    files = [os.path.join(ROOT, "atomnas_amd", "csrc", f) for f in ("dwconv_cw.hip", "dwconv.hip", "pwconv.hip", "xbwd.hip")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_waits.py")] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_asm_wait_checker_follows_the_control_flow(tmp_path):
+    """The checker itself (tools/check_asm_waits.py) on synthetic assembly: a consumer laid out BEFORE the block that waits is fine
+    when every path to it passes the wait, a use on a path without the wait is a finding, a use inside inline asm is not."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_asm_waits as caw
+    ok = """
+_Z4goodv:
+	s_cbranch_vccz .LBB0_3
+.LBB0_1:
+	v_add_f32_e32 v1, v10, v10
+	s_endpgm
+.LBB0_3:
+	;;#ASMSTART
+	ds_read_b64_tr_b16 v[10:11], v5
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	s_branch .LBB0_1
+.Lfunc_end0:
+"""
+    bad = ok.replace("\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n", "")
+    fo, fb = tmp_path / "ok.s", tmp_path / "bad.s"
+    fo.write_text(ok)
+    fb.write_text(bad)
+    f, n = caw.check(str(fo))
+    assert n == 1 and not f, f
+    f, n = caw.check(str(fb))
+    assert n == 1 and len(f) == 1 and "v_add_f32" in f[0], f

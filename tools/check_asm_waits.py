@@ -7,8 +7,8 @@ scans the gfx950 assembly of a translation unit and reports every instruction th
 
     python tools/check_asm_waits.py atomnas_amd/csrc/dwconv_cw.hip      (compiles with the build's flags, -S)  -> exit 1 on a finding
 
-Linear scan per function: registers written by an asm load are pending until an `s_waitcnt` with lgkmcnt(0) (or a bare
-`s_waitcnt lgkmcnt(0)`), and no instruction outside ASMSTART/ASMEND may name a pending register.
+Per function a forward data-flow over the basic blocks: registers written by an asm load are pending until an `s_waitcnt` with
+lgkmcnt(0), and no instruction outside ASMSTART/ASMEND may name a pending register on any path.
 """
 import os
 import re
@@ -43,12 +43,20 @@ def assemble(src):
     return out
 
 
-def check(path):
-    findings, func, in_asm, pending, nloads = [], None, False, set(), 0
+ASM_LOADS = ("ds_read_b64", "s_load_dwordx2", "s_load_dwordx4", "ds_read_b128", "ds_read_b32", "ds_read_b64_tr_b16")
+
+
+def functions(path):
+    """[(name, [(line number, text, inside inline asm)])] per kernel of the assembly file"""
+    out, cur, in_asm = [], None, False
     for ln, line in enumerate(open(path), 1):
         t = line.strip()
         if re.match(r"^_Z\w+:", t):
-            func, pending = t.split(":")[0], set()
+            cur = (t.split(":")[0], [])
+            out.append(cur)
+            in_asm = False
+            continue
+        if cur is None:
             continue
         if t.startswith(";;#ASMSTART"):
             in_asm = True
@@ -56,22 +64,78 @@ def check(path):
         if t.startswith(";;#ASMEND"):
             in_asm = False
             continue
-        if not t or t[0] in ";." or t.endswith(":"):
+        if t.startswith(".Lfunc_end"):
+            cur = None
             continue
-        op, _, rest = t.partition(" ")
-        rest = rest.split(";")[0]
-        if op == "s_waitcnt":
-            if "lgkmcnt(0)" in rest:
-                pending = set()
+        if not t or t[0] == ";" or (t[0] == "." and not t.endswith(":")):
             continue
-        if in_asm:
-            if op in ("ds_read_b64", "s_load_dwordx2", "s_load_dwordx4", "ds_read_b128", "ds_read_b32"):
-                pending |= regs(rest.split(",")[0])
-                nloads += 1
-            continue
-        hit = regs(rest) & pending
-        if hit:
-            findings.append("%s:%d %s: `%s` touches %s while its asm load is in flight" % (os.path.basename(path), ln, func, t, sorted(hit)[:4]))
+        cur[1].append((ln, t.split(";")[0].strip() if not t.endswith(":") else t, in_asm))
+    return out
+
+
+def check(path):
+    """Forward data-flow over the basic blocks of every kernel: `pending` = registers written by an inline-asm load that no
+    `s_waitcnt ... lgkmcnt(0)` has covered yet; at a block entry the union over its predecessors (the assembler lays blocks out of
+    line: a linear scan would see the consumers of a conditional read before its wait).  A finding = an instruction outside inline
+    asm that names a pending register."""
+    findings, nloads = [], 0
+    for func, ins in functions(path):
+        # basic blocks
+        blocks, label_of, cur = [], {}, []
+        for item in ins:
+            ln, t, ia = item
+            if t.endswith(":"):
+                if cur:
+                    blocks.append(cur)
+                cur = []
+                label_of[t[:-1]] = len(blocks)
+                continue
+            cur.append(item)
+            op = t.split(" ")[0]
+            if op.startswith("s_cbranch") or op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                blocks.append(cur)
+                cur = []
+        if cur:
+            blocks.append(cur)
+        # a label may point at an index one past the blocks emitted so far: it names the NEXT block
+        succ = [[] for _ in blocks]
+        for i, blk in enumerate(blocks):
+            if not blk:
+                if i + 1 < len(blocks):
+                    succ[i].append(i + 1)
+                continue
+            t = blk[-1][1]
+            op = t.split(" ")[0]
+            tgt = t.split(" ")[-1] if (op.startswith("s_cbranch") or op == "s_branch") else None
+            if tgt is not None and tgt in label_of and label_of[tgt] < len(blocks):
+                succ[i].append(label_of[tgt])
+            if op not in ("s_branch", "s_endpgm", "s_setpc_b64") and i + 1 < len(blocks):
+                succ[i].append(i + 1)
+        entry = [set() for _ in blocks]
+        work = list(range(len(blocks)))
+        reported = set()
+        while work:
+            i = work.pop()
+            pending = set(entry[i])
+            for ln, t, ia in blocks[i]:
+                op, _, rest = t.partition(" ")
+                if op == "s_waitcnt":
+                    if "lgkmcnt(0)" in rest:
+                        pending = set()
+                    continue
+                if ia:
+                    if op in ASM_LOADS:
+                        pending |= regs(rest.split(",")[0])
+                    continue
+                hit = regs(rest) & pending
+                if hit and ln not in reported:
+                    reported.add(ln)
+                    findings.append("%s:%d %s: `%s` touches %s while its asm load is in flight" % (os.path.basename(path), ln, func, t, sorted(hit)[:4]))
+            for j in succ[i]:
+                if not pending <= entry[j]:
+                    entry[j] |= pending
+                    work.append(j)
+        nloads += sum(1 for _, t, ia in ins if ia and t.split(" ")[0] in ASM_LOADS)
     return findings, nloads
 
 
