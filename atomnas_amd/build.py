@@ -44,9 +44,27 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+
+
+def _deps(path, seen=None):
+    """the quoted includes of a source, transitively (paths relative to the including file)"""
+    seen = [] if seen is None else seen
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith('#include "'):
+                inc = os.path.normpath(os.path.join(os.path.dirname(path), line.split('"')[1]))
+                if inc not in seen and os.path.exists(inc):
+                    seen.append(inc)
+                    _deps(inc, seen)
+    return seen
+
+
 def _digest(path):
     h = hashlib.sha1()
-    for p in [path, os.path.join(CSRC, "common.h")]:
+    for p in [path] + sorted(_deps(path)):
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
@@ -54,10 +72,10 @@ def _digest(path):
 
 
 def sources_digest():
-    """sha1 over every kernel source, common.h and the compiler flags: identifies the library a measurement belongs to
+    """sha1 over every kernel source, the headers of csrc/ and the compiler flags: identifies the library a measurement belongs to
     (profiles/*_pmc_*.json carry it as `lib_src_sha`; bench.py drops PMC-derived figures taken on another build)"""
     h = hashlib.sha1()
-    for p in sources() + [os.path.join(CSRC, "common.h")]:
+    for p in sources() + headers():
         with open(p, "rb") as f:
             h.update(os.path.basename(p).encode())
             h.update(f.read())

@@ -207,14 +207,14 @@ int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
                   float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride,
                   int dtype, hipStream_t st);
 
-#ifdef ATOMNAS_EXPERIMENTAL_XDW
-// dwconv_cw.hip: the depthwise backward with the expand output recomputed on chip (entry point atomnas_xdw_bwd in xdw.hip)
-int xdw_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3, const void* xin,
-               int ldx, int inp, const void* wexp, int ldwe, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h,
-               long hss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k,
-               hipStream_t st);
-int xdw_cw_bwd_supported(int N, int H, int W, int C, int k);
-#endif
+// dwconv_mm.hip: the bf16 instances of the depthwise forward with the tap arithmetic on the matrix cores (same contract: -1 = not mine)
+int dwconv_mm_fwd(const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y, long yss,
+                  float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int dtype, hipStream_t st);
+int dwconv_mm_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
+                  const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h, long hss,
+                  float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride,
+                  int dtype, hipStream_t st);
+int dwconv_mm_fwd_supported(int N, int H, int W, int C, int k);
 
 #define ATOMNAS_REQUIRE(cond, ...)            \
   do {                                        \

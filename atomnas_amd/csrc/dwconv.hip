@@ -1054,7 +1054,9 @@ extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, long x_ss, const float
   ATOMNAS_REQUIRE(!stats || (stat_ld >= C && stat_rows > 0), "dwconv_fwd: statistics pitch %d < C=%d or stat_rows=%d", stat_ld, C, stat_rows);
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
-    const int rc = dwconv_cw_fwd(x, x_ss, in_scale, in_shift, in_relu, w, ldw, y, y_ss, stats, stat_ld, stat_rows, N, H, W, C, k, dtype, st);
+    int rc = dwconv_mm_fwd(x, x_ss, in_scale, in_shift, in_relu, w, ldw, y, y_ss, stats, stat_ld, stat_rows, N, H, W, C, k, dtype, st);
+    if (rc >= 0) return rc;
+    rc = dwconv_cw_fwd(x, x_ss, in_scale, in_shift, in_relu, w, ldw, y, y_ss, stats, stat_ld, stat_rows, N, H, W, C, k, dtype, st);
     if (rc >= 0) return rc;
   }
   DW_DISPATCH(launch_fwd, x, ldx, x_ss, in_scale, in_shift, in_relu, w, ldw, y, ldy, y_ss, stats, stat_ld, stat_rows, N, H, W, C, st);
@@ -1082,8 +1084,11 @@ extern "C" int atomnas_dwconv_bwd(const void* g, int ldg, long g_ss, const void*
   ATOMNAS_REQUIRE(!dw || dw_ws, "dwconv_bwd: the weight gradient needs the partial workspace dw_ws [part_rows][C][k*k]");
   hipStream_t st = (hipStream_t)stream;
   {
-    const int rc = dwconv_cw_bwd(g, g_ss, yraw, yraw_ss, c1, c2, c3, x, x_ss, in_scale, in_shift, in_relu, w, ldw, h, h_ss, dw, stats, stat_ld,
-                                 part_rows, dw_ws, N, H, W, C, k, stride, dtype, st);
+    int rc = dwconv_mm_bwd(g, g_ss, yraw, yraw_ss, c1, c2, c3, x, x_ss, in_scale, in_shift, in_relu, w, ldw, h, h_ss, dw, stats, stat_ld,
+                           part_rows, dw_ws, N, H, W, C, k, stride, dtype, st);
+    if (rc >= 0) return rc;
+    rc = dwconv_cw_bwd(g, g_ss, yraw, yraw_ss, c1, c2, c3, x, x_ss, in_scale, in_shift, in_relu, w, ldw, h, h_ss, dw, stats, stat_ld,
+                       part_rows, dw_ws, N, H, W, C, k, stride, dtype, st);
     if (rc >= 0) return rc;
   }
   DW_DISPATCH(launch_bwd, g, ldg, g_ss, yraw, ldyr, yraw_ss, c1, c2, c3, x, ldx, x_ss, in_scale, in_shift, in_relu, w, ldw, h, ldh,

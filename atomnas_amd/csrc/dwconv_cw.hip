@@ -22,176 +22,13 @@
 // Numerics: identical arithmetic per element to dwconv.hip (fp32 accumulation, one rounding to the storage type); per-channel
 // sums are per-lane partials added in a fixed order (lanes by butterfly, workers by reduce_parts / the BatchNorm finalize), so
 // results are bit-reproducible.  No atomics.
-#include "common.h"
-#include <cstdlib>
-
-#ifndef CW_TIMING
-#define CW_TIMING 0   // experiment builds (tools/variant.sh): s_memtime accounting of the phases of a tile in the backward kernel
-#endif
+#include "dwconv_cw.h"
 
 namespace atomnas {
 
 #if CW_TIMING
 __device__ unsigned long long g_cw_timing[8];
-#define CWMARK(i)                                                    \
-  {                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    const unsigned long long tn_ = __builtin_readcyclecounter();     \
-    tacc[i] += tn_ - tlast;                                          \
-    tlast = tn_;                                                     \
-    __builtin_amdgcn_sched_barrier(0);                               \
-  }
-#else
-#define CWMARK(i)
 #endif
-
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-struct CwGeom {
-  int N, H, W, C;
-  int TH, NI, tiles_y, ns;   // tile: NI images x TH rows x W columns; ns = W / 7 strips per row
-  int LH, LWp, plane;        // operand window: rows per image, row pitch, elements (f32x2) per channel-pair plane
-  int RH;                    // rows of the window ring per image (= LH)
-  int TPIX, TPIXp;           // pixels per tile; pitch of the pixel planes
-  int nworkers, nslabs, ntiles;
-  int ring;                  // 1: several tiles per image, the window rows are a ring
-  // stride-2 kernels (k_dwb_cw2 / k_dwf_cw2): the lanes live on the dY / output grid (Ho x Wo), the window holds that grid
-  int Ho, Wo, THd;           // output rows / columns, output rows per tile (TH = 2 THd input rows)
-  int TPIXD;                 // output pixels per tile
-};
-
-// storage-type plumbing: `piece` = 8 channels of one pixel (16-byte global accesses), `pair` = one channel pair of one pixel
-template <typename T> struct Cw;
-template <> struct Cw<bf16_t> {
-  typedef unsigned pair_t;
-  struct piece_t { u32x4 v; };
-  static __device__ __forceinline__ void zero(piece_t& p) { p.v = u32x4{0u, 0u, 0u, 0u}; }
-  static __device__ __forceinline__ void load(piece_t& p, const bf16_t* s) { p.v = *reinterpret_cast<const u32x4*>(s); }
-  static __device__ __forceinline__ void store(const piece_t& p, bf16_t* d) { *reinterpret_cast<u32x4*>(d) = p.v; }
-  static __device__ __forceinline__ pair_t pair(const piece_t& p, int q) { return p.v[q]; }
-  static __device__ __forceinline__ void set_pair(piece_t& p, int q, pair_t v) { p.v[q] = v; }
-  static __device__ __forceinline__ float lo(pair_t v) { return __uint_as_float(v << 16); }
-  static __device__ __forceinline__ float hi(pair_t v) { return __uint_as_float(v & 0xffff0000u); }
-  static __device__ __forceinline__ pair_t pack(float a, float b) {
-    bf16x2 t;
-    t[0] = (bf16_t)a; t[1] = (bf16_t)b;   // RNE
-    return __builtin_bit_cast(unsigned, t);
-  }
-  static __device__ __forceinline__ pair_t zero_pair() { return 0u; }
-  static __device__ __forceinline__ void touch(const piece_t& p) { asm volatile("" ::"v"(p.v)); }   // "the register is read here"
-};
-template <> struct Cw<float> {
-  typedef f32x2 pair_t;
-  struct piece_t { f32x4 a, b; };
-  static __device__ __forceinline__ void zero(piece_t& p) { p.a = f32x4{0.f, 0.f, 0.f, 0.f}; p.b = p.a; }
-  static __device__ __forceinline__ void load(piece_t& p, const float* s) {
-    p.a = *reinterpret_cast<const f32x4*>(s); p.b = *reinterpret_cast<const f32x4*>(s + 4);
-  }
-  static __device__ __forceinline__ void store(const piece_t& p, float* d) {
-    *reinterpret_cast<f32x4*>(d) = p.a; *reinterpret_cast<f32x4*>(d + 4) = p.b;
-  }
-  static __device__ __forceinline__ pair_t pair(const piece_t& p, int q) {
-    return q < 2 ? f32x2{p.a[2 * q], p.a[2 * q + 1]} : f32x2{p.b[2 * q - 4], p.b[2 * q - 3]};
-  }
-  static __device__ __forceinline__ void set_pair(piece_t& p, int q, pair_t v) {
-    if (q < 2) { p.a[2 * q] = v[0]; p.a[2 * q + 1] = v[1]; } else { p.b[2 * q - 4] = v[0]; p.b[2 * q - 3] = v[1]; }
-  }
-  static __device__ __forceinline__ float lo(pair_t v) { return v[0]; }
-  static __device__ __forceinline__ float hi(pair_t v) { return v[1]; }
-  static __device__ __forceinline__ pair_t pack(float a, float b) { return f32x2{a, b}; }
-  static __device__ __forceinline__ pair_t zero_pair() { return f32x2{0.f, 0.f}; }
-  static __device__ __forceinline__ void touch(const piece_t& p) { asm volatile("" ::"v"(p.a), "v"(p.b)); }
-};
-
-__device__ __forceinline__ float cw_act(float a, int in_relu, int AM) {
-  if (AM == ACT_RELU6) return fminf(fmaxf(a, 0.f), 6.f);
-  if (AM == ACT_SWISH) return swish_f(a);
-  return in_relu ? fmaxf(a, 0.f) : a;
-}
-__device__ __forceinline__ float cw_act_bwd(float c, float a, int in_relu, int AM) {
-  if (AM == ACT_RELU6) return (a > 0.f && a < 6.f) ? c : 0.f;
-  if (AM == ACT_SWISH) return c * swish_grad(a);
-  return (in_relu && !(a > 0.f)) ? 0.f : c;
-}
-
-// Sum over the 64 lanes of a wave with DPP adds only (no LDS traffic): quad butterflies, half-row and row mirrors leave every
-// lane with the sum of its 16-lane row; row_bcast15 / row_bcast31 then carry the row sums upwards.  The total is valid in
-// lanes 48..63 (lane 63 is read); the order of the additions is fixed.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float cw_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
-}
-__device__ __forceinline__ float cw_wave_sum63(float v) {
-  v += cw_dpp<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v += cw_dpp<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v += cw_dpp<0x141, 0xF>(v);   // row_half_mirror
-  v += cw_dpp<0x140, 0xF>(v);   // row_mirror
-  v += cw_dpp<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
-  v += cw_dpp<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
-  return v;
-}
-__device__ __forceinline__ unsigned cw_lds_addr(const void* p) {
-  return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
-}
-// The operands of one tap row, all asynchronous: the K tap pairs of the wave's channel pair as scalar loads (s_load_dwordx2 from
-// the tap-major table: wave-uniform, so they cost no vector instruction and no vector register -- v_readlane broadcasts were
-// measured at 9 cycles each, 14 per row next to 98 FMAs of ~4, tools/probe/vpk.hip) and the lane's NR consecutive operand pairs
-// from LDS.  Inline asm on purpose: hipcc's load/store optimizer merges neighbouring ds_read_b64 into ds_read2_b64, which moves
-// the same bytes in twice the LDS cycles (MI355X_MICROARCH.md, LDS table), and it cannot keep SMEM results in flight across
-// its own waits.  The loads are invisible to the compiler's wait counters: cw_row_wait() makes every result valid before its first
-// use (s_waitcnt + scheduling fence; cdna_hip_programming.md 5.7 form iii).
-template <int K, int NR>
-__device__ __forceinline__ void cw_row_issue(f32x2 (&wr)[K], f32x2 (&v)[NR], const float* wp, unsigned tap_off, unsigned ld4, unsigned addr) {
-#pragma unroll
-  for (int kx = 0; kx < K; ++kx) asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(wr[kx]) : "s"(wp), "s"(tap_off + (unsigned)kx * ld4));
-#pragma unroll
-  for (int i = 0; i < NR; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[i]) : "v"(addr), "i"(i * 8));
-}
-__device__ __forceinline__ void cw_row_wait() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// Tile-independent decode of the two staging slots of a thread: slot i of thread tid is 16-byte piece (tid + i * NT) of the tile;
-// pieces run over (image, row, column, channel group of the workgroup) with the channel group fastest.
-struct CwSlots {
-  int pp[2];     // pixel index inside the tile (im, row, col) -> also the index into the pixel planes; -1: no such piece
-  int rr[2];     // row inside the tile
-  int dyo[2];    // window element offset without the row term: im * LH * LWp + col + P
-  int goff[2];   // element offset inside the slab relative to the tile's first pixel: ((im * H + rr) * W + col) * 16 + cg * 8
-  int im[2];
-};
-template <int P, int NT, int CGS>
-__device__ __forceinline__ void cw_decode(CwSlots& s, const CwGeom& g, int tid, int cg) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pp = (tid + i * NT) / CGS;
-    const bool ok = pp < g.TPIX;
-    const int col = pp % g.W, t2 = pp / g.W;
-    const int rr = t2 % g.TH, im = t2 / g.TH;
-    s.pp[i] = ok ? pp : -1;
-    s.rr[i] = rr;
-    s.im[i] = im;
-    s.dyo[i] = im * g.RH * g.LWp + col + P;
-    s.goff[i] = ((im * g.H + rr) * g.W + col) * 16 + cg * 8;
-  }
-}
-
-// Workgroup -> (slab, worker, half).  NW = 8: the 8 waves are the 8 channel pairs of a slab.  NW = 4: a workgroup owns 8 of the 16
-// channels (the 16-byte half of every 32-byte pixel); blocks b and b + 8 -- the same XCD, i.e. the same L2, under the observed
-// round-robin placement -- are the two halves of one (slab, worker), so the shared 128-byte lines are fetched from HBM once.
-template <int NW>
-__device__ __forceinline__ bool cw_block(const CwGeom& g, int& slab, int& worker, int& half) {
-  if (NW == 8) {
-    slab = blockIdx.x % g.nslabs; worker = blockIdx.x / g.nslabs; half = 0;
-    return true;
-  }
-  const int q = blockIdx.x >> 3;
-  half = q & 1;
-  const int u = (q >> 1) * 8 + (blockIdx.x & 7);
-  slab = u % g.nslabs; worker = u / g.nslabs;
-  return worker < g.nworkers;
-}
 
 // ---------------------------------------------------------------------------------------------------------------- backward
 //   dYraw = c1*g + c2*yraw + c3 (BN-backward of the BN behind the conv, on load; yraw == NULL: dYraw = g)
@@ -505,393 +342,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw(const T* __restrict__ g
 #endif
 }
 
-#ifdef ATOMNAS_EXPERIMENTAL_XDW   // round-4 experiment (csrc/experimental/xdw_fused.hip): not part of the product library
-// ------------------------------------------------------------------------------------------- backward, expand recomputed
-// k_dwb_cw with its input operand recomputed on chip ("E-elimination", see xdw.hip): the raw expand output E = xin W1^T of the
-// tile's pixels comes out of an MFMA stage (weights of the slab as the A operand, 16-pixel groups of the narrow block input xin
-// as the B operand straight from global memory, prefetched behind the tap loop like the other streams) instead of a fourth HBM
-// stream, in fp32 (it used to be read back rounded to bf16).  Half-slab workgroups of 4 waves: the MFMA tile covers the 16
-// channels of the slab, the workgroup keeps its 8.
-//   dYraw = c1*g + c2*yraw + c3;  e = xin W1^T;  h = dwconv^T(dYraw) * act'(e*in_scale+in_shift),
-//   dW += corr(act(e*in_scale+in_shift), dYraw),  stats: sum h, sum h*e
-template <int K, int AM, int KC, int WPS, bool PF>
-__global__ __launch_bounds__(256, WPS) void k_xdwb(const bf16_t* __restrict__ gup, long gss, const bf16_t* __restrict__ yraw, long yrss,
-                                                   const float* __restrict__ c1, const float* __restrict__ c2p,
-                                                   const float* __restrict__ c3, const bf16_t* __restrict__ xin, int ldx, int inp,
-                                                   const bf16_t* __restrict__ wexp, int ldwe,
-                                                   const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                   int in_relu, const float* __restrict__ w, int ldw, bf16_t* __restrict__ h, long hss,
-                                                   float* __restrict__ dwp, float* __restrict__ stats, int stat_ld, int stat_rows,
-                                                   CwGeom g) {
-  typedef bf16_t T;
-  constexpr int NW = 4, GPW = 7;
-  constexpr bool LATEB = (K == 7);
-  typedef Cw<T> X;
-  typedef typename X::pair_t pair_t;
-  typedef typename X::piece_t piece_t;
-  constexpr int P = (K - 1) / 2, KK = K * K, SW = 7, DWN = SW + K - 1, NT = NW * 64, CGS = NW / 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x2* s_dy = reinterpret_cast<f32x2*>(smem);                    // [NW pairs][plane]: dYraw window, fp32
-  f32x2* s_xe = s_dy + NW * g.plane;                                 // [NW pairs][TPIXp]: raw expand output of the tile, fp32
-  pair_t* s_x = reinterpret_cast<pair_t*>(s_xe + NW * g.TPIXp);       // [NW pairs][TPIXp]: h of the tile (bf16 pairs)
-  float* s_cf = reinterpret_cast<float*>(s_x + NW * g.TPIXp);        // [3][16] BN-backward coefficients of the slab
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);           // channel pair of this wave (wave-uniform)
-  const int mq_ = lane >> 4, mj_ = lane & 15;                         // MFMA lane coordinates
-  int slab, worker, half;
-  {
-    // blocks b and b + 8 (the same XCD under round-robin placement) are the two halves of one (slab, worker) unit.  Every XCD owns a
-    // CONTIGUOUS range of the worker-major unit list, i.e. all slabs of a few workers -- the same pixel tiles of xin -- so its L2
-    // fetches those tiles once (a worker whose slabs straddle two XCDs is fetched twice).
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    half = li & 1;
-    const int units = g.nworkers * g.nslabs, upx = (units + 7) >> 3;
-    const int pidx = li >> 1;
-    const int unit = xcd * upx + pidx;
-    if (pidx >= upx || unit >= units) return;   // surplus block (whole workgroup, before any barrier)
-    worker = unit / g.nslabs;
-    slab = unit - worker * g.nslabs;
-  }
-  const int c_base = slab * 16;
-  const int ch = c_base + 2 * (wv + 4 * half);
-  const int cpad = (g.C + 7) & ~7;
-  const int cgl = CGS == 2 ? (tid & 1) : 0;   // channel group inside the workgroup's planes
-  const int cg = cgl + half;                   // channel group inside the slab
-  const bool cg_ok = c_base + cg * 8 < cpad;
-
-  for (int i = tid; i < NW * g.plane; i += NT) s_dy[i] = f32x2{0.f, 0.f};   // halo columns / rows outside the image stay zero
-  if (tid < 48) {
-    const int v = tid >> 4, c = c_base + (tid & 15);
-    const float* src = (v == 0) ? c1 : (v == 1 ? c2p : c3);
-    s_cf[tid] = (c1 && src && (v == 0 || yraw) && c < cpad) ? src[c] : (v == 0 ? 1.f : 0.f);
-  }
-
-  // wave-uniform per-channel scalars
-  float sc0 = 1.f, sc1 = 1.f, sh0 = 0.f, sh1 = 0.f;
-  if (in_scale && ch < cpad) { sc0 = in_scale[ch]; sc1 = in_scale[ch + 1]; sh0 = in_shift[ch]; sh1 = in_shift[ch + 1]; }
-  const bool ch0_ok = ch < g.C, ch1_ok = ch + 1 < g.C;
-  // taps of the pair: w[t * ldw + ch], w[t * ldw + ch + 1] (ldw >= C rounded up to 8: the host side checks), read per tap row
-  // as wave-uniform scalars.  Taps of channels beyond C are whatever the table holds there: their results are forced to zero.
-  const float* wp = w + ch;
-  unsigned ld4 = (unsigned)ldw * 4u;
-
-  CwSlots sl;
-  cw_decode<P, NT, CGS>(sl, g, tid, cg);
-
-  // work item of this lane: (image, row, strip) -- tile-independent
-  const int ipi = g.TH * g.ns;
-  const int it_im = lane / ipi, it_rem = lane % ipi;
-  const int it_r = it_rem / g.ns, it_j = it_rem % g.ns;
-  const bool it_ok = lane < g.NI * ipi;
-  const int pix0 = (it_im * g.TH + it_r) * g.W + SW * it_j;
-  const unsigned dy_addr0 = cw_lds_addr(s_dy + wv * g.plane + it_im * g.RH * g.LWp + SW * it_j);   // + slot * LWp * 8
-
-  f32x2 dwa[KK];
-#pragma unroll
-  for (int t = 0; t < KK; ++t) dwa[t] = f32x2{0.f, 0.f};
-  float s0a = 0.f, s0b = 0.f, s1a = 0.f, s1b = 0.f;
-
-  piece_t pfg[2], pfy[2];
-  unsigned pfmask = 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { X::zero(pfg[i]); X::zero(pfy[i]); }
-  // expand weights of the slab as MFMA A fragments (row = channel c_base + mj), fetched with the pixels of every tile (L1 hits)
-  bf16x8 afr[KC];
-  bf16x8 bfr[GPW][KC];   // pixels of xin: group gi of this wave = tile pixels 16 (4 gi + wv) .. + 15
-
-  const int t_beg = (int)((long)worker * g.ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * g.ntiles / g.nworkers);
-  const long slab_g = (long)slab * gss, slab_y = (long)slab * yrss, slab_h = (long)slab * hss;
-
-  // issue the HBM loads of a tile (n0 = first image, hi0 = first row): dY rows [ho_s, ho_s + TH), input rows [hi0, hi0 + TH)
-  // Branch-free: a piece that does not exist (image / row beyond the tensor, channel group beyond C) reads the first piece of the
-  // slab instead and is masked at the commit.  (With the loads under per-lane branches hipcc cannot prove at the loop back-edge
-  // that they were waited for, and puts an s_waitcnt vmcnt(0) in front of the next tile's loads: that wait also covers the h
-  // stores issued just before -- 20 to 30 % of the kernel in the first measurements.)
-  auto issue = [&](int n0, int hi0) {
-    const int ho_s = g.ring ? hi0 + P : 0;
-    const long pg = ((long)n0 * g.H + ho_s) * g.W * 16;
-    pfmask = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool in_n = sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N;
-      const bool okg = in_n && ho_s + sl.rr[i] < g.H;
-      const long og = okg ? pg + sl.goff[i] : 0;
-      X::load(pfg[i], gup + slab_g + og);
-      if (yraw) X::load(pfy[i], yraw + slab_y + og);
-      pfmask |= okg ? 1u << i : 0u;
-    }
-  };
-  // the tile's pixels of xin (contiguous: whole rows / whole images); beyond the tensor: the first bytes of xin, zeroed.
-  // k = 7 (LATEB): issued behind the tap loop instead of in front of it -- its operand buffers and the weight-gradient
-  // accumulators leave no registers for the fragments; the activation epilogue, barrier (A), the h stores and the dY commit
-  // cover the (L2) latency.
-  auto issue_b = [&](int n0, int hi0) {
-    // opaque per tile: the fragment addresses are formed here (hoisted out of the tile loop they stay live across the tap rows)
-    int mj = mj_, mq = mq_;
-    asm volatile("" : "+v"(mj), "+v"(mq));
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) afr[kc] = *reinterpret_cast<const bf16x8*>(wexp + (long)(c_base + mj) * ldwe + kc * 32 + 8 * mq);
-    const long base_px = ((long)n0 * g.H + hi0) * g.W;
-    const long lim_l = g.NI == 1 ? (long)(g.H - hi0) * g.W : (long)(g.N - n0) * g.H * g.W;
-    const int lim = (int)(lim_l < g.TPIX ? lim_l : g.TPIX);
-#pragma unroll
-    for (int gi = 0; gi < GPW; ++gi) {
-      const int pp = (gi * 4 + wv) * 16 + mj;
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const int kk = kc * 32 + 8 * mq;
-        // beyond the tensor / beyond inp: the first bytes of xin -- finite values that meet zero weight columns or are never read
-        const bool ok = pp < lim && kk < inp;
-        bfr[gi][kc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xin + (ok ? (base_px + pp) * ldx + kk : 0)));
-      }
-    }
-  };
-  // dYraw of one piece -> the four pair planes of this thread's channel group
-  auto put_dy = [&](const piece_t& pg_, const piece_t& py_, bool ok, f32x2* d) {
-    float q1[8], q2[8], q3[8];
-    VecIO<float, 8>::load(s_cf + cg * 8, q1);
-    VecIO<float, 8>::load(s_cf + 16 + cg * 8, q2);
-    VecIO<float, 8>::load(s_cf + 32 + cg * 8, q3);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const pair_t gq = X::pair(pg_, q), yq = X::pair(py_, q);
-      const float a0 = q1[2 * q] * X::lo(gq) + (q2[2 * q] * X::lo(yq) + q3[2 * q]);
-      const float a1 = q1[2 * q + 1] * X::hi(gq) + (q2[2 * q + 1] * X::hi(yq) + q3[2 * q + 1]);
-      d[q * g.plane] = ok ? f32x2{a0, a1} : f32x2{0.f, 0.f};
-    }
-  };
-  auto commit = [&](int base) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (sl.pp[i] >= 0) {
-        int slot = (g.ring ? 2 * P : P) + sl.rr[i] + base;
-        if (slot >= g.LH) slot -= g.LH;
-        put_dy(pfg[i], pfy[i], (pfmask >> i) & 1u, s_dy + (cgl * 4) * g.plane + sl.dyo[i] + slot * g.LWp);
-      }
-    }
-    // MFMA stage: raw expand output of the tile's pixels for the 16 channels of the slab; the lanes that hold this workgroup's
-    // half (channels 4 mq .. 4 mq + 3 with mq >> 1 == half) write their two channel pairs
-    int mj = mj_, mq = mq_;
-    asm volatile("" : "+v"(mj), "+v"(mq));
-#pragma unroll
-    for (int gi = 0; gi < GPW; ++gi) {
-      if ((gi * 4 + wv) * 16 < g.TPIX) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], bfr[gi][kc], acc, 0, 0, 0);
-        const int pp = (gi * 4 + wv) * 16 + mj;
-        if ((mq >> 1) == half && pp < g.TPIX) {
-          f32x2* d = s_xe + (2 * (mq & 1)) * g.TPIXp + pp;
-          d[0] = f32x2{acc[0], acc[1]};
-          d[g.TPIXp] = f32x2{acc[2], acc[3]};
-        }
-      }
-    }
-  };
-  // first tile of an image (or of this worker): the 2P window rows above the tile's own rows, loaded synchronously
-  auto halo_sync = [&](int n0, int hi0) {
-    const int npc = 2 * P * g.W * CGS;
-    for (int p = tid; p < npc; p += NT) {
-      const int col = (p / CGS) % g.W, wr = (p / CGS) / g.W;
-      const int ho = hi0 - P + wr;
-      piece_t a, b;
-      X::zero(a); X::zero(b);
-      const bool ok = cg_ok && ho >= 0 && ho < g.H && n0 < g.N;
-      if (ok) {
-        const long off = (((long)n0 * g.H + ho) * g.W + col) * 16 + cg * 8;
-        X::load(a, gup + slab_g + off);
-        if (yraw) X::load(b, yraw + slab_y + off);
-      }
-      put_dy(a, b, ok, s_dy + (cgl * 4) * g.plane + wr * g.LWp + col + P);
-    }
-  };
-  auto store_h = [&](int n0, int hi0) {
-    const long px = ((long)n0 * g.H + hi0) * g.W * 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N && hi0 + sl.rr[i] < g.H) {
-        piece_t v;
-        const pair_t* sx_ = s_x + (cgl * 4) * g.TPIXp + sl.pp[i];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) X::set_pair(v, q, sx_[q * g.TPIXp]);
-        X::store(v, h + slab_h + px + sl.goff[i]);
-      }
-    }
-  };
-
-  int tile = t_beg;
-  int nb = tile / g.tiles_y, ty = tile % g.tiles_y;
-  if (tile < t_end) { issue(nb * g.NI, ty * g.TH); issue_b(nb * g.NI, ty * g.TH); }
-  int base = 0;
-  int pn0 = -1, phi0 = 0;   // tile whose result waits in s_x
-#if CW_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_readcyclecounter();
-#endif
-  for (; tile < t_end; ++tile) {
-    const int n0 = nb * g.NI, hi0 = ty * g.TH;
-    const bool fresh = g.ring && (tile == t_beg || ty == 0);
-    if (fresh) base = 0;
-    CWMARK(6)
-    // opaque per tile: the 64-bit global addresses of the slots are formed where they are used.  (Hoisted out of the tile loop they
-    // are spilled, and every reload waits for vmcnt(0), i.e. for all loads and stores issued before it: the prefetch serialises.)
-    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]), "+v"(sl.pp[0]), "+v"(sl.pp[1]), "+v"(sl.dyo[0]), "+v"(sl.dyo[1]));
-    __syncthreads();   // (A) previous tile consumed, its h complete in s_x (first pass: also orders the LDS initialisation)
-    CWMARK(0)
-    // every prefetched register is consumed here on every path: nothing is pending when the next tile's loads overwrite them
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { X::touch(pfg[i]); X::touch(pfy[i]); }
-#pragma unroll
-    for (int gi = 0; gi < GPW; ++gi)
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(bfr[gi][kc]));
-    if (pn0 >= 0) store_h(pn0, phi0);
-    commit(base);
-    if (fresh) halo_sync(n0, hi0);
-    CWMARK(1)
-    __syncthreads();   // (B) window and pixel planes complete
-    CWMARK(2)
-    int nnb = nb, nty = ty + 1;
-    if (nty == g.tiles_y) { nty = 0; ++nnb; }
-    if (tile + 1 < t_end) {
-      issue(nnb * g.NI, nty * g.TH);
-      if (!LATEB) issue_b(nnb * g.NI, nty * g.TH);
-    }
-    CWMARK(3)
-
-    // opaque per tile: the k^2 tap offsets are formed in their tap rows instead of being hoisted out of the tile loop (they spill)
-    asm volatile("" : "+s"(ld4));
-    if (it_ok && n0 + it_im < g.N && hi0 + it_r < g.H && ch < cpad) {
-      pair_t* xp = s_x + wv * g.TPIXp + pix0;
-      const f32x2* ep = s_xe + wv * g.TPIXp + pix0;
-      f32x2 xq[SW];
-      f32x2 xa[SW], dx[SW];
-#pragma unroll
-      for (int t = 0; t < SW; ++t) xq[t] = ep[t];
-#pragma unroll
-      for (int t = 0; t < SW; ++t) {
-        xa[t] = f32x2{cw_act(xq[t][0] * sc0 + sh0, in_relu, AM), cw_act(xq[t][1] * sc1 + sh1, in_relu, AM)};
-        dx[t] = f32x2{0.f, 0.f};
-        asm volatile("" : "+v"(xa[t]));   // computed here, not sunk behind the tap rows (that keeps every operand row alive)
-      }
-      asm volatile("" ::: "memory");
-      // tap rows.  PF (k = 7, where the registers allow two waves per SIMD anyway): the operands of row ky + 1 are in flight while
-      // row ky is multiplied -- two operand buffers, static indices after unrolling.
-      f32x2 dyb[PF ? 2 : 1][DWN], wb[PF ? 2 : 1][K];
-      auto row_addr = [&](int ky) {
-        int slot = it_r + (K - 1 - ky) + base;
-        if (slot >= g.LH) slot -= g.LH;
-        return dy_addr0 + (unsigned)(slot * g.LWp) * 8u;
-      };
-      if (PF) cw_row_issue<K, DWN>(wb[0], dyb[0], wp, 0u, ld4, row_addr(0));
-#pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        constexpr int dummy = 0; (void)dummy;
-        const int cur = PF ? (ky & 1) : 0;
-        if (!PF) cw_row_issue<K, DWN>(wb[0], dyb[0], wp, (unsigned)(ky * K) * ld4, ld4, row_addr(ky));
-        cw_row_wait();
-        if (PF && ky + 1 < K) {
-          cw_row_issue<K, DWN>(wb[cur ^ 1], dyb[cur ^ 1], wp, (unsigned)((ky + 1) * K) * ld4, ld4, row_addr(ky + 1));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-          for (int t = 0; t < SW; ++t) {
-            dx[t] += dyb[cur][t + (K - 1 - kx)] * wb[cur][kx];
-            dwa[ky * K + kx] += xa[t] * dyb[cur][t + (K - 1 - kx)];
-          }
-          asm volatile("" : "+v"(dwa[ky * K + kx]));   // this row's FMAs are done before the next row's operands are touched
-        }
-#pragma unroll
-        for (int t = 0; t < SW; ++t) asm volatile("" : "+v"(dx[t]));
-        __builtin_amdgcn_sched_barrier(0);   // one / two operand rows live at a time (the tap loop is unrolled for static dwa indices)
-      }
-      // epilogue: activation backward of the producer, rounding, statistics; h goes to its own plane
-#pragma unroll
-      for (int t = 0; t < SW; ++t) xq[t] = ep[t];   // read again: the raw values are not kept in registers across the tap rows
-#pragma unroll
-      for (int t = 0; t < SW; ++t) {
-        const float x0 = xq[t][0], x1 = xq[t][1];
-        float v0 = cw_act_bwd(dx[t][0], x0 * sc0 + sh0, in_relu, AM);
-        float v1 = cw_act_bwd(dx[t][1], x1 * sc1 + sh1, in_relu, AM);
-        v0 = ch0_ok ? v0 : 0.f;
-        v1 = ch1_ok ? v1 : 0.f;
-        const pair_t o = X::pack(v0, v1);
-        v0 = X::lo(o); v1 = X::hi(o);   // statistics of the stored (rounded) values
-        s0a += v0; s0b += v1;
-        s1a += v0 * x0; s1b += v1 * x1;
-        xp[t] = o;
-      }
-    }
-    CWMARK(4)
-    // unconditional (the last tile fetches its own pixels again): under a branch the old fragments would stay live across the tap rows
-    if (LATEB) { const bool more = tile + 1 < t_end; issue_b(more ? nnb * g.NI : n0, more ? nty * g.TH : hi0); }
-    pn0 = n0; phi0 = hi0;
-    nb = nnb; ty = nty;
-    if (g.ring) { base += g.TH; if (base >= g.LH) base -= g.LH; }
-  }
-  __syncthreads();
-  if (pn0 >= 0) store_h(pn0, phi0);
-  CWMARK(5)
-
-  // Weight-gradient flush.  All 64 lanes of a wave hold partial sums of the SAME 2 k^2 values (tap t of channel e = value e k^2 + t,
-  // which is also its position in this wave's 2 k^2 consecutive floats of the partial row).  Cross-lane sums with 6 DPP steps per
-  // value are ~1300 instructions of straight-line code that run once -- measured 30-45 us per launch, mostly instruction-cache
-  // misses.  Instead: the wave transposes G = 14 values at a time through its own (now unused) operand plane -- lane l writes
-  // row l of a [64][G + 1] matrix -- and lane q * G + v adds quarter q (16 lanes, in lane order) of value v; the four quarters are
-  // added in order by lane v, which stores the total.  Fixed order, coalesced stores, a few hundred instructions.
-  {
-    constexpr int G = 14, NV = 2 * KK;
-    float* red = reinterpret_cast<float*>(s_dy + wv * g.plane);   // 64 * (G + 1) + 4 * G floats <= 2 * plane (cw_geometry)
-    float* red2 = red + 64 * (G + 1);
-    float* drow = dwp ? dwp + ((long)worker * g.C + ch) * KK : nullptr;
-    const int nvalid = ch1_ok ? NV : (ch0_ok ? KK : 0);
-    const int rq = lane / G, rv = lane - rq * G;   // quarter and value of this lane in the column sums (lanes 0 .. 4G-1)
-#pragma unroll
-    for (int r0 = 0; r0 < NV; r0 += G) {
-#pragma unroll
-      for (int v = 0; v < G; ++v)
-        if (r0 + v < NV) red[lane * (G + 1) + v] = (r0 + v < KK) ? dwa[(r0 + v) % KK][0] : dwa[(r0 + v) % KK][1];
-      __builtin_amdgcn_wave_barrier();
-      float part = 0.f;
-      if (lane < 4 * G) {
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) part += red[(rq * 16 + i) * (G + 1) + rv];
-        red2[lane] = part;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < G && drow && r0 + lane < nvalid) drow[r0 + lane] = ((red2[lane] + red2[G + lane]) + red2[2 * G + lane]) + red2[3 * G + lane];
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  // BN-backward statistics of the pair: 4 values, DPP sums (fixed order), lane 63 owns row `worker` of the partial buffer
-  s0a = cw_wave_sum63(s0a); s0b = cw_wave_sum63(s0b); s1a = cw_wave_sum63(s1a); s1b = cw_wave_sum63(s1b);
-  if (lane == 63 && stats) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int c = ch + e;
-      if (c < g.C) {
-        const float v0 = e ? s0b : s0a, v1 = e ? s1b : s1a;
-        float* r = stats + (long)worker * 2 * stat_ld;
-        r[c] = v0;
-        r[stat_ld + c] = v1;
-        stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, c);
-        stat_zero_tail(stats, 2L * stat_ld, worker + g.nworkers, g.nworkers, stat_rows, (long)stat_ld + c);
-      }
-    }
-  }
-#if CW_TIMING
-  CWMARK(7)
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_cw_timing[i], tacc[i]);
-  }
-#endif
-}
-
-#endif   // ATOMNAS_EXPERIMENTAL_XDW
 
 // ------------------------------------------------------------------------------------------------------- backward, stride 2
 // Stride-2 depthwise backward in the same form.  The lanes live on the dY grid (Ho x Wo = H/2 x W/2): a lane owns 7 dY columns of
@@ -900,7 +350,6 @@ __global__ __launch_bounds__(256, WPS) void k_xdwb(const bf16_t* __restrict__ gu
 // no lane is masked (the tile kernels lose half of the lanes of every tap row of a stride-2 layer).  The window holds dYraw exactly as
 // in k_dwb_cw (ring over dY rows, HL kept rows); the input tile is 4x the dY tile (2 THd x W pixels, contiguous in HBM because the
 // tile spans the full width), staged through 7 register slots per thread that need no per-slot state.
-constexpr __host__ __device__ int cw_fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 template <typename T, int K, int AM, int NW, int WPS>
 __global__ __launch_bounds__(NW * 64, WPS) void k_dwb_cw2(const T* __restrict__ gup, long gss, const T* __restrict__ yraw, long yrss,
@@ -1410,117 +859,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_dwf_cw(const T* __restrict__ x
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- host side
-static bool cw_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
-  if (W % 7 != 0 || W < 7) return false;
-  g.N = N; g.H = H; g.W = W; g.C = C;
-  g.ns = W / 7;
-  if (g.ns > 16) return false;
-  if (H * g.ns <= 64) {   // whole images
-    g.TH = H; g.tiles_y = 1; g.NI = 64 / (H * g.ns); g.ring = 0;
-    if (g.NI > N) g.NI = N;
-  } else {
-    const int cap = 64 / g.ns;
-    const int nty = (H + cap - 1) / cap;
-    g.TH = (H + nty - 1) / nty;
-    g.tiles_y = (H + g.TH - 1) / g.TH;
-    g.NI = 1; g.ring = 1;
-  }
-  g.LH = g.TH + K - 1;
-  // row pitch: the 32 lanes of an LDS group are (rows x strips); their first elements r * LWp + 7 * j must differ mod 32 (8-byte
-  // bank pairs): LWp = ns (mod 2 ns) for ns a power of two does it (7 is invertible mod 32), an odd pitch otherwise
-  const int lw = W + K - 1;
-  const bool pow2 = (g.ns & (g.ns - 1)) == 0;
-  int lwp = lw;
-  if (pow2) { while (lwp % (2 * g.ns) != g.ns) ++lwp; } else if (lwp % 2 == 0) ++lwp;
-  g.LWp = lwp;
-  g.RH = g.LH;
-  int plane = g.NI * g.RH * g.LWp;
-  if (plane < 512) plane = 512;      // the weight-gradient flush transposes 64 x 15 + 56 floats through a wave's own plane
-  while (plane % 4 != 2) ++plane;     // staging writes of the two channel groups land in different bank halves
-  g.plane = plane;
-  g.TPIX = g.NI * g.TH * W;
-  int tp = g.TPIX;
-  while (tp % 8 != 4) ++tp;
-  g.TPIXp = tp;
-  g.ntiles = ((N + g.NI - 1) / g.NI) * g.tiles_y;
-  g.nslabs = (C + 15) / 16;
-  return true;
-}
-
-// stride 2: the lane grid is the output grid; K decides the halo rows / columns of the window
-static bool cw2_geometry(CwGeom& g, int N, int H, int W, int C, int K) {
-  if (H % 2 || W % 14 != 0 || W < 14) return false;
-  const int P = (K - 1) / 2;
-  const int RELMIN = cw_fdiv(-P, 2), RELMAX = cw_fdiv(13 + P, 2), CL = -RELMIN, CR = RELMAX - 6;
-  const int HL = P / 2 + cw_fdiv(P - 1, 2) + 1;
-  g.N = N; g.H = H; g.W = W; g.C = C;
-  g.Ho = H / 2; g.Wo = W / 2;
-  g.ns = g.Wo / 7;
-  if (g.ns > 16) return false;
-  if (g.Ho * g.ns <= 64) {   // whole images
-    g.THd = g.Ho; g.tiles_y = 1; g.NI = 64 / (g.Ho * g.ns); g.ring = 0;
-    if (g.NI > N) g.NI = N;
-  } else {
-    const int cap = 64 / g.ns;
-    const int nty = (g.Ho + cap - 1) / cap;
-    g.THd = (g.Ho + nty - 1) / nty;
-    g.tiles_y = (g.Ho + g.THd - 1) / g.THd;
-    g.NI = 1; g.ring = 1;
-  }
-  g.TH = 2 * g.THd;
-  g.LH = g.THd + HL;
-  const int lw = g.Wo + CL + CR;
-  const bool pow2 = (g.ns & (g.ns - 1)) == 0;
-  int lwp = lw;
-  if (pow2) { while (lwp % (2 * g.ns) != g.ns) ++lwp; } else if (lwp % 2 == 0) ++lwp;
-  g.LWp = lwp;
-  g.RH = g.LH;
-  int plane = g.NI * g.RH * g.LWp + 4;   // + slack: a half strip reads a fixed number of operand pairs, up to 2 past its last one
-  if (plane < 512) plane = 512;
-  while (plane % 4 != 2) ++plane;
-  g.plane = plane;
-  g.TPIX = g.NI * g.TH * W;
-  g.TPIXD = g.NI * g.THd * g.Wo;
-  int tp = g.TPIX;
-  while (tp % 8 != 4) ++tp;
-  g.TPIXp = tp;
-  g.ntiles = ((N + g.NI - 1) / g.NI) * g.tiles_y;
-  g.nslabs = (C + 15) / 16;
-  return true;
-}
-
-static void cw_workers(CwGeom& g, int per_cu, int max_rows, int nw) {
-  if (per_cu < 1) per_cu = 1;
-  const int units = g.nslabs * (nw == 4 ? 2 : 1);   // workgroups per worker
-  // experiment switch: this launch is one of `share` concurrent ones (the branches of a block on separate streams): 1 / share of the slots
-  static const int share = getenv("ATOMNAS_DW_SHARE") ? atoi(getenv("ATOMNAS_DW_SHARE")) : 1;
-  long want = ((long)num_cus() * per_cu) / units / (share > 1 ? share : 1);
-  static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: long tile walks
-  if (max_env > 0 && want > max_env) want = max_env;
-  if (max_rows > 0 && want > max_rows) want = max_rows;   // every worker owns one partial row
-  if (want > g.ntiles) want = g.ntiles;
-  if (want < 1) want = 1;
-  g.nworkers = (int)want;
-}
-static unsigned cw_grid(const CwGeom& g, int nw) {
-  const unsigned u = (unsigned)g.nworkers * g.nslabs;
-  return nw == 4 ? (u + 7) / 8 * 16 : u;   // half-slab workgroups: 8 (slab, worker) units -> 16 blocks, see cw_block
-}
-
-static int cw_mode() {
-  // bit 0: backward, bit 1: forward (stride 1); bit 2: backward stride 2, bit 3: forward stride 2
-  static const int m = getenv("ATOMNAS_DW_CW") ? atoi(getenv("ATOMNAS_DW_CW")) : 7;
-  return m;
-}
-static int cw_nw() {
-  static const int m = getenv("ATOMNAS_DW_CW_NW") ? atoi(getenv("ATOMNAS_DW_CW_NW")) : 4;   // waves per workgroup: 8 (whole slab) or 4 (half)
-  return m == 8 ? 8 : 4;
-}
-template <typename T> static size_t cw_lds(const CwGeom& g, int nw) {
-  typedef typename Cw<T>::pair_t pair_t;
-  return (size_t)nw * g.plane * sizeof(f32x2) + (size_t)nw * g.TPIXp * sizeof(pair_t) + 48 * sizeof(float);
-}
 
 template <typename T, int K>
 static int cw_launch_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
@@ -1597,54 +935,6 @@ static int cw2_launch_bwd(const void* gup, long gss, const void* yraw, long yrss
   return 0;
 }
 
-#ifdef ATOMNAS_EXPERIMENTAL_XDW
-template <int K, int KC>
-static int xdw_launch_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,
-                          const void* xin, int ldx, int inp, const void* wexp, int ldwe, const float* sc, const float* sh, int relu,
-                          const float* w, int ldw, void* h, long hss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws,
-                          int N, int H, int W, int C, hipStream_t st) {
-  CwGeom g;
-  if (!cw_geometry(g, N, H, W, C, K)) return -1;
-  const size_t lds = (size_t)4 * g.plane * sizeof(f32x2) + (size_t)4 * g.TPIXp * (sizeof(f32x2) + sizeof(unsigned)) + 48 * sizeof(float);
-  if (lds > max_lds_bytes()) return -1;
-  constexpr int WPSV = (K == 3 && KC == 1) ? 3 : 2;
-#define XDW_BWD(AMV)                                                                                                          \
-  {                                                                                                                           \
-    auto kern = k_xdwb<K, AMV, KC, WPSV, (K == 7)>;                                                                           \
-    cw_workers(g, resident_per_cu(kern, 256, lds), (stats || dw) ? part_rows : 0, 4);                                         \
-    hipLaunchKernelGGL(kern, dim3((unsigned)(((g.nworkers * g.nslabs + 7) / 8) * 16)), dim3(256), lds, st, (const bf16_t*)gup, gss, (const bf16_t*)yraw, yrss, c1, c2, c3, \
-                       (const bf16_t*)xin, ldx, inp, (const bf16_t*)wexp, ldwe, sc, sh, relu, w, ldw, (bf16_t*)h, hss,       \
-                       dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g);                                                   \
-  }
-  if (relu == ACT_RELU6) XDW_BWD(ACT_RELU6) else if (relu == ACT_SWISH) XDW_BWD(ACT_SWISH) else XDW_BWD(0)
-#undef XDW_BWD
-  if (int rc = check_launch("xdw_bwd")) return rc;
-  if (dw) return reduce_parts(dw_ws, (long)C * K * K, g.nworkers, (long)C * K * K, dw, C * K * K, 0, 1, st);
-  return 0;
-}
-
-// the fused expand + depthwise backward (xdw.hip's entry point atomnas_xdw_bwd): -1 when the shape has no instance
-int xdw_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3, const void* xin,
-               int ldx, int inp, const void* wexp, int ldwe, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h,
-               long hss, float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k,
-               hipStream_t st) {
-  if (gss == 0 || hss == 0 || (yraw && yrss == 0) || ldw < ((C + 7) & ~7) || C % 16 || inp > 64) return -1;
-  const int kc = (inp + 31) / 32;
-#define XDW_B(KV, KCV) \
-  if (k == KV && kc == KCV) return xdw_launch_bwd<KV, KCV>(gup, gss, yraw, yrss, c1, c2, c3, xin, ldx, inp, wexp, ldwe, sc, sh, relu, w, ldw, h, hss, dw, stats, stat_ld, part_rows, dw_ws, N, H, W, C, st);
-  XDW_B(3, 1) XDW_B(5, 1) XDW_B(7, 1) XDW_B(3, 2) XDW_B(5, 2) XDW_B(7, 2)
-#undef XDW_B
-  return -1;
-}
-// 1 when xdw_cw_bwd has an instance for the shape
-int xdw_cw_bwd_supported(int N, int H, int W, int C, int k) {
-  CwGeom g;
-  if (!(k == 3 || k == 5 || k == 7) || C % 16 || !cw_geometry(g, N, H, W, C, k)) return 0;
-  const size_t lds = (size_t)4 * g.plane * sizeof(f32x2) + (size_t)4 * g.TPIXp * (sizeof(f32x2) + sizeof(unsigned)) + 48 * sizeof(float);
-  return lds <= max_lds_bytes() ? 1 : 0;
-}
-
-#endif   // ATOMNAS_EXPERIMENTAL_XDW
 
 // -1: not one of this file's cases (the caller continues with the tile kernels of dwconv.hip); otherwise the launch status
 int dwconv_cw_bwd(const void* gup, long gss, const void* yraw, long yrss, const float* c1, const float* c2, const float* c3,

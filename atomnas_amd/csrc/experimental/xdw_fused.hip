@@ -20,6 +20,7 @@
 // Numerics: E is never rounded to the storage type (it used to be stored as bf16); everything else as in dwconv_cw.hip.
 // No atomics; all reductions in a fixed order.
 #include "../common.h"
+#include "xdw_internal.h"
 #include <cstdio>
 #include <cstdlib>
 

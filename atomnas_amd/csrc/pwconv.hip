@@ -702,6 +702,9 @@ enum { ST_FWD = 1, ST_MASK = 2, ST_PBWD = 3 };
 #ifndef ST_SHARED
 #define ST_SHARED 1
 #endif
+#ifndef ST_STORE_SOFFSET
+#define ST_STORE_SOFFSET 0   // experiment builds: 1 = the tile offset of the output stores in an SGPR soffset (round 3/4 form)
+#endif
 #ifndef ST_BT6
 #define ST_BT6 4   // six k-steps (K = 192): bursts only in the shared form (one tile is already a 6 KB request: per-tile ring otherwise)
 #endif
@@ -915,7 +918,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       // tile).  HAZARD: with an SGPR soffset LLVM does not keep the next VALU instructions off the store's data registers (its rule
       // exempts that form), but on gfx950 data overwritten in the two instructions after the store IS what gets written (r03: 0.17 %
       // wrong elements in test_gemm_nt[20000-1440-80]).  The asm below uses `ob` after the statistics: its registers stay intact.
+#if ST_STORE_SOFFSET
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rc, rv ? c_lane[h] : ST_OOB, (unsigned)t * c_tile, 0);
+#else
+      // round 5: the tile offset is added to the vector offset (soffset 0).  With the scalar offset the hazard above is NOT bounded by
+      // two instructions: at M = 12544, N = 3456, K = 192 (the 7x7 expand, store queue backed up) the first data dword of a store was
+      // replaced by a value written to that register ~28 instructions later (the next store's offset), 4 lanes at a time, ~4000 of 43 M
+      // outputs per launch, different ones in every run (tools/gemmcheck.py, profiles/r05_st_store_hazard.txt).
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rc, rv ? c_lane[h] + (unsigned)t * c_tile : ST_OOB, 0, 0);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x2 o = f32x2{(float)ob[2 * i], (float)ob[2 * i + 1]};   // statistics see the stored value

@@ -367,6 +367,60 @@ def test_dwconv_bwd_cw(gpu_lib, dtype, k, stride, N, C, H, W):
         assert_close("sum_hx", stats[1], (h * rounded(x, dtype)).sum((0, 2, 3)), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("H,C,k", [(56, 144, 7), (28, 240, 5), (14, 480, 3), (14, 576, 7), (7, 1152, 3), (7, 1152, 5), (7, 1152, 7)])
+def test_dwconv_bench_shapes_against_torch(gpu_lib, H, C, k):
+    """The depthwise entry points at the bench's own sizes (batch 256: several tiles per worker, partial last tiles -- the small cases
+    above give every worker one tile), bf16 slab-major tensors, against torch's convolution in fp32 on the GPU: forward output and
+    statistics, input gradient, weight gradient, backward statistics.  bf16 shapes of stride 1 run csrc/dwconv_mm.hip (tap arithmetic
+    on the matrix cores: fp16 operands forward, bf16 operands backward), so the bounds are those of one bf16 output rounding plus the
+    operand roundings stated there."""
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    N, s = 256, 1
+    P = (k - 1) // 2
+    g = torch.Generator(device="cuda").manual_seed(H * 1000 + C + k)
+    rn = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    x2 = rn(N * H * H, C).bfloat16()
+    g2 = (rn(N * H * H, C) * 1e-3).bfloat16()
+    w = rn(C, 1, k, k) * 0.3
+    tp = w.reshape(C, k * k).t().contiguous()
+    sc, sh = torch.rand(C, device="cuda", generator=g) + 0.5, rn(C) * 0.3
+    c1, c2, c3 = torch.rand(C, device="cuda", generator=g) + 0.5, rn(C) * 0.1, rn(C) * 1e-4
+    rows = ops.stat_rows_for(C)
+    nchw = lambda sl: sl.to_plain()[:, :C].float().reshape(N, H, H, C).permute(0, 3, 1, 2)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    xs, gs = Slab.from_plain(x2), Slab.from_plain(g2)
+    ys = Slab(N * H * H, C, torch.bfloat16, "cuda")
+    ys.t.fill_(float("nan"))
+    st = torch.full((rows, 2, C), float("nan"), device="cuda")
+    ops.dwconv_fwd(xs, sc, sh, True, tp, ys, st, C, N, H, H, C, k, s, stat_rows=rows)
+    x4 = x2.float().reshape(N, H, H, C).permute(0, 3, 1, 2).requires_grad_(True)
+    xa = torch.relu(x4 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    xa.retain_grad()
+    wr = w.clone().requires_grad_(True)
+    yref = F.conv2d(xa, wr, None, s, P, 1, C)
+    y = nchw(ys)
+    assert torch.isfinite(y).all()
+    assert rel(y, yref.detach()) < 2.5e-3          # one bf16 rounding is 1.7e-3
+    assert float((y - yref.detach()).abs().max()) < 2e-2 * float(yref.abs().max())
+    ssum = st.sum(0)
+    assert torch.allclose(ssum[0], y.sum((0, 2, 3)), rtol=1e-4, atol=1.0) and torch.allclose(ssum[1], (y * y).sum((0, 2, 3)), rtol=1e-4, atol=1.0)
+    dy = c1.view(1, -1, 1, 1) * g2.float().reshape(N, H, H, C).permute(0, 3, 1, 2) + c2.view(1, -1, 1, 1) * y + c3.view(1, -1, 1, 1)
+    (yref * dy).sum().backward()
+    href = xa.grad * (xa.detach() > 0).float()
+    hs = Slab(N * H * H, C, torch.bfloat16, "cuda")
+    hs.t.fill_(float("nan"))
+    dw = torch.zeros(C * k * k, device="cuda")
+    st2 = torch.full((rows, 2, C), float("nan"), device="cuda")
+    ops.dwconv_bwd(gs, ys, c1, c2, c3, xs, sc, sh, True, tp, hs, dw, st2, C, N, H, H, C, k, s, stat_rows=rows)
+    h = nchw(hs)
+    assert torch.isfinite(h).all()
+    assert rel(h, href) < 3.5e-3                   # bf16 output rounding + bf16 rounding of dY (matrix-core operand)
+    assert rel(dw.view(C, k * k), wr.grad.view(C, k * k)) < 1e-3
+    s2 = st2.sum(0)
+    assert rel(s2[0], h.sum((0, 2, 3))) < 1e-4 and rel(s2[1], (h * x4.detach()).sum((0, 2, 3))) < 1e-4
+
+
 def test_dwconv_long_tile_walks():
     """The depthwise kernels keep the halo rows of the tile above in their LDS ring when a workgroup walks down a column of
     tiles.  With the small tensors of the tests every workgroup normally gets a single tile, so the same cases are re-run
@@ -556,6 +610,38 @@ def test_gemm_nt_streaming_kernel(gpu_lib, M, N, K, act):
         for form in ("fwd", "mask"):
             assert torch.equal(outs[(False, form)][0], outs[(True, form)][0])
             assert torch.equal(outs[(False, form)][1], outs[(True, form)][1])
+
+
+@pytest.mark.parametrize("M,N,K", [(12544, 3456, 192), (12544, 1728, 192), (50176, 1728, 96)])
+def test_gemm_nt_streaming_kernel_bench_shapes_repeated(gpu_lib, M, N, K):
+    """The expand forward of the late stages at the bench's own sizes (bs 256: 7x7 -> M = 12544, K = 192; 14x14 -> M = 50176), every
+    element against an fp32 matmul on the GPU, output pre-filled with NaN, repeated launches.  Round 5 found the 7x7 instance writing the
+    NEXT store's byte offset into the first dword of ~4400 of 43 M outputs per launch (a store-data hazard of `buffer_store ... sN offen`
+    under a backed-up store queue, csrc/pwconv.hip k_gemm_nt_st::finish; profiles/r05_st_store_hazard.txt): different elements in every
+    launch, nothing at the small shapes of the other tests."""
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    Wp = torch.zeros((N + 63) // 64 * 64, (K + 31) // 32 * 32, dtype=torch.bfloat16, device="cuda")
+    Wp[:N, :K] = W.bfloat16()
+    ref = A.float() @ Wp[:N, :K].float().t()
+    rows = ops.stat_rows_for(N)
+    for rep in range(4):
+        for slab in (True, False):
+            C = Slab(M, N, torch.bfloat16, "cuda") if slab else torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            (C.t if slab else C).fill_(float("nan"))
+            st = torch.full((rows, 2, N), float("nan"), device="cuda")
+            ops.gemm_nt(A, Wp, C, M, N, K, stats=st, stat_mode=ops.STAT_SQ, stat_rows=rows)
+            torch.cuda.synchronize()
+            Cp = (C.to_plain() if slab else C)[:, :N].float()
+            bad = ~((Cp - ref).abs() <= 1.2e-2 * ref.abs() + 2e-2)
+            assert int(bad.sum()) == 0, "rep %d %s: %d wrong outputs, first rows %s" % (
+                rep, "slab" if slab else "plain", int(bad.sum()), torch.nonzero(bad.any(1)).flatten()[:8].tolist())
+            s = st.sum(0)
+            assert torch.allclose(s[0], Cp.sum(0), rtol=1e-4, atol=1e-2 * M ** 0.5)
+            assert torch.allclose(s[1], (Cp * Cp).sum(0), rtol=1e-4, atol=1e-2 * M ** 0.5)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
