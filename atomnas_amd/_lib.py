@@ -63,9 +63,10 @@ NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version":
              "atomnas_project_bwd_supported": (i32, [i32, i32, i32]),
              "atomnas_project_bwd_dp_supported": (i32, [i64, i32, i32, i32, i32, i64, i32, i64, i32, i32]),
              "atomnas_dwconv_cw_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+             "atomnas_dwconv_mm_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
              "atomnas_se_pool_parts": (i32, [i32, i32, i32])}
 
-ABI_VERSION = 5   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
+ABI_VERSION = 6   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None
 
 

@@ -214,7 +214,7 @@ int dwconv_mm_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
                   const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* h, long hss,
                   float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride,
                   int dtype, hipStream_t st);
-int dwconv_mm_fwd_supported(int N, int H, int W, int C, int k);
+int dwconv_mm_supported(int N, int H, int W, int C, int k, int dir);
 
 #define ATOMNAS_REQUIRE(cond, ...)            \
   do {                                        \

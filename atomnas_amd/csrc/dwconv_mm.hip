@@ -679,8 +679,9 @@ static bool mm_geometry(CwGeom& g, MmGeom& mg, int N, int H, int W, int C, int K
 }
 
 static int mm_mode() {
-  // bits 0-2: forward k = 3 / 5 / 7, bits 3-5: backward k = 3 / 5 / 7
-  static const int m = getenv("ATOMNAS_DW_MM") ? atoi(getenv("ATOMNAS_DW_MM")) : 63;
+  // bits 0-2: forward k = 3 / 5 / 7, bits 3-5: backward k = 3 / 5 / 7.  Default: forward k = 5, 7 (k = 3 is as fast on the packed-FMA rows,
+  // the backward instances are not yet: profiles/r05_dw_mm_*.txt)
+  static const int m = getenv("ATOMNAS_DW_MM") ? atoi(getenv("ATOMNAS_DW_MM")) : 6;
   return m;
 }
 
@@ -756,12 +757,20 @@ int dwconv_mm_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
   return -1;
 }
 
-int dwconv_mm_fwd_supported(int N, int H, int W, int C, int k) {
+int dwconv_mm_supported(int N, int H, int W, int C, int k, int dir) {
   CwGeom g;
   MmGeom mg;
-  const int bit = k == 3 ? 1 : (k == 5 ? 2 : 4);
-  if (!(k == 3 || k == 5 || k == 7) || !(mm_mode() & bit) || !mm_geometry(g, mg, N, H, W, C, k, false)) return 0;
-  return mm_lds(g, mg, k, false) <= max_lds_bytes() ? 1 : 0;
+  if (!(k == 3 || k == 5 || k == 7)) return 0;
+  const int bit = (k == 3 ? 1 : (k == 5 ? 2 : 4)) << (dir ? 3 : 0);
+  if (!(mm_mode() & bit) || !mm_geometry(g, mg, N, H, W, C, k, dir != 0)) return 0;
+  return mm_lds(g, mg, k, dir != 0) <= max_lds_bytes() ? 1 : 0;
 }
 
 }  // namespace atomnas
+
+// 1 when atomnas_dwconv_fwd (dir = 0) / atomnas_dwconv_bwd (dir = 1) take the matrix-core kernels of this file for the shape (bf16
+// slab-major tensors, stride 1).  Tests build the oracle's storage model from it (oracle/atomnas_oracle.py bf16_storage_mm).
+extern "C" int atomnas_dwconv_mm_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir) {
+  if (stride != 1 || dtype != atomnas::DT_BF16) return 0;
+  return atomnas::dwconv_mm_supported(N, H, W, C, k, dir);
+}

@@ -495,6 +495,73 @@ def run_block(pl, x, anchor):
     return to_4d(out, N, (H - 1) // s + 1, (W - 1) // s + 1, pl.oup)
 
 
+# ---------------------------------------------------------------------------------------------- stand-alone SqueezeAndExcitation
+class SEFunction(torch.autograd.Function):
+    """SqueezeAndExcitation.forward (models/mobilenet_base.py:109-112) as a module call of its own: sigmoid(W2 act(W1 mean(x) + b1) + b2) * x
+    with the SE entry points the fused block uses (squeeze -> dense layers -> scale; backward: gate gradient + dense-layer gradients,
+    then the gradient wrt x).  Inside InvertedResidualChannelsFused the gate runs in the block's executor on the raw depthwise
+    output; this is the same arithmetic on an already activated tensor (identity BatchNorm coefficients, activation mode 0)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, se_act, dtype):
+        x2d, (N, H, W, C) = to_2d(x, dtype)
+        dev = x.device
+        hid = w1.shape[0]
+        HT = pads(C)
+        M, HW = N * H * W, H * W
+        D = ops.zeros(M, HT, dtype=dtype, device=dev)
+        D[:, :C] = x2d
+        cmap = torch.full((HT,), -1, dtype=torch.int32, device=dev)
+        cmap[:C] = torch.arange(C, dtype=torch.int32, device=dev)
+        w1m, w2m = w1.detach().reshape(hid, C).float(), w2.detach().reshape(C, hid).float()
+        w1p, w2t, b2p = (ops.zeros(hid, HT, dtype=torch.float32, device=dev), ops.zeros(hid, HT, dtype=torch.float32, device=dev),
+                         ops.zeros(HT, dtype=torch.float32, device=dev))
+        w1p[:, :C] = w1m
+        w2t[:, :C] = w2m.t()
+        b2p[:C] = b2.detach().float()
+        one, zero = torch.ones(HT, dtype=torch.float32, device=dev), ops.zeros(HT, dtype=torch.float32, device=dev)
+        one[C:] = 0
+        pooled, gate = _f32(N * HT, dev).view(N, HT), _f32(N * HT, dev).view(N, HT)
+        hpre = _f32(N * hid, dev).view(N, hid)
+        parts = ops.se_pool_parts(N, HW, HT)
+        pparts = _f32(parts * N * HT, dev).view(parts, N, HT)
+        ops.se_squeeze(D, one, zero, ACT_NONE, pparts, N, HW, HT)
+        ops.se_mlp_fwd(pparts, pooled, cmap, w1p, b1.detach().float().contiguous(), w2t, b2p, se_act, hpre, gate, N, HT, hid)
+        S = torch.empty(M, HT, dtype=dtype, device=dev)
+        ops.se_scale(D, one, zero, ACT_NONE, gate, S, M, HW, HT)
+        ctx.save_for_backward(D, one, zero, gate, pooled, cmap, w1p, w2t, hpre)
+        ctx.dims = (N, H, W, C, HT, hid, se_act, dtype)
+        return to_4d(S[:, :C], N, H, W, C)
+
+    @staticmethod
+    def backward(ctx, gout):
+        D, one, zero, gate, pooled, cmap, w1p, w2t, hpre = ctx.saved_tensors
+        N, H, W, C, HT, hid, se_act, dtype = ctx.dims
+        dev = D.device
+        M, HW = N * H * W, H * W
+        g2d, _ = to_2d(gout, dtype)
+        dS = ops.zeros(M, HT, dtype=dtype, device=dev)
+        dS[:, :C] = g2d
+        dz2, dpooled = _f32(N * HT, dev).view(N, HT), _f32(N * HT, dev).view(N, HT)
+        parts = ops.se_pool_parts(N, HW, HT)
+        dgate = _f32(parts * N * HT, dev).view(parts, N, HT)
+        dz1 = _f32(N * hid, dev).view(N, hid)
+        dw1, db1, dw2, db2 = (_f32(hid * C, dev, zero=True), _f32(hid, dev, zero=True), _f32(C * hid, dev, zero=True), _f32(C, dev, zero=True))
+        ops.se_bwd_gate(dS, D, one, zero, ACT_NONE, gate, pooled, cmap, w1p, w2t, hpre, dgate, dz2, dz1, dpooled, dw1, db1, dw2, db2, N, HW, HT, C,
+                        hid, se_act=se_act)
+        g = torch.empty(M, HT, dtype=dtype, device=dev)
+        st = _stats(HT, dev)
+        ops.se_bwd_apply(dS, D, one, zero, ACT_NONE, gate, dpooled, g, st.t, M, HW, HT, stat_rows=st.rows)
+        return (to_4d(g[:, :C], N, H, W, C), dw1.view(hid, C, 1, 1), db1, dw2.view(C, hid, 1, 1), db2, None, None)
+
+
+def run_se(module, x):
+    """stand-alone call of a SqueezeAndExcitation module (NCHW tensor on the GPU, C a multiple of 8)"""
+    dtype = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    return SEFunction.apply(x, module.se_reduce.weight, module.se_reduce.bias, module.se_expand.weight, module.se_expand.bias,
+                            act_code(module.active_fn), dtype)
+
+
 # ---------------------------------------------------------------------------------------------- ConvBNReLU (stem / 1x1 / depthwise)
 def convbn_forward(pl, x, need_grad):
     """Stand-alone ConvBNReLU: stem 3x3/s2 on an NCHW fp32 image (im2col + GEMM), 1x1 conv, or depthwise conv."""

@@ -53,9 +53,10 @@ class HSwish(nn.Module):
 
 
 class SqueezeAndExcitation(nn.Module):
-    """Squeeze-and-excitation gate (models/mobilenet_base.py:93-117).  Parameter container: the gate runs inside the fused block's
-    executor (functional.block_forward: atomnas_se_squeeze / se_mlp_fwd / se_scale), where the activated depthwise output it acts
-    on is re-derived from the raw depthwise output instead of being materialised."""
+    """Squeeze-and-excitation gate (models/mobilenet_base.py:93-117).  Inside InvertedResidualChannelsFused the gate runs in the
+    block's executor (functional.block_forward: atomnas_se_squeeze / se_mlp_fwd / se_scale), where the activated depthwise output it
+    acts on is re-derived from the raw depthwise output instead of being materialised; called on its own it runs the same entry
+    points on its input (functional.SEFunction)."""
 
     def __init__(self, n_feature, n_hidden, spatial_dims=[2, 3], active_fn=None):
         super().__init__()
@@ -65,8 +66,10 @@ class SqueezeAndExcitation(nn.Module):
         self.active_fn = active_fn()
 
     def forward(self, x):
-        raise NotImplementedError('SqueezeAndExcitation runs inside InvertedResidualChannelsFused on the HIP path; a stand-alone call '
-                                  'has no kernel')
+        # stand-alone call (the reference's module API, :109-112); inside InvertedResidualChannelsFused the executor runs the gate
+        if tuple(self.spatial_dims) != (2, 3):
+            raise NotImplementedError('SqueezeAndExcitation on the HIP path squeezes over the spatial dimensions [2, 3]')
+        return AF.run_se(self, x)
 
     def __repr__(self):
         return '{}({}, {}, spatial_dims={}, active_fn={})'.format(self._get_name(), self.n_feature, self.n_hidden,

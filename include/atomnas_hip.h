@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 5   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout */
+#define ATOMNAS_ABI_VERSION 6   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -88,6 +88,12 @@ int atomnas_dwconv_bwd(const void* g, int ldg, long g_ss, const void* yraw, int 
  *   shape with slab-major tensors, 0 when they run the tile kernels (csrc/dwconv.hip); dir: 0 forward, 1 backward.  Same results
  *   either way; a query for tests and launch-geometry tools. */
 int atomnas_dwconv_cw_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir);
+
+/* 1 when they run the matrix-core kernels (csrc/dwconv_mm.hip: bf16, stride 1, slab-major tensors; the tap arithmetic as MFMAs
+ *   against a Toeplitz operand of the taps) for this shape; dir: 0 forward, 1 backward.  Those kernels round the MFMA operands
+ *   (forward: activated input and taps to fp16; backward: the gradient of the raw output, the taps and the activated input to bf16),
+ *   which oracle/atomnas_oracle.py restates where this query says so (bf16_storage_mm). */
+int atomnas_dwconv_mm_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir);
 
 /* ---- pointwise (1x1) convolutions as MFMA GEMMs: models/mobilenet_base.py:316-320 (expand), :338 (project),
  *      models/mobilenet_supernet.py:148-153 (last conv), :160-163 (classifier); branches concatenated (:378).

@@ -64,6 +64,46 @@ class Bf16Storage:
         return _RoundBwd.apply(x)
 
 
+class _DwMatrixCore(torch.autograd.Function):
+    """The depthwise convolution as atomnas_amd/csrc/dwconv_mm.hip computes it in bf16 storage mode (tap arithmetic on the matrix
+    cores), restated: forward operands -- the activated input, clamped to the fp16 range, and the taps -- rounded to fp16, fp32
+    accumulation; backward (where the backward kernel of that file runs): the gradient of the raw output and the taps rounded to bf16
+    for the input gradient, the gradient and the activated input rounded to bf16 for the weight gradient.  The operation itself is
+    the reference's nn.Conv2d(groups = channels) (models/mobilenet_base.py:330-336)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, groups, fwd_mm, bwd_mm):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, groups, bwd_mm)
+        if fwd_mm:
+            x = x.clamp(-65504.0, 65504.0).to(torch.float16).to(x.dtype)
+            w = w.to(torch.float16).to(w.dtype)
+        return F.conv2d(x, w, None, stride, pad, 1, groups)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad, groups, bwd_mm = ctx.cfg
+        r = (lambda t: t.to(torch.bfloat16).to(t.dtype)) if bwd_mm else (lambda t: t)
+        gy = r(gy)
+        gx = torch.nn.grad.conv2d_input(x.shape, r(w), gy, stride, pad, 1, groups)
+        gw = torch.nn.grad.conv2d_weight(r(x), w.shape, gy, stride, pad, 1, groups)
+        return gx, gw, None, None, None, None, None
+
+
+def bf16_storage_mm(pred):
+    """Bf16Storage for a HIP path that runs depthwise convolutions on the matrix cores: pred(k, stride, N, C, H, W, slab) -> (forward
+    kernel is csrc/dwconv_mm.hip's, backward kernel is) -- tests build it from the library's own query atomnas_dwconv_mm_supported."""
+    class Bf16StorageMM(Bf16Storage):
+        @staticmethod
+        def dwconv(x, w, stride, k, slab):
+            fwd_mm, bwd_mm = pred(k, stride, x.shape[0], x.shape[1], x.shape[2], x.shape[3], slab)
+            if not (fwd_mm or bwd_mm):
+                return F.conv2d(x, w, None, stride, (k - 1) // 2, 1, x.shape[1])
+            return _DwMatrixCore.apply(x, w, stride, (k - 1) // 2, x.shape[1], bool(fwd_mm), bool(bwd_mm))
+    return Bf16StorageMM
+
+
 # ------------------------------------------------------------------------------------------------ structure
 def spec_from_model(model):
     """Structure description read from public attributes only (works on the reference's modules and on atomnas_amd's):
@@ -111,11 +151,16 @@ def bn(x, sd, prefix, training, eps, momentum, stats_out=None):
     return y
 
 
-def conv_bn_act(x, sd, prefix, stride, groups, k, training, spec, stats_out, q=NoQuant, dense=True, store_out=True):
+def conv_bn_act(x, sd, prefix, stride, groups, k, training, spec, stats_out, q=NoQuant, dense=True, store_out=True, slab=False):
     """ConvBNReLU (models/mobilenet_base.py:120-142): conv(no bias, pad (k-1)/2) -> BN -> activation.
-    q: storage emulation; dense convs run on MFMA with weights rounded to the storage type, depthwise taps stay fp32."""
+    q: storage emulation; dense convs run on MFMA with weights rounded to the storage type, depthwise taps stay fp32 unless the
+    storage model says the depthwise kernel is a matrix-core one (q.dwconv, bf16_storage_mm).  slab: the input is a hidden tensor of
+    an expanding block (slab-major in the HIP path: the layout the matrix-core depthwise kernels exist for)."""
     w = sd[prefix + '.0.weight']
-    y = F.conv2d(x, q.f(w) if dense else w, None, stride, (k - 1) // 2, 1, groups)
+    if not dense and hasattr(q, 'dwconv'):
+        y = q.dwconv(x, w, stride, k, slab)
+    else:
+        y = F.conv2d(x, q.f(w) if dense else w, None, stride, (k - 1) // 2, 1, groups)
     y = q.f(y)                       # raw conv output is stored
     if dense:
         y = q.b(y)                   # its gradient is rounded before the weight / input gradient GEMMs
@@ -149,7 +194,7 @@ def fused_block_forward(x, sd, blk, training, spec, stats_out=None, q=NoQuant):
         start += h
         # without SE the activated depthwise output is the (rounded) MFMA operand of the projection; with SE the gated tensor is
         outs.append(conv_bn_act(ti, sd, '{}.depth_ops.{}.{}'.format(name, i, j), blk['stride'], h, k, training, spec, stats_out, q,
-                                dense=False, store_out=not blk.get('se')))
+                                dense=False, store_out=not blk.get('se'), slab=bool(blk['expand'])))
     res = torch.cat(outs, 1) if len(outs) != 1 else outs[0]
     if blk.get('se'):
         res = q.b(q.f(se_forward(res, sd, name + '.se_op', spec['act'])))
@@ -177,7 +222,8 @@ def block_forward(x, sd, blk, training, spec, stats_out=None, q=NoQuant):
             t = conv_bn_act(t, sd, p + '.0', 1, 1, 1, training, spec, stats_out, q, dense=True, store_out=False)
             j = 1
         # the activated depthwise output is the (rounded) MFMA operand of the projection
-        t = conv_bn_act(t, sd, '{}.{}'.format(p, j), blk['stride'], h, k, training, spec, stats_out, q, dense=False, store_out=True)
+        t = conv_bn_act(t, sd, '{}.{}'.format(p, j), blk['stride'], h, k, training, spec, stats_out, q, dense=False, store_out=True,
+                        slab=bool(blk['expand']))
         t = F.conv2d(t, q.f(sd['{}.{}.weight'.format(p, j + 1)]))
         outs.append(t)
     tmp = q.b(q.f(sum(outs)))

@@ -95,3 +95,19 @@ def check_digest(name, t, d, rtol=1e-6, atol=0.0):
     s = max(1e-6, float(d["head"].abs().max()), float(d["tail"].abs().max()))
     assert float((f[:4] - d["head"]).abs().max()) <= rtol * 100 * s + 1e-12 + atol, (name, f[:4], d["head"])
     assert float((f[-4:] - d["tail"]).abs().max()) <= rtol * 100 * s + 1e-12 + atol, (name, f[-4:], d["tail"])
+
+
+def bf16_storage():
+    """The oracle's storage model of the bf16 HIP path on THIS library: Bf16Storage, with the depthwise convolutions restated as
+    matrix-core ones (fp16 / bf16 MFMA operands, csrc/dwconv_mm.hip) exactly where the library says it runs those kernels."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import atomnas_oracle as orc
+    from atomnas_amd import _lib
+    lib = _lib.load()
+
+    def pred(k, stride, N, C, H, W, slab):
+        if not slab or os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0") != "0":
+            return False, False
+        return (bool(lib.atomnas_dwconv_mm_supported(N, H, W, C, k, stride, 1, 0)), bool(lib.atomnas_dwconv_mm_supported(N, H, W, C, k, stride, 1, 1)))
+    return orc.bf16_storage_mm(pred)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import atomnas_oracle as orc  # noqa: E402
 
-from kutil import assert_close  # noqa: E402
+from kutil import assert_close, bf16_storage  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -97,7 +97,7 @@ def test_block_forward_backward(gpu_lib, cfg, dtype):
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
     xo = x.double().requires_grad_(True)
     stats = {}
-    q = orc.NoQuant if dtype == torch.float32 else orc.Bf16Storage
+    q = orc.NoQuant if dtype == torch.float32 else bf16_storage()
     ref = orc.block_forward(xo, work, ob, True, spec, stats, q)
     ref.backward(gout.double())
 
@@ -226,7 +226,7 @@ def test_model_forward_backward(gpu_lib, dtype):
 
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
     xin = x.bfloat16().double() if dtype == torch.bfloat16 else x.double()
-    ref_logits = orc.model_forward(xin, work, spec, True, {}, q=orc.NoQuant if dtype == torch.float32 else orc.Bf16Storage)
+    ref_logits = orc.model_forward(xin, work, spec, True, {}, q=orc.NoQuant if dtype == torch.float32 else bf16_storage())
     ref_loss = orc.ce_label_smooth(ref_logits, y, 0.1).mean()
     ref_loss.backward()
     # Bounds from tools/parity_diag.py on this very network (profiles/r03_parity_diag.txt; the kernels are bit-reproducible, so the

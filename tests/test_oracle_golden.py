@@ -243,3 +243,45 @@ def test_resume_from_reference_checkpoint():
         check_digest("buf " + k, opt_state[k]["momentum_buffer"], g["after"]["buf"][k], rtol=5e-4, atol=2e-5)
     for k, dg in g["after"]["ema"].items():
         check_digest("ema " + k, ema[k], dg, rtol=2e-5, atol=1e-6)
+
+
+def test_matrix_core_depthwise_restatement_is_the_plain_convolution_on_rounded_operands():
+    """oracle.bf16_storage_mm (the storage model of csrc/dwconv_mm.hip): with the predicate off it IS Bf16Storage's convolution;
+    with the forward on, the output is the convolution of the fp16-rounded operands and the backward is the plain one (the packed-FMA
+    backward kernel); with both on, the backward uses bf16-rounded gradient / taps / input.  All against hand-written float64."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 9, 9, generator=g, dtype=torch.float64)
+    w = torch.randn(6, 1, 5, 5, generator=g, dtype=torch.float64) * 0.3
+    gy = torch.randn(2, 6, 9, 9, generator=g, dtype=torch.float64)
+    h16 = lambda t: t.to(torch.float16).to(torch.float64)
+    b16 = lambda t: t.to(torch.bfloat16).to(torch.float64)
+
+    def run(pred):
+        q = orc.bf16_storage_mm(pred)
+        xl, wl = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = q.dwconv(xl, wl, 1, 5, True)
+        y.backward(gy)
+        return y.detach(), xl.grad, wl.grad
+
+    def plain(xv, wv, gv):
+        xl, wl = xv.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+        y = F.conv2d(xl, wl, None, 1, 2, 1, 6)
+        y.backward(gv)
+        return y.detach(), xl.grad, wl.grad
+
+    y0, gx0, gw0 = run(lambda *a: (False, False))
+    yp, gxp, gwp = plain(x, w, gy)
+    assert torch.equal(y0, yp) and torch.equal(gx0, gxp) and torch.equal(gw0, gwp)
+    y1, gx1, gw1 = run(lambda *a: (True, False))
+    assert torch.allclose(y1, F.conv2d(h16(x), h16(w), None, 1, 2, 1, 6), rtol=0, atol=1e-12)
+    assert torch.allclose(gx1, gxp, atol=1e-12) and torch.allclose(gw1, gwp, atol=1e-12)
+    assert 0 < float((y1 - yp).abs().max()) < 2e-3 * float(yp.abs().max())       # fp16 operands: 2^-11 relative per product
+    y2, gx2, gw2 = run(lambda *a: (True, True))
+    _, gxr, _ = plain(x, b16(w), b16(gy))
+    _, _, gwr = plain(b16(x), w, b16(gy))
+    assert torch.allclose(gx2, gxr, atol=1e-12) and torch.allclose(gw2, gwr, atol=1e-12)
+    # the predicate sees (k, stride, N, C, H, W, slab)
+    seen = []
+    orc.bf16_storage_mm(lambda *a: (seen.append(a), (False, False))[1]).dwconv(x, w, 1, 5, True)
+    assert seen == [(5, 1, 2, 6, 9, 9, True)]

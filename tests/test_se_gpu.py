@@ -153,3 +153,38 @@ def test_se_forward_backward(gpu_lib, case, dtype):
         ref = p.grad.reshape(-1)
         scale_ = max(1.0, float(ref.abs().max()))
         assert_close(name, got.double().cpu() - b.double(), ref, 1e-3, 2e-5 * scale_ * (N * HW) ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,hid,act", [(3, 40, 7, 12, "Swish"), (2, 24, 14, 8, "ReLU")])
+def test_se_module_stand_alone(gpu_lib, dtype, N, C, H, hid, act):
+    """SqueezeAndExcitation called as a module of its own (the reference's API, models/mobilenet_base.py:109-112): output, input
+    gradient and the gradients of both dense layers against the reference's formula in float64."""
+    from atomnas_amd.models import mobilenet_base as mb
+    fn = mb.Swish if act == "Swish" else torch.nn.ReLU
+    se = mb.SqueezeAndExcitation(C, hid, active_fn=fn)
+    g = torch.Generator().manual_seed(C + H)
+    with torch.no_grad():
+        for p in se.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.1))
+    x = torch.randn(N, C, H, H, generator=g).to(dtype)
+    gout = torch.randn(N, C, H, H, generator=g).to(dtype)
+    # float64 reference with the module's own parameters
+    xr = x.double().requires_grad_(True)
+    pr = [p.detach().double().requires_grad_(True) for p in (se.se_reduce.weight, se.se_reduce.bias, se.se_expand.weight, se.se_expand.bias)]
+    t = xr.mean([2, 3], keepdim=True)
+    t = F.conv2d(t, pr[0], pr[1])
+    t = t * torch.sigmoid(t) if act == "Swish" else F.relu(t)
+    ref = torch.sigmoid(F.conv2d(t, pr[2], pr[3])) * xr
+    ref.backward(gout.double())
+    se.cuda()
+    xg = x.cuda().requires_grad_(True)
+    out = se(xg)
+    assert out.shape == x.shape and out.dtype == dtype
+    out.backward(gout.cuda())
+    torch.cuda.synchronize()
+    rt, at = (2e-2, 2e-2) if dtype == torch.bfloat16 else (1e-4, 1e-5)
+    assert_close("out", out, ref.detach(), rt, at)
+    assert_close("dx", xg.grad, xr.grad, rt, at * max(1.0, float(xr.grad.abs().max())))
+    for name, p, r in zip(("dw1", "db1", "dw2", "db2"), (se.se_reduce.weight, se.se_reduce.bias, se.se_expand.weight, se.se_expand.bias), pr):
+        assert_close(name, p.grad, r.grad, 2e-2 if dtype == torch.bfloat16 else 1e-3, (3e-2 if dtype == torch.bfloat16 else 1e-4) * max(1.0, float(r.grad.abs().max())))

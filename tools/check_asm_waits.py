@@ -9,6 +9,14 @@ scans the gfx950 assembly of a translation unit and reports every instruction th
 
 Per function a forward data-flow over the basic blocks: registers written by an asm load are pending until an `s_waitcnt` with
 lgkmcnt(0), and no instruction outside ASMSTART/ASMEND may name a pending register on any path.
+
+Round 5: the LDS-DMA rings (k_expand_bwd_s, k_gemm_nt_sw, k_gemm_tn3 of pwconv.hip, k_gram_part of xbwd.hip) wait for their copies with
+a COUNTED `s_waitcnt vmcnt(N)`.  That is right only if (check_rings)
+  * every pass of the loop that holds the wait issues the same number CPS of `global_load_lds_dwordx4` copies on every path,
+  * N is a multiple of CPS and exactly N + CPS copies were issued on every path from the kernel entry to that loop (the ring is
+    N / CPS + 1 stages deep when the first wait runs: the oldest stage is what the wait completes),
+  * the compiler put no vector-memory LOAD of its own into that loop (its wait would ignore the copies and, memory operations
+    retiring in order, drain the ring; stores only make the counted wait conservative).
 """
 import os
 import re
@@ -139,11 +147,158 @@ def check(path):
     return findings, nloads
 
 
+def _cfg(ins):
+    """basic blocks of one function: (blocks, successor lists)"""
+    blocks, label_of, cur = [], {}, []
+    for item in ins:
+        ln, t, ia = item
+        if t.endswith(":"):
+            if cur:
+                blocks.append(cur)
+            cur = []
+            label_of[t[:-1]] = len(blocks)
+            continue
+        cur.append(item)
+        op = t.split(" ")[0]
+        if op.startswith("s_cbranch") or op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            blocks.append(cur)
+            cur = []
+    if cur:
+        blocks.append(cur)
+    succ = [[] for _ in blocks]
+    for i, blk in enumerate(blocks):
+        if not blk:
+            if i + 1 < len(blocks):
+                succ[i].append(i + 1)
+            continue
+        t = blk[-1][1]
+        op = t.split(" ")[0]
+        tgt = t.split(" ")[-1] if (op.startswith("s_cbranch") or op == "s_branch") else None
+        if tgt is not None and tgt in label_of and label_of[tgt] < len(blocks):
+            succ[i].append(label_of[tgt])
+        if op not in ("s_branch", "s_endpgm", "s_setpc_b64") and i + 1 < len(blocks):
+            succ[i].append(i + 1)
+    return blocks, succ
+
+
+COPY = "global_load_lds_dwordx4"
+VMEM_LOAD = ("global_load_", "buffer_load_", "flat_load_", "scratch_load_")
+
+
+def check_rings(path):
+    """-> (findings, [description of every ring found])"""
+    findings, rings = [], []
+    for func, ins in functions(path):
+        if not any(ia and t.startswith(COPY) for _, t, ia in ins):
+            continue
+        blocks, succ = _cfg(ins)
+        n = len(blocks)
+        # back edges by depth-first search from the entry (an edge to a block on the search stack)
+        back, state, stack = set(), [0] * n, [(0, 0)]
+        state[0] = 1
+        while stack:
+            i, k = stack[-1]
+            if k < len(succ[i]):
+                stack[-1] = (i, k + 1)
+                j = succ[i][k]
+                if state[j] == 1:
+                    back.add((i, j))
+                elif state[j] == 0:
+                    state[j] = 1
+                    stack.append((j, 0))
+            else:
+                state[i] = 2
+                stack.pop()
+        pred = [[] for _ in range(n)]
+        for i in range(n):
+            for j in succ[i]:
+                pred[j].append(i)
+
+        def natural_loop(latch, header):
+            body, work = {header, latch}, [latch]
+            while work:
+                b = work.pop()
+                if b == header:
+                    continue
+                for q in pred[b]:
+                    if q not in body:
+                        body.add(q)
+                        work.append(q)
+            return body
+        loops = {}
+        for (latch, header) in back:
+            loops.setdefault(header, set()).update(natural_loop(latch, header))
+        copies = [sum(1 for _, t, ia in blk if ia and t.startswith(COPY)) for blk in blocks]
+        # forward DAG (back edges removed): min / max copies on the paths from `src` into (not including) every block
+        order, seen = [], [False] * n
+
+        def topo(i):
+            seen[i] = True
+            for j in succ[i]:
+                if (i, j) not in back and not seen[j]:
+                    topo(j)
+            order.append(i)
+        sys.setrecursionlimit(max(10000, 4 * n))
+        topo(0)
+        order.reverse()
+
+        def path_counts(src, allowed=None):
+            lo, hi = {src: 0}, {src: 0}
+            for i in order:
+                if i not in lo or (allowed is not None and i not in allowed):
+                    continue
+                for j in succ[i]:
+                    if (i, j) in back or (allowed is not None and j not in allowed):
+                        continue
+                    a, b = lo[i] + copies[i], hi[i] + copies[i]
+                    lo[j] = min(lo.get(j, a), a)
+                    hi[j] = max(hi.get(j, b), b)
+            return lo, hi
+        for bi, blk in enumerate(blocks):
+            for ln, t, ia in blk:
+                m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+                if not (ia and m and int(m.group(1)) > 0):
+                    continue
+                N = int(m.group(1))
+                cands = [(len(body), h) for h, body in loops.items() if bi in body]
+                if not cands:
+                    findings.append("%s:%d %s: counted wait vmcnt(%d) outside any loop" % (os.path.basename(path), ln, func, N))
+                    continue
+                _, h = min(cands)
+                body = loops[h]
+                if any(h2 != h and h2 in body and any(copies[b] for b in loops[h2]) for h2 in loops):
+                    findings.append("%s:%d %s: ring copies inside a loop nested in the wait's loop" % (os.path.basename(path), ln, func))
+                    continue
+                lo, hi = path_counts(h, body)
+                latches = [i for (i, j) in back if j == h]
+                per = {(lo[i] + copies[i], hi[i] + copies[i]) for i in latches if i in lo}
+                if len(per) != 1 or next(iter(per))[0] != next(iter(per))[1]:
+                    findings.append("%s:%d %s: copies per pass of the ring loop differ by path: %s" % (os.path.basename(path), ln, func, sorted(per)))
+                    continue
+                cps = next(iter(per))[0]
+                plo, phi = path_counts(0)
+                pro = (plo.get(h), phi.get(h))
+                own = [t2 for b in body for _, t2, ia2 in blocks[b] if not ia2 and t2.split(" ")[0].startswith(VMEM_LOAD)]
+                desc = "%s: wait vmcnt(%d), %d copies per pass, %s copies before the loop" % (func[:60], N, cps, pro[0] if pro[0] == pro[1] else pro)
+                rings.append(desc)
+                if cps == 0 or N % cps != 0 or pro[0] != pro[1] or pro[0] != N + cps:
+                    findings.append("%s:%d ring miscount -- %s (expected N %% CPS == 0 and N + CPS copies before the loop)" % (os.path.basename(path), ln, desc))
+                if own:
+                    findings.append("%s:%d %s: compiler-emitted vector-memory load inside the ring loop: `%s`" % (os.path.basename(path), ln, func, own[0]))
+    return findings, rings
+
+
 if __name__ == "__main__":
     bad = []
     for src in sys.argv[1:]:
-        f, n = check(assemble(os.path.abspath(src)))
+        asm = src if src.endswith(".s") else assemble(os.path.abspath(src))
+        f, n = check(asm)
         print("%s: %d asynchronous asm loads checked, %d findings" % (src, n, len(f)))
+        bad += f
+        f, rings = check_rings(asm)
+        print("%s: %d LDS-DMA rings with counted waits checked, %d findings" % (src, len(rings), len(f)))
+        for r in rings:
+            print("    " + r)
         bad += f
     for b in bad[:20]:
         print(b)

@@ -18,6 +18,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import atomnas_oracle as orc  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from kutil import bf16_storage  # noqa: E402  (Bf16Storage + the matrix-core depthwise restatement where the library runs those kernels)
 
 
 def sd64(model):
@@ -45,7 +47,7 @@ def run_pair(model, x, y, dtype, num_classes, p_drop):
     loss.backward()
     torch.cuda.synchronize()
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
-    q = orc.NoQuant if dtype == torch.float32 else orc.Bf16Storage
+    q = orc.NoQuant if dtype == torch.float32 else bf16_storage()
     xin = x.bfloat16().double() if dtype == torch.bfloat16 else x.double()
     mask = None if keep is None else keep.double().cpu() / (1.0 - p_drop)
     t0 = time.perf_counter()
@@ -68,7 +70,7 @@ def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32)
     spec = orc.spec_from_model(model)
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
     t0 = time.perf_counter()
-    ref_logits, feats = orc.model_forward(x.bfloat16().to(oracle_dtype), work, spec, True, {}, dropout_mask=None, return_features=True, q=orc.Bf16Storage)
+    ref_logits, feats = orc.model_forward(x.bfloat16().to(oracle_dtype), work, spec, True, {}, dropout_mask=None, return_features=True, q=bf16_storage())
     for f in feats:
         f.retain_grad()
     orc.ce_label_smooth(ref_logits, y, 0.1).mean().backward()
