@@ -98,11 +98,36 @@ def _compile(src):
     return obj, True
 
 
-def build_library(verbose=False):
+# sources whose inline-asm loads / counted LDS-DMA waits tools/check_asm_waits.py verifies on the ISA: their device assembly is kept
+# next to the objects (csrc/build/*.s, stamped with the same digest) so that the check in the CPU test suite costs a parse, not a compile
+ISA_CHECKED = ("dwconv_cw.hip", "dwconv.hip", "dwconv_mm.hip", "pwconv.hip", "xbwd.hip")
+
+
+def assemble(src):
+    """device assembly of one source (cached by digest) -> path of the .s file"""
+    out = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".s")
+    stamp = out + ".sha1"
+    dig = _digest(src)
+    if not (os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig):
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        r = subprocess.run([_hipcc()] + FLAGS + ["--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc -S failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        with open(stamp, "w") as f:
+            f.write(dig)
+    return out
+
+
+def build_library(verbose=False, with_asm=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = sources()
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    if with_asm is None:
+        with_asm = os.environ.get("ATOMNAS_BUILD_ASM", "1") != "0"
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(12, len(srcs) + len(ISA_CHECKED))) as ex:
+        asm = [ex.submit(assemble, s) for s in srcs if with_asm and os.path.basename(s) in ISA_CHECKED]
         results = list(ex.map(_compile, srcs))
+        for a in asm:
+            a.result()
     objs = [o for o, _ in results]
     rebuilt = any(r for _, r in results)
     if rebuilt or not os.path.exists(LIB_PATH):

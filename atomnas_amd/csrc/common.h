@@ -216,6 +216,11 @@ int dwconv_mm_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
                   int dtype, hipStream_t st);
 int dwconv_mm_supported(int N, int H, int W, int C, int k, int dir);
 
+// End of one stage of an LDS-DMA ring (all of the stage's global_load_lds copies of this wave have been issued).  An assembler
+// comment, no code: tools/check_asm_waits.py models the ring as a queue of stages and checks every counted `s_waitcnt vmcnt(N)`
+// against the number of copies issued AFTER the end of the stage that wait is for.
+#define ATOMNAS_RING_STAGE_END() asm volatile("; atomnas_ring_stage_end" ::: "memory")
+
 #define ATOMNAS_REQUIRE(cond, ...)            \
   do {                                        \
     if (!(cond)) {                            \

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(NWV * 64, WGPC) void k_gemm_nt_swg(const bf16_t* __
       k = k < kmax ? k : kmax;
       dma(((lane >> 4) & 1 ? shift : scale) + k, sb + (unsigned)(AT + WT) * 1024u);
     }
+    ATOMNAS_RING_STAGE_END();
     islot = islot + 1 == DEPTH ? 0 : islot + 1;
     if (++ic == nchunk) { ic = 0; ++ib; }
   };

@@ -2447,6 +2447,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_sw(const bf16_t* __restrict_
       row = row < M ? row : M - 1;
       dma(a + slab * ass + row * 16 + 8 * (lane & 1), lds_st + (unsigned)islot * STAGE_B + (unsigned)(4 * i + wave) * 1024u);
     }
+    ATOMNAS_RING_STAGE_END();
     islot = islot + 1 == DEPTH ? 0 : islot + 1;
     if (++ic == nchunk) { ic = 0; ++ib; }
   };
@@ -2807,6 +2808,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn3(Operand U, int NU, Operand 
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(g), "s"(d) : "memory");
     }
+    ATOMNAS_RING_STAGE_END();
   };
 
   // V prologue coefficients of this lane's two columns (B fragment: lane j <-> column)
@@ -3162,6 +3164,7 @@ __global__ __launch_bounds__(256, 2) void k_expand_bwd_s(const bf16_t* __restric
       row = row < M ? row : M - 1;
       dma(h + slab * hss + row * 16 + 8 * (lane & 1), lds_st + (unsigned)islot * STAGE_B + (unsigned)(4 * i + wave) * 1024u);
     }
+    ATOMNAS_RING_STAGE_END();
     islot = islot + 1 == DEPTH ? 0 : islot + 1;
     if (++ic == nchunk) { ic = 0; ++ib; }
   };

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_gram_part(const bf16_t* __restrict__ x,
       const int ch = 16 * ct + 8 * (lane & 1);
       dma(x + row * ldx + (ch < ldx - 8 ? ch : ldx - 8), lds0 + (unsigned)(islot * UT + ct) * 1024u);
     }
+    ATOMNAS_RING_STAGE_END();
     islot = islot + 1 == DEPTH ? 0 : islot + 1;
     ++iu;
   };

@@ -41,14 +41,7 @@ def regs(text):
 def assemble(src):
     sys.path.insert(0, ROOT)
     from atomnas_amd import build
-    out = os.path.join(build.OBJ_DIR, os.path.basename(src)[:-4] + ".s")
-    stamp = out + ".sha1"
-    dig = build._digest(src)
-    if not (os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig):
-        os.makedirs(build.OBJ_DIR, exist_ok=True)
-        subprocess.run([build._hipcc()] + build.FLAGS + ["--cuda-device-only", "-S", src, "-o", out], check=True, capture_output=True)
-        open(stamp, "w").write(dig)
-    return out
+    return build.assemble(src)
 
 
 ASM_LOADS = ("ds_read_b64", "s_load_dwordx2", "s_load_dwordx4", "ds_read_b128", "ds_read_b32", "ds_read_b64_tr_b16")
@@ -75,9 +68,13 @@ def functions(path):
         if t.startswith(".Lfunc_end"):
             cur = None
             continue
-        if not t or t[0] == ";" or (t[0] == "." and not t.endswith(":")):
+        m = re.match(r"^(\.L\w+):", t)      # a label, possibly followed by a comment ("; =>This Inner Loop Header: Depth=1")
+        if m:
+            cur[1].append((ln, m.group(1) + ":", in_asm))
             continue
-        cur[1].append((ln, t.split(";")[0].strip() if not t.endswith(":") else t, in_asm))
+        if not t or t[0] == ";" or t[0] == ".":
+            continue
+        cur[1].append((ln, t.split(";")[0].strip(), in_asm))
     return out
 
 
@@ -185,16 +182,85 @@ COPY = "global_load_lds_dwordx4"
 VMEM_LOAD = ("global_load_", "buffer_load_", "flat_load_", "scratch_load_")
 
 
+MARK = "; atomnas_ring_stage_end"
+
+
 def check_rings(path):
-    """-> (findings, [description of every ring found])"""
+    """Counted waits of the LDS-DMA rings, as a queue model.  The kernels mark the end of every stage they issue
+    (ATOMNAS_RING_STAGE_END, an assembler comment inside inline asm); stages are consumed first in first out, one per counted
+    `s_waitcnt vmcnt(N)`.  Vector-memory operations retire in order, so the wait leaves the stage complete iff at least N copies were
+    issued AFTER that stage's end marker.  State = for every stage not yet waited for, the copies issued since its marker; forward
+    data-flow of the set of states per basic block (loops make it periodic).  A finding: a wait with fewer than N copies behind its
+    stage (returns early: stale LDS data), a wait with no stage outstanding, or a compiler-emitted vector-memory LOAD inside a loop
+    that holds a counted wait (its own wait would ignore the copies and drain the ring).  More than N copies behind the stage only
+    makes the wait conservative (k_expand_bwd_s: the x / residual rows ride in the queue); reported in the description.
+    -> (findings, [description of every ring kernel])"""
     findings, rings = [], []
-    for func, ins in functions(path):
-        if not any(ia and t.startswith(COPY) for _, t, ia in ins):
+    for func, raw in functions_with_marks(path):
+        if not any(ia and t.startswith(COPY) for _, t, ia in raw):
             continue
-        blocks, succ = _cfg(ins)
+        blocks, succ = _cfg(raw)
         n = len(blocks)
-        # back edges by depth-first search from the entry (an edge to a block on the search stack)
-        back, state, stack = set(), [0] * n, [(0, 0)]
+        base = os.path.basename(path)
+
+        def events(blk):
+            out = []
+            for ln, t, ia in blk:
+                if ia and t.startswith(COPY):
+                    out.append(("c", ln, 0))
+                elif ia and t == MARK:
+                    out.append(("m", ln, 0))
+                else:
+                    m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+                    if ia and m and int(m.group(1)) > 0:
+                        out.append(("w", ln, int(m.group(1))))
+            return out
+        ev = [events(b) for b in blocks]
+        if not any(e[0] == "w" for b in ev for e in b):
+            continue
+        if not any(e[0] == "m" for b in ev for e in b):
+            findings.append("%s %s: counted vmcnt waits but no ATOMNAS_RING_STAGE_END markers" % (base, func))
+            continue
+        val = [set() for _ in range(n)]
+        val[0] = {()}
+        work, noted, slack, slack_hi, sites, depth = [0], set(), {}, {}, set(), 0
+        while work:
+            i = work.pop()
+            outs = set()
+            for st in val[i]:
+                st = list(st)
+                for kind, ln, N in ev[i]:
+                    if kind == "c":
+                        st = [v + 1 for v in st]
+                    elif kind == "m":
+                        st.append(0)
+                        depth = max(depth, len(st))
+                    else:
+                        sites.add(ln)
+                        if not st:
+                            if ln not in noted:
+                                noted.add(ln)
+                                findings.append("%s:%d %s: wait vmcnt(%d) with no stage outstanding" % (base, ln, func, N))
+                            continue
+                        behind = st.pop(0)
+                        slack[ln] = min(slack.get(ln, behind - N), behind - N)
+                        slack_hi[ln] = max(slack_hi.get(ln, behind - N), behind - N)
+                        if behind < N and ln not in noted:
+                            noted.add(ln)
+                            findings.append("%s:%d %s: wait vmcnt(%d) but only %d copies were issued after the end of its stage: the wait "
+                                            "can return before the stage has landed" % (base, ln, func, N, behind))
+                outs.add(tuple(st))
+            for j in succ[i]:
+                if not outs <= val[j]:
+                    val[j] |= outs
+                    if len(val[j]) > 64 or any(len(t) > 16 for t in val[j]):
+                        if ("u", j) not in noted:
+                            noted.add(("u", j))
+                            findings.append("%s %s: stages issued and counted waits are not balanced over a loop (block %d)" % (base, func, j))
+                        continue
+                    work.append(j)
+        # compiler-emitted vector-memory loads inside a loop that holds a counted wait
+        state, stack, back = [0] * n, [(0, 0)], set()
         state[0] = 1
         while stack:
             i, k = stack[-1]
@@ -213,79 +279,61 @@ def check_rings(path):
         for i in range(n):
             for j in succ[i]:
                 pred[j].append(i)
-
-        def natural_loop(latch, header):
-            body, work = {header, latch}, [latch]
-            while work:
-                b = work.pop()
-                if b == header:
-                    continue
-                for q in pred[b]:
-                    if q not in body:
-                        body.add(q)
-                        work.append(q)
-            return body
-        loops = {}
         for (latch, header) in back:
-            loops.setdefault(header, set()).update(natural_loop(latch, header))
-        copies = [sum(1 for _, t, ia in blk if ia and t.startswith(COPY)) for blk in blocks]
-        # forward DAG (back edges removed): min / max copies on the paths from `src` into (not including) every block
-        order, seen = [], [False] * n
-
-        def topo(i):
-            seen[i] = True
-            for j in succ[i]:
-                if (i, j) not in back and not seen[j]:
-                    topo(j)
-            order.append(i)
-        sys.setrecursionlimit(max(10000, 4 * n))
-        topo(0)
-        order.reverse()
-
-        def path_counts(src, allowed=None):
-            lo, hi = {src: 0}, {src: 0}
-            for i in order:
-                if i not in lo or (allowed is not None and i not in allowed):
+            body, wk = {header, latch}, [latch]
+            while wk:
+                q = wk.pop()
+                if q == header:
                     continue
-                for j in succ[i]:
-                    if (i, j) in back or (allowed is not None and j not in allowed):
-                        continue
-                    a, b = lo[i] + copies[i], hi[i] + copies[i]
-                    lo[j] = min(lo.get(j, a), a)
-                    hi[j] = max(hi.get(j, b), b)
-            return lo, hi
-        for bi, blk in enumerate(blocks):
-            for ln, t, ia in blk:
-                m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
-                if not (ia and m and int(m.group(1)) > 0):
-                    continue
-                N = int(m.group(1))
-                cands = [(len(body), h) for h, body in loops.items() if bi in body]
-                if not cands:
-                    findings.append("%s:%d %s: counted wait vmcnt(%d) outside any loop" % (os.path.basename(path), ln, func, N))
-                    continue
-                _, h = min(cands)
-                body = loops[h]
-                if any(h2 != h and h2 in body and any(copies[b] for b in loops[h2]) for h2 in loops):
-                    findings.append("%s:%d %s: ring copies inside a loop nested in the wait's loop" % (os.path.basename(path), ln, func))
-                    continue
-                lo, hi = path_counts(h, body)
-                latches = [i for (i, j) in back if j == h]
-                per = {(lo[i] + copies[i], hi[i] + copies[i]) for i in latches if i in lo}
-                if len(per) != 1 or next(iter(per))[0] != next(iter(per))[1]:
-                    findings.append("%s:%d %s: copies per pass of the ring loop differ by path: %s" % (os.path.basename(path), ln, func, sorted(per)))
-                    continue
-                cps = next(iter(per))[0]
-                plo, phi = path_counts(0)
-                pro = (plo.get(h), phi.get(h))
-                own = [t2 for b in body for _, t2, ia2 in blocks[b] if not ia2 and t2.split(" ")[0].startswith(VMEM_LOAD)]
-                desc = "%s: wait vmcnt(%d), %d copies per pass, %s copies before the loop" % (func[:60], N, cps, pro[0] if pro[0] == pro[1] else pro)
-                rings.append(desc)
-                if cps == 0 or N % cps != 0 or pro[0] != pro[1] or pro[0] != N + cps:
-                    findings.append("%s:%d ring miscount -- %s (expected N %% CPS == 0 and N + CPS copies before the loop)" % (os.path.basename(path), ln, desc))
-                if own:
-                    findings.append("%s:%d %s: compiler-emitted vector-memory load inside the ring loop: `%s`" % (os.path.basename(path), ln, func, own[0]))
+                for r in pred[q]:
+                    if r not in body:
+                        body.add(r)
+                        wk.append(r)
+            if not any(e[0] == "w" for q in body for e in ev[q]):
+                continue
+            own = [(ln, t2) for q in body for ln, t2, ia2 in blocks[q] if not ia2 and t2.split(" ")[0].startswith(VMEM_LOAD)]
+            if own and ("l", own[0][0]) not in noted:
+                noted.add(("l", own[0][0]))
+                findings.append("%s:%d %s: compiler-emitted vector-memory load inside a ring loop: `%s`" % (base, own[0][0], func, own[0][1]))
+        ws = sorted({e[2] for b in ev for e in b if e[0] == "w"})
+        rings.append("%s: waits %s at %d sites, up to %d stages in flight, copies behind the awaited stage beyond N: %s" % (
+            func[:64], ["vmcnt(%d)" % w for w in ws], len(sites), depth,
+            "0 (exact)" if slack and max(slack_hi.values()) == 0 and min(slack.values()) == 0 else "%d..%d" % (min(slack.values()), max(slack_hi.values())) if slack else "-"))
     return findings, rings
+
+
+def functions_with_marks(path):
+    """functions(), keeping the stage-end marker comments of inline asm as instructions"""
+    out, cur, in_asm = [], None, False
+    for ln, line in enumerate(open(path), 1):
+        t = line.strip()
+        if re.match(r"^_Z\w+:", t):
+            cur = (t.split(":")[0], [])
+            out.append(cur)
+            in_asm = False
+            continue
+        if cur is None:
+            continue
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if t.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        if in_asm and t == MARK:
+            cur[1].append((ln, MARK, True))
+            continue
+        m = re.match(r"^(\.L\w+):", t)
+        if m:
+            cur[1].append((ln, m.group(1) + ":", in_asm))
+            continue
+        if not t or t[0] == ";" or t[0] == ".":
+            continue
+        cur[1].append((ln, t.split(";")[0].strip(), in_asm))
+    return out
 
 
 if __name__ == "__main__":
