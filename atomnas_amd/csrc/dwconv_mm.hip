@@ -679,10 +679,17 @@ static bool mm_geometry(CwGeom& g, MmGeom& mg, int N, int H, int W, int C, int K
 }
 
 static int mm_mode() {
-  // bits 0-2: forward k = 3 / 5 / 7, bits 3-5: backward k = 3 / 5 / 7.  Default: forward k = 5, 7 (k = 3 is as fast on the packed-FMA rows,
-  // the backward instances are not yet: profiles/r05_dw_mm_*.txt)
-  static const int m = getenv("ATOMNAS_DW_MM") ? atoi(getenv("ATOMNAS_DW_MM")) : 6;
+  // bits 0-2: forward k = 3 / 5 / 7, bits 3-5: backward k = 3 / 5 / 7, bit 6: backward also on whole-image tiles (14 x 14, 7 x 7 maps).
+  // Default (profiles/r05_dw_mm_per_shape.txt, batch 256): forward k = 5, 7 everywhere (k = 3 is as fast on the packed-FMA rows);
+  // backward k = 7 on row-ring tiles (56 x 56: 0.42 -> 0.34 ms, 28 x 28: 0.20 -> 0.16 ms) -- a tile of the backward kernel costs about
+  // the same for every k (commit + two operand copies + epilogue, ~1000 instructions per wave), which beats the packed-FMA rows only
+  // at k = 7 and only where a worker walks many tiles.
+  static const int m = getenv("ATOMNAS_DW_MM") ? atoi(getenv("ATOMNAS_DW_MM")) : 38;
   return m;
+}
+static bool mm_bwd_wanted(const CwGeom& g, int k) {
+  const int bit = k == 3 ? 8 : (k == 5 ? 16 : 32);
+  return (mm_mode() & bit) && (g.ring || (mm_mode() & 64));
 }
 
 template <int K>
@@ -725,7 +732,7 @@ static int mm_launch_bwd(const void* gup, long gss, const void* yraw, long yrss,
                          float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, hipStream_t st) {
   CwGeom g;
   MmGeom mg;
-  if (!mm_geometry(g, mg, N, H, W, C, K, true)) return -1;
+  if (!mm_geometry(g, mg, N, H, W, C, K, true) || !mm_bwd_wanted(g, K)) return -1;
   const size_t lds = mm_lds(g, mg, K, true);
   if (lds > max_lds_bytes()) return -1;
 #define MM_BWD(AMV)                                                                                                         \
@@ -747,8 +754,6 @@ int dwconv_mm_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
                   float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride,
                   int dtype, hipStream_t st) {
   if (dtype != DT_BF16 || stride != 1 || gss == 0 || xss == 0 || hss == 0 || (yraw && yrss == 0) || ldw < ((C + 7) & ~7)) return -1;
-  const int bit = k == 3 ? 8 : (k == 5 ? 16 : 32);
-  if (!(mm_mode() & bit)) return -1;
 #define MM_B(KV) return mm_launch_bwd<KV>(gup, gss, yraw, yrss, c1, c2, c3, x, xss, sc, sh, relu, w, ldw, h, hss, dw, stats, stat_ld, part_rows, dw_ws, N, H, W, C, st)
   if (k == 3) MM_B(3);
   if (k == 5) MM_B(5);
@@ -761,8 +766,9 @@ int dwconv_mm_supported(int N, int H, int W, int C, int k, int dir) {
   CwGeom g;
   MmGeom mg;
   if (!(k == 3 || k == 5 || k == 7)) return 0;
-  const int bit = (k == 3 ? 1 : (k == 5 ? 2 : 4)) << (dir ? 3 : 0);
-  if (!(mm_mode() & bit) || !mm_geometry(g, mg, N, H, W, C, k, dir != 0)) return 0;
+  const int bit = k == 3 ? 1 : (k == 5 ? 2 : 4);
+  if (!mm_geometry(g, mg, N, H, W, C, k, dir != 0)) return 0;
+  if (dir ? !mm_bwd_wanted(g, k) : !(mm_mode() & bit)) return 0;
   return mm_lds(g, mg, k, dir != 0) <= max_lds_bytes() ? 1 : 0;
 }
 

@@ -561,6 +561,47 @@ def test_gemm_nt_streaming_wide_input(gpu_lib, M, N, K, act):
     assert torch.allclose(outs[0], outs[2], rtol=2e-2, atol=2e-2 * max(1.0, scale))
 
 
+@pytest.mark.parametrize("act", [1, 3])
+@pytest.mark.parametrize("M,N,K", [(12544, 192, 3456), (12544, 320, 3456), (50176, 80, 1440), (50176, 96, 1728),
+                                   # ragged post-shrink widths (hidden width = sum of branch segments padded to 16), ragged M
+                                   (12001, 192, 2608), (33333, 96, 1104), (9000, 40, 272), (50000, 88, 656)])
+def test_gemm_nt_streaming_wide_input_late_stages(gpu_lib, M, N, K, act):
+    """k_gemm_nt_swg (bf16, BNRELU prologue, slab-major A, 8192 <= M <= 100000, K >= 256: the projection forward of the 14x14 / 7x7
+    stages with the weight chunks in the LDS-DMA queue) at the bench's shapes and at post-shrink widths: against fp64, with and without
+    the statistics, and against the LDS-weights kernel on the plain layout -- the same k order of the MFMA accumulation, so the outputs
+    are BIT-IDENTICAL (the slab / plain layouts of a hidden tensor must not change a result bit)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + act)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    A, W = r(M, K).to(dtype), r(N, K) / K ** 0.5
+    c1, c2 = torch.rand(K, device="cuda", generator=g) + 0.5, r(K) * 0.3
+    pre = A.double() * c1.double() + c2.double()
+    Aeff = pre * torch.sigmoid(pre) if act == 3 else pre.clamp(min=0.0)
+    Wp = pack_w(W.cpu(), dtype)
+    Cref = Aeff.to(dtype).double() @ Wp[:N, :K].double().t()
+    scale = float(Cref.abs().max())
+    Ap = torch.cat([A, torch.zeros(M, pad8(K) - K, dtype=dtype, device="cuda")], 1)
+    outs = []
+    for slab, with_stats in ((True, True), (True, False), (False, True)):
+        C = fresh(M, N, dtype)
+        st = poisoned_stats(512, N) if with_stats else None
+        ops.gemm_nt(_slab(Ap, K) if slab else Ap, Wp, C, M, N, K, a_mode=ops.PRO_BNRELU, ac1=cvec(c1), ac2=cvec(c2), a_relu=act, stats=st,
+                    stat_mode=ops.STAT_SQ if with_stats else 0)
+        torch.cuda.synchronize()
+        Cg = C[:, :N].double()
+        bad = (Cg - Cref).abs() > tol(dtype)["atol"] * max(1.0, scale) + tol(dtype)["rtol"] * Cref.abs()
+        assert int(bad.sum()) == 0, (slab, with_stats, int(bad.sum()))
+        if with_stats:
+            assert not torch.isnan(st).any()
+            sm = st.sum(0).double()
+            assert torch.allclose(sm[0], Cg.sum(0), rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale))
+            assert torch.allclose(sm[1], (Cg * Cg).sum(0), rtol=1e-4, atol=1e-3 * M ** 0.5 * max(1.0, scale) ** 2)
+        outs.append(C[:, :N].clone())
+    assert torch.equal(outs[0], outs[1])   # the statistics do not change the output
+    assert torch.equal(outs[0], outs[2])   # slab-major (weights in the queue) == plain (LDS-weights kernel), bit for bit
+
+
 @pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(2000, 432, 24), (1500, 288, 16), (4111, 720, 40), (3000, 203, 80), (2500, 1440, 96), (1029, 400, 192),
                                    (30000, 432, 24)])
