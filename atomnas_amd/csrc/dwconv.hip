@@ -877,12 +877,11 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   // r03: for slab-major tensors whole slabs win on every stride-2 shape of the step since the prefetch became branch-free (8-channel
   // workgroups read half of every 32-byte slab row; tools/dwbench.py fwd, ATOMNAS_DW_FWD_CB=16 vs the rule: 1.55 -> 1.36 ms)
   int cb_rule = 16;
-  // bf16 only.  fp32 storage is the PARITY mode: its instances keep the configuration the reference-written fixtures were validated
-  // with (tests/golden/checkpoint_ref.pt, 4e-3 of an update element-wise).  Any regrouping of the statistics partials is an equally valid
-  // fp32 summation order, but it moves which ReLU pre-activations next to zero flip, i.e. single fp32 gradients by 1e-3 ... 1e-2
-  // (profiles/r04_fp32_flip_noise.txt: the fp32 oracle against its float64 self does the same on 4 of 8 batches) -- the fixture
-  // comparison would have to be loosened 15x for a mode nobody benchmarks.
-  const bool whole_slabs = xss != 0 && sizeof(T) == 2;
+  // One rule for both storage types (round 5).  Rounds 3-4 kept 8-channel slabs for fp32 because regrouping the statistics partials
+  // moved tests/golden/checkpoint_ref.pt's element-wise comparison across a ReLU-mask flip; the fixture's resume batch had a
+  // pre-activation ON zero (|pre| / rms 7.8e-9).  The fixture now resumes on a wide-margin batch (tools/make_golden.py: 1.75e-6), so
+  // the comparison no longer depends on the summation order.
+  const bool whole_slabs = xss != 0;
   if (S == 2 && C <= 96 && !whole_slabs) cb_rule = 8;
   else if (S == 2 && K >= 5 && H <= 56 && !whole_slabs) cb_rule = 8;
   else if (S == 1 && C <= 32) cb_rule = 32;

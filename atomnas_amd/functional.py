@@ -208,6 +208,14 @@ _EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "48"))
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
 _DP_TENSOR = bool(int(os.environ.get("ATOMNAS_DP_TENSOR", "1")))   # experiment switch: 0 = the BatchNorm-backward prologue in every GEMM tile
 TAIL_TAP = None   # set to a list by tests to receive the dropout keep mask of every tail forward
+# set to a list by tests to receive, for every activation the forward applies, (kind, plan, raw tensor, scale, shift): the pre-activation
+# is raw * scale + shift per channel -- what a test needs to compare ReLU masks with the oracle's (tests/test_block_gpu.py)
+ACT_TAP = None
+
+
+def _tap(kind, pl, raw, st):
+    if ACT_TAP is not None and st is not None:
+        ACT_TAP.append((kind, pl, raw, st.scale, st.shift))
 _CHECK_LOSS_SEED = bool(int(os.environ.get("ATOMNAS_CHECK_LOSS_SEED", "0")))   # experiment switch (same-box A/B of the two layouts)
 
 
@@ -237,6 +245,7 @@ def block_forward(pl, x2d, N, H, W, need_grad):
         ops.gemm_nt(x2d, pl.We_pack, E, M, HT, pl.inp, stats=stE.t if bs else None, stat_mode=STAT_SQ if bs else 0,
                     stat_rows=stE.rows if bs else None)
         bE = bn_forward_coeffs(pl.bne, stE, M, dev)
+        _tap("expand", pl, E, bE)
     else:
         E, bE = x2d, None
     bsd = bn_uses_batch_stats(pl.bnd)
@@ -251,6 +260,7 @@ def block_forward(pl, x2d, N, H, W, need_grad):
                            stD.at(o) if bsd else None, HT, N, H, W, c, pl.ks[i], s, stat_rows=stD.rows if bsd else None)
     br.join()
     bD = bn_forward_coeffs(pl.bnd, stD, M2, dev)
+    _tap("dw", pl, D, bD)
     bsp = bn_uses_batch_stats(pl.bnp)
     Pr = torch.empty(M2, pl.oup, dtype=T, device=dev)
     stP = _stats(pl.oup, dev, pl.bnp["mgr"]) if bsp else None
@@ -601,6 +611,8 @@ def convbn_forward(pl, x, need_grad):
         ops.gemm_nt(a2d, pl.W_pack, Y, M, pl.cout, K, stats=st.t if bs else None, stat_mode=STAT_SQ if bs else 0,
                     stat_rows=st.rows if bs else None)
     b = bn_forward_coeffs(pl.bn, st, M, dev)
+    if act:
+        _tap("convbn", pl, Y, b)
     out = torch.empty(M, Cp, dtype=T, device=dev)
     ops.bn_apply(Y, b.scale, b.shift, int(act), None, out, M, pl.cout)
     if need_grad:
@@ -678,6 +690,8 @@ def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
     ops.gemm_nt(a2d, lp.W_pack, L, M, lp.cout, lp.cin, stats=st.t if bs else None, stat_mode=STAT_SQ if bs else 0,
                 stat_rows=st.rows if bs else None)
     b = bn_forward_coeffs(lp.bn, st, M, dev)
+    if act:
+        _tap("convbn", lp, L, b)
     pooled = torch.empty(N, lp.cout, dtype=T, device=dev)
     p = float(drop_p) if training else 0.0
     keep = torch.empty(N, lp.cout, dtype=torch.uint8, device=dev) if p > 0 else None

@@ -147,22 +147,45 @@ TINY = dict(num_classes=10, input_size=64, input_channel=16, last_channel=64, wi
                                        [6, 40, 1, 2, [3, 5, 7]]])
 
 
-def test_model_forward_backward_fp32_against_measured_fp32_noise(gpu_lib):
-    """Whole tiny network, fp32 storage, all gradients against the float64 oracle -- with a bound derived from what fp32 arithmetic itself
-    does to this network instead of a fixed one.  A random-init ReLU network turns a 1e-7 forward difference into a 1e-3 ... 1e-2
-    gradient difference whenever one pre-activation near zero lands on the other side ("mask flip"): the oracle run in fp32 torch
-    arithmetic shows exactly that against its own float64 run on 4 of 8 batches (profiles/r04_fp32_flip_noise.txt: up to 1.45e-2, else
-    4e-6), and which batch flips differs between two equally valid summation orders.  So, per batch: the forward (logits, loss) must be
-    tight; the gradients must be within 10x the fp32 oracle's own distance to float64 (floor 2e-5) unless a flip is in play, in which
-    case 5e-2 (3x the largest measured flip); and at least two of the three batches must be flip-free for the HIP path -- exact
-    arithmetic parity is demonstrated there.  (Round 3 read 9e-4 against a fixed 1e-4 on one batch when a depthwise slab rule changed:
-    that was a flip, not a defect of the rule -- either rule passes this test.  The fp32 instances nevertheless stay on the frozen
-    configuration, because the element-wise comparison with the reference-written checkpoint fixture is tied to one flip pattern:
-    csrc/dwconv.hip launch_fwd.)"""
+def _hip_masks(taps):
+    """ReLU masks of a HIP forward from functional.ACT_TAP entries, as NHWC-flattened [M, C] boolean tensors per activation, in the
+    oracle's order of activations: ConvBNReLU -> one; atomic block -> per branch (expand, depthwise), as the oracle walks them"""
+    from atomnas_amd.ops import Slab
+    out, i = [], 0
+    plain = lambda t: t.to_plain() if isinstance(t, Slab) else t
+    while i < len(taps):
+        kind, pl, raw, sc, sh = taps[i]
+        if kind == "convbn":
+            C = pl.cout
+            out.append((plain(raw)[:, :C].float() * sc[:C] + sh[:C]) > 0)
+            i += 1
+            continue
+        ex = taps[i] if kind == "expand" else None
+        dw = taps[i + 1] if ex is not None else taps[i]
+        assert dw[0] == "dw" and dw[1] is pl
+        i += 2 if ex is not None else 1
+        for sg, h in zip(pl.seg, pl.hid):
+            for t in ([ex] if ex is not None else []) + [dw]:
+                _, _, raw_t, sc_t, sh_t = t
+                out.append((plain(raw_t)[:, sg:sg + h].float() * sc_t[sg:sg + h] + sh_t[sg:sg + h]) > 0)
+    return out
+
+
+def test_model_forward_backward_fp32_flips_detected_against_the_oracle(gpu_lib):
+    """Whole tiny network, fp32 storage, all gradients against the float64 oracle.  A random-init ReLU network turns a 1e-7 forward
+    difference into a 1e-3 ... 1e-2 gradient difference whenever one pre-activation near zero lands on the other side of zero ("mask
+    flip"; the fp32 oracle does it against its own float64 run on 4 of 8 batches, profiles/r04_fp32_flip_noise.txt).  Round 4 inferred
+    a flip from the size of the error; here flips are DETECTED: every ReLU mask of the HIP forward (functional.ACT_TAP: raw tensor and
+    BatchNorm coefficients of every activation) is compared with the oracle's float64 mask.
+      * no flipped element  -> every gradient tensor within a FIXED 1e-4 relative L2 (measured 4e-6 ... 7e-6);
+      * flips               -> the number is reported and must be tiny (< 1e-5 of the activations); gradients within 5e-2.
+    The batches are three of the seeds whose smallest |pre-activation| / rms is largest in float64 (>= 1.4e-6; tools search over 60
+    seeds, margin asserted below), so all three are expected flip-free; at least two must be."""
+    from atomnas_amd import functional as AF
     from atomnas_amd.models import mobilenet_supernet as ms
     from atomnas_amd.utils import optim as aopt
     clean = 0
-    for seed in (3, 6, 7):
+    for seed in (53, 23, 44):
         model = ms.Model(**TINY)
         model.set_compute_dtype(torch.float32)
         _randomize(model, 5)
@@ -173,34 +196,55 @@ def test_model_forward_backward_fp32_against_measured_fp32_noise(gpu_lib):
         x = torch.randn(N, 3, 64, 64, generator=g)
         y = torch.randint(0, 10, (N,), generator=g)
         model.cuda().train()
-        logits = model(x.cuda())
+        AF.ACT_TAP = []
+        try:
+            logits = model(x.cuda())
+            taps = AF.ACT_TAP
+        finally:
+            AF.ACT_TAP = None
         loss = aopt.CrossEntropyLabelSmooth(10, 0.1, reduction="none")(logits, y.cuda()).mean()
         loss.backward()
         torch.cuda.synchronize()
 
-        def oracle(dt):
-            work = {k: (v.clone().to(dt).requires_grad_(True) if (v.is_floating_point() and "running" not in k)
-                        else (v.to(dt) if v.is_floating_point() else v)) for k, v in sd0.items()}
-            ref = orc.model_forward(x.to(dt), work, spec, True, {}, q=orc.NoQuant)
-            rl = orc.ce_label_smooth(ref, y, 0.1).mean()
-            rl.backward()
-            return ref.detach().double(), float(rl.detach()), {n: work[n].grad.double() for n, _ in model.named_parameters()}
-        r64, l64, g64 = oracle(torch.float64)
-        _, _, g32 = oracle(torch.float32)
+        # float64 oracle with its pre-activations recorded
+        pre, orig_act = [], orc._act
+
+        def rec(t, name):
+            pre.append(t.detach())
+            return orig_act(t, name)
+        work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
+        orc._act = rec
+        try:
+            ref = orc.model_forward(x.double(), work, spec, True, {}, q=orc.NoQuant)
+        finally:
+            orc._act = orig_act
+        rl = orc.ce_label_smooth(ref, y, 0.1).mean()
+        rl.backward()
         rel = lambda a, b: float((a - b).norm() / max(float(b.norm()), 1e-30))
-        assert rel(logits.double().cpu(), r64) < 2e-5 and abs(float(loss.detach()) - l64) < 1e-5
+        assert rel(logits.double().cpu(), ref.detach()) < 2e-5 and abs(float(loss.detach()) - float(rl.detach())) < 1e-5
+        margin = min(float((t.abs() / t.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt().clamp_min(1e-30)).min()) for t in pre)
+        assert margin > 1e-6, (seed, margin)   # the batch is one of the wide-margin ones (guards the seed list against drift)
+        masks = _hip_masks(taps)
+        assert len(masks) == len(pre), (len(masks), len(pre))
+        flips = total = 0
+        for m, t in zip(masks, pre):
+            om = (t > 0).permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+            assert om.shape == m.shape, (om.shape, m.shape)
+            flips += int((m.cpu() != om).sum())
+            total += om.numel()
+        g64 = {n: work[n].grad.double() for n, _ in model.named_parameters()}
         gnorm = max(float(v.norm()) for v in g64.values())
-        hip = ora = 0.0
+        hip = 0.0
         for name, p in model.named_parameters():
             if float(g64[name].norm()) > 1e-6 * gnorm:
                 hip = max(hip, rel(p.grad.double().cpu(), g64[name]))
-                ora = max(ora, rel(g32[name], g64[name]))
             else:   # a bias in front of another BatchNorm: the true gradient is zero, both sides hold rounding noise
                 assert float(p.grad.abs().max()) < 1e-5 * gnorm, (name, float(p.grad.abs().max()), gnorm)
-        assert hip < 5e-2, (seed, hip, ora)
-        if hip < 1e-4:
+        if flips == 0:
             clean += 1
-            assert hip <= 10 * max(ora, 2e-6) or ora > 1e-4, (seed, hip, ora)
+            assert hip < 1e-4, (seed, hip)
+        else:
+            assert flips < 1e-5 * total and hip < 5e-2, (seed, flips, total, hip)
     assert clean >= 2, clean
 
 

@@ -288,7 +288,10 @@ def test_reference_written_checkpoint_resumes_identically(gpu_lib):
     ts = engine.TrainStep(model, opt, ema, pinfo, weight_decay=1e-3, label_smoothing=0.1, batch_size=6, image_size=64, use_graph=False)
     ts.global_step = 2
     step = 2
-    x = (counter_fill(torch.empty(6, 3, 64, 64), 700 + step) * 4).float()
+    # the batch of the resumed iteration is the one make_golden.py chose for its ReLU margin (smallest |pre-activation| / rms 1.75e-6
+    # in float64; round 4's batch had 7.8e-9, i.e. a pre-activation ON zero: whichever way fp32 rounding put it decided 1e-3 of every
+    # upstream gradient, and the fp32 kernels were frozen on one slab rule to reproduce the reference's side of that coin)
+    x = (counter_fill(torch.empty(6, 3, 64, 64), g["resume_seed"]) * 4).float()
     y = (torch.arange(6) * 3 + step) % 10
     ts.set_batch(x.cuda(), y.cuda())
     ts.step(lr=0.002 * (1 + step), rho=1e-3 * (1 + step))
@@ -298,7 +301,7 @@ def test_reference_written_checkpoint_resumes_identically(gpu_lib):
     # equally far off (median 2e-6 of the update, up to 3e-3 where the update is a few ulps of the parameter: gamma ~ 1 moving by
     # 2e-5, BN biases in front of another BN moving by rounding noise).  So: element-wise on the first 512 elements of every tensor,
     # relative to the size of the reference's UPDATE plus a few ulps of the value; digests of the whole tensors with a loose bound.
-    REL = 4e-3
+    REL = 2e-3
     sd = model.state_dict()
     head = g["after_head"]
     ck = g["checkpoint"]

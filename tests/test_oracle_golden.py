@@ -231,7 +231,8 @@ def test_resume_from_reference_checkpoint():
                          momentum_buffer=ck["optimizer"]["state"][i]["momentum_buffer"].clone().double()) for i, k in enumerate(pnames)}
     ema = collections.OrderedDict((k, v.clone().double()) for k, v in ck["ema"]["shadow"].items())
     step = 2
-    x = (counter_fill(torch.empty(6, 3, 64, 64), 700 + step) * 4).double()
+    x = (counter_fill(torch.empty(6, 3, 64, 64), g["resume_seed"]) * 4).double()   # the wide-margin batch make_golden.py chose
+    assert g["resume_margin"] > 1e-6
     y = (torch.arange(6) * 3 + step) % 10
     r = orc.train_step(sd, spec, opt_state, ema, x, y, dict(lr=0.002 * (1 + step), rho=1e-3 * (1 + step), weight_decay=1e-3, wd_method="mnas",
                        label_smoothing=0.1, alpha=0.9, eps=1e-3, momentum=0.9, ema_decay=orc.ema_decay(0.99, step + 1)), names, pen)

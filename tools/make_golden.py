@@ -307,9 +307,28 @@ def g_checkpoint():
 
     crit = roptim.CrossEntropyLabelSmooth(10, 0.1, reduction='none')
 
-    def iterate(m, pinfo, opt, ema, step):
+    def batch(xseed):
+        return (counter_fill(torch.empty(6, 3, 64, 64), xseed) * 4).float()
+
+    def relu_margin(m, x):
+        """smallest |pre-activation| / channel rms over every ReLU input of one training-mode forward (float64 copy of the model)"""
+        m64 = copy.deepcopy(m).double()
+        worst = [float("inf")]
+
+        def hook(mod, inp):
+            t = inp[0].detach()
+            rms = t.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt().clamp_min(1e-30)
+            worst[0] = min(worst[0], float((t.abs() / rms).min()))
+        hs = [mod.register_forward_pre_hook(hook) for mod in m64.modules() if isinstance(mod, torch.nn.ReLU)]
+        with torch.no_grad():
+            m64(x.double())
+        for h in hs:
+            h.remove()
+        return worst[0]
+
+    def iterate(m, pinfo, opt, ema, step, xseed=None):
         named = dict(m.named_parameters())
-        x = (counter_fill(torch.empty(6, 3, 64, 64), 700 + step) * 4).float()
+        x = batch(700 + step if xseed is None else xseed)
         y = (torch.arange(6) * 3 + step) % 10
         lr, rho = 0.002 * (1 + step), 1e-3 * (1 + step)
         for g in opt.param_groups:
@@ -340,8 +359,16 @@ def g_checkpoint():
     model2.load_state_dict(ckpt['model'])
     opt2.load_state_dict(ckpt['optimizer'])
     ema2.load_state_dict(ckpt['ema'])
-    losses.append(iterate(model2, pinfo2, opt2, ema2, 2))
+    # The batch of the resumed iteration: the one of 64 candidates whose smallest |pre-activation| / rms over all ReLU inputs is
+    # largest at the checkpointed state (float64).  An fp32 implementation with another summation order than ATen's then puts no
+    # pre-activation on the other side of zero, so the element-wise comparison of the continuation does not depend on a ReLU-mask
+    # flip pattern (round 4 kept an fp32-only depthwise slab rule for that reason; profiles/r04_fp32_flip_noise.txt).
+    margins = sorted(((relu_margin(model2, batch(sd_)), sd_) for sd_ in range(702, 766)), reverse=True)
+    resume_margin, resume_seed = margins[0]
+    print("checkpoint fixture: resume batch seed %d, ReLU margin %.3g (seed 702: %.3g)" % (resume_seed, resume_margin, dict((b, a) for a, b in margins)[702]))
+    losses.append(iterate(model2, pinfo2, opt2, ema2, 2, xseed=resume_seed))
     out = dict(kw=TINY, seed=123, init_digest=init_digest, checkpoint=ckpt_saved, losses=losses, kwparams=mb.output_network(model),
+               resume_seed=resume_seed, resume_margin=resume_margin,
                after=dict(sd=digests(sd_of(model2)), sq=digests({n: opt2.state[p]['square_avg'] for n, p in model2.named_parameters()}),
                           buf=digests({n: opt2.state[p]['momentum_buffer'] for n, p in model2.named_parameters()}),
                           ema=digests({k: ema2.average(k) for k in ema2.average_names()}),
