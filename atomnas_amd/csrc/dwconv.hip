@@ -838,13 +838,13 @@ static void set_workers(DwGeom& g, int nslabs, int per_cu, int cap, long max_wor
   const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > cap) per_cu = cap;
-  static const int level_env = getenv("ATOMNAS_DW_XCD_LEVEL") ? atoi(getenv("ATOMNAS_DW_XCD_LEVEL")) : 2;   // A/B: 0 round-1 rule, 1 aligned
+  constexpr int level_env = 2;   // A/B: 0 round-1 rule, 1 aligned
   const bool aligned = level_env == 1 || (level_env == 2 && xcd_decode);
   g.xcd = (level_env == 2 && !xcd_decode) ? 0 : 1;
   const long slots_xcd = (long)(num_cus() / 8) * per_cu;
   long want = aligned ? (slots_xcd / nslabs) * 8 : ((long)num_cus() * per_cu) / nslabs;
   if (want < 8) want = ((long)num_cus() * per_cu) / nslabs;   // more slabs than slots of an XCD: several rounds either way
-  static const int share = getenv("ATOMNAS_DW_SHARE") ? atoi(getenv("ATOMNAS_DW_SHARE")) : 1;   // experiment: one of `share` concurrent launches
+  constexpr int share = 1;   // experiment: one of `share` concurrent launches
   if (share > 1) want = want / share > 0 ? want / share : 1;
   static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: force long tile walks
   if (max_env > 0 && want > max_env) want = max_env;
@@ -870,7 +870,7 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   const int cpad = (C + 7) / 8 * 8;
   // 14x14 output tiles of 16 channels (several workgroups per CU); small maps take the whole image and 64 channels
   const int sw = 7;
-  static const int cb_env = getenv("ATOMNAS_DW_FWD_CB") ? atoi(getenv("ATOMNAS_DW_FWD_CB")) : 0;
+  constexpr int cb_env = 0;
   // default 16; deviations measured in situ on the supernet's own shapes (bs 256 step, tools/bringup.py DETAIL=1 +
   // tools/cmpdetail.py, re-done after the XCD-level fix of set_workers): 8-channel slabs for the stride-2 layers with few channels
   // per pixel, 32 for C <= 32
@@ -894,7 +894,7 @@ static int launch_fwd(const void* x, int ldx, long xss, const float* sc, const f
   const int nslabs = (cpad + cb - 1) / cb;
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + 8 * cb) * sizeof(float) + (DW_FWD_STAGE ? (size_t)g.TH * g.TW * cb * sizeof(T) : 0);
   ATOMNAS_REQUIRE(lds <= max_lds_bytes(), "dwconv_fwd: tile does not fit in LDS (%zu bytes)", lds);
-  static const int cap_env = getenv("ATOMNAS_DW_FWD_PERCU") ? atoi(getenv("ATOMNAS_DW_FWD_PERCU")) : 0;
+  constexpr int cap_env = 0;
   const int cap = cap_env ? cap_env : 8;
 #define FWD_CASE(CBV, TMV)                                                                                                   \
   {                                                                                                                      \
@@ -925,7 +925,7 @@ static int launch_bwd_sw(const void* gup, int ldg, long gss, const void* yraw, i
   const int cpad = (C + 7) / 8 * 8;
   // measured (tools/dwbench.py): 32-channel slabs win for stride 2 and for 7x7 maps with k <= 5, 16-channel slabs elsewhere
   // (k = 7 with 32 channels spills its 98 weight-gradient accumulators)
-  static const int cb_env = getenv("ATOMNAS_DW_BWD_CB") ? atoi(getenv("ATOMNAS_DW_BWD_CB")) : 0;
+  constexpr int cb_env = 0;
   // in-situ deviations (same sweep as the forward, re-done after the XCD-level fix of set_workers): k = 5 at 28x28 and 14x14
   // prefers 32
   int cb_rule = (S == 2 || (H <= 7 && W <= 7 && K <= 5)) ? 32 : 16;
@@ -950,7 +950,7 @@ static int launch_bwd_sw(const void* gup, int ldg, long gss, const void* yraw, i
   const size_t lds = ((size_t)g.LH * g.RP + (size_t)K * K * cb + (size_t)cb * (K * K + 2) + 3 * (size_t)cb) * sizeof(float) +
                      (size_t)2 * tm * tm * cb * sizeof(T) + ((DW_DMA && sizeof(T) == 2) ? (size_t)2 * pf * 256 * 16 : 0);
   ATOMNAS_REQUIRE(lds <= max_lds_bytes(), "dwconv_bwd: tile does not fit in LDS (%zu bytes)", lds);
-  static const int cap_env2 = getenv("ATOMNAS_DW_BWD_PERCU") ? atoi(getenv("ATOMNAS_DW_BWD_PERCU")) : 0;
+  constexpr int cap_env2 = 0;
   const int cap = cap_env2 ? cap_env2 : 8;
 #define BWD_CASE(CBV, TMV)                                                                                                \
   {                                                                                                                       \
@@ -987,7 +987,7 @@ static int launch_bwd(const void* gup, int ldg, long gss, const void* yraw, int 
                       hipStream_t st) {
   // experiment (ATOMNAS_DW_BWD_SW14=k-mask, bit 0: k = 3, bit 1: k = 5): 14-pixel strips for stride 1 -- 27 % fewer LDS reads per FMA
   if constexpr (sizeof(T) == 2 && S == 1 && K <= 5) {
-    static const int wide_env = getenv("ATOMNAS_DW_BWD_SW14") ? atoi(getenv("ATOMNAS_DW_BWD_SW14")) : 0;
+    constexpr int wide_env = 0;
     if (((wide_env >> (K == 3 ? 0 : 1)) & 1) && H > 7 && W >= 14 && C >= 32)
       return launch_bwd_sw<T, K, S, 14>(gup, ldg, gss, yraw, ldyr, yrss, c1, c2, c3, x, ldx, xss, sc, sh, relu, w, ldw, h, ldh, hss, dw, stats,
                                          stat_ld, part_rows, dw_ws, N, H, W, C, st);

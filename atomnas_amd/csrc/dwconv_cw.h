@@ -260,7 +260,7 @@ static void cw_workers(CwGeom& g, int per_cu, int max_rows, int nw) {
   if (per_cu < 1) per_cu = 1;
   const int units = g.nslabs * (nw == 4 ? 2 : 1);   // workgroups per worker
   // experiment switch: this launch is one of `share` concurrent ones (the branches of a block on separate streams): 1 / share of the slots
-  static const int share = getenv("ATOMNAS_DW_SHARE") ? atoi(getenv("ATOMNAS_DW_SHARE")) : 1;
+  constexpr int share = 1;
   long want = ((long)num_cus() * per_cu) / units / (share > 1 ? share : 1);
   static const long max_env = getenv("ATOMNAS_DW_MAX_WORKERS") ? atol(getenv("ATOMNAS_DW_MAX_WORKERS")) : 0;   // tests: long tile walks
   if (max_env > 0 && want > max_env) want = max_env;
@@ -280,7 +280,7 @@ static int cw_mode() {
   return m;
 }
 static int cw_nw() {
-  static const int m = getenv("ATOMNAS_DW_CW_NW") ? atoi(getenv("ATOMNAS_DW_CW_NW")) : 4;   // waves per workgroup: 8 (whole slab) or 4 (half)
+  constexpr int m = 4;   // waves per workgroup: 8 (whole slab) or 4 (half)
   return m == 8 ? 8 : 4;
 }
 template <typename T> static size_t cw_lds(const CwGeom& g, int nw) {

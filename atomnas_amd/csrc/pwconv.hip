@@ -2350,7 +2350,7 @@ static int launch_nt_ws(int mode, const Operand& A, const void* Wp, int ldw, con
   const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
   const size_t lds_stat = do_stats ? (size_t)8 * 64 * ncg * sizeof(float) : 0;
   // two 16-row subtiles per wave (each weight fragment read feeds two MFMAs) when there are enough 128-row blocks
-  static const int rt_env = getenv("ATOMNAS_NT_WS_RT") ? atoi(getenv("ATOMNAS_NT_WS_RT")) : 0;
+  constexpr int rt_env = 0;
   // measured in situ per shape (bs 256 step, same box, ATOMNAS_NT_WS_RT=1/2): one subtile per wave is faster wherever the prologue is
   // BN-apply (the projection forward: M = 50176 -28 %, 200704 -15 %, 802816 -7 % -- the two-subtile BNRELU instance with two chunks
   // needs 335 registers, one wave per SIMD) and on the small maps; two subtiles only pay with the two-stream BN-backward prologue
@@ -2804,12 +2804,18 @@ static int launch_nt_swg(int mode, const Operand& A, const void* Wp, int ldw, co
   // chip: 14 x 14 (392 workgroups); 64-row stages at 7 x 7 (196 workgroups of four waves)
   const bool wide = (M + 127) / 128 >= num_cus() && ut <= 6;
   float* stats = do_stats ? ep.stats : nullptr;
-#define SWG_CASE(UTV, WG)                                                                                                              \
-  if (ut == UTV) {                                                                                                                     \
-    if (wide) return launch_swg<UTV, 1, 8>((const bf16_t*)A.p1, A.ss1, A.c1, A.c2, A.relu, (const bf16_t*)Wp, ldw, (bf16_t*)ep.c, ep.ldc, stats, ep.stat_rows, M, N, K, st); \
-    return launch_swg<UTV, WG, 4>((const bf16_t*)A.p1, A.ss1, A.c1, A.c2, A.relu, (const bf16_t*)Wp, ldw, (bf16_t*)ep.c, ep.ldc, stats, ep.stat_rows, M, N, K, st); \
+#define SWG_ARGS (const bf16_t*)A.p1, A.ss1, A.c1, A.c2, A.relu, (const bf16_t*)Wp, ldw, (bf16_t*)ep.c, ep.ldc, stats, ep.stat_rows, M, N, K, st
+#define SWG_CASE(UTV, WG)                                   \
+  if (ut == UTV) {                                          \
+    if (wide) return launch_swg<UTV, 1, 8>(SWG_ARGS);       \
+    return launch_swg<UTV, WG, 4>(SWG_ARGS);                \
   }
-  SWG_CASE(3, 2) SWG_CASE(5, 2) SWG_CASE(6, 2) SWG_CASE(12, 1) SWG_CASE(20, 1)
+  SWG_CASE(3, 2) SWG_CASE(5, 2) SWG_CASE(6, 2)
+  // wide outputs: four-wave stages only (an eight-wave instance would have 128 registers per lane for 2 x 16 UT accumulators and
+  // weight fragments: it spills, and a scratch reload inside the ring loop drains the queue -- tools/check_asm_waits.py flags it)
+  if (ut == 12) return launch_swg<12, 1, 4>(SWG_ARGS);
+  if (ut == 20) return launch_swg<20, 1, 4>(SWG_ARGS);
+#undef SWG_ARGS
 #undef SWG_CASE
   return -1;
 }
@@ -2824,10 +2830,10 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
   }
   if constexpr (sizeof(T) == 2) {
     // column-stationary form when the output is the wide operand
-    static const int cs_maxk = getenv("ATOMNAS_NT_CS_MAXK") ? atoi(getenv("ATOMNAS_NT_CS_MAXK")) : 192;
+    constexpr int cs_maxk = 192;
     // with the BatchNorm-backward prologue the 6-k-step instance (K = 192: 7x7 maps) needs 256 + 49 registers, one wave per SIMD;
     // the LDS-weights kernel is 10 % faster there (in situ, M = 12544, N = 3456 / 1728), without a prologue it is 50 % slower
-    static const int cs_maxk_pro = getenv("ATOMNAS_NT_CS_MAXK_PRO") ? atoi(getenv("ATOMNAS_NT_CS_MAXK_PRO")) : 96;
+    constexpr int cs_maxk_pro = 96;
     if (K <= (mode == PRO_BNBWD ? cs_maxk_pro : cs_maxk) && K <= 192 && N >= 2 * K && N >= 96 && M >= 1024) {
       const int ksteps = (K + 31) / 32;
       if (const int kind = nt_st_kind(mode, A, ep, M, N, K)) {
@@ -2845,7 +2851,7 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
     }
   }
   if constexpr (sizeof(T) == 2) {
-    static const int small_env = getenv("ATOMNAS_NT_SMALL") ? atoi(getenv("ATOMNAS_NT_SMALL")) : 1;
+    constexpr int small_env = 1;
     if (small_env && N <= 64 && K <= 64 && M >= 65536) {
       const long mtiles = (M + 15) / 16;
       const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
@@ -2871,8 +2877,8 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
     }
   }
   if constexpr (sizeof(T) == 2) {
-    static const int ws_env = getenv("ATOMNAS_NT_WS") ? atoi(getenv("ATOMNAS_NT_WS")) : 1;
-    static const int ws_mink = getenv("ATOMNAS_NT_WS_MINK") ? atoi(getenv("ATOMNAS_NT_WS_MINK")) : 97;
+    constexpr int ws_env = 1;
+    constexpr int ws_mink = 97;
     if (ws_env && K >= ws_mink && M >= 4096) return launch_nt_ws(mode, A, Wp, ldw, ep, M, N, K, st);
   }
   constexpr int KS = 4 * Mma<T>::EPL;
@@ -2909,8 +2915,8 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
   const int vt = (NV + 64 * VTT - 1) / (64 * VTT), uz = (NU + 16 * UTT - 1) / (16 * UTT);
   const size_t lds = (size_t)(64 * VTT + 16 * UTT) * (ROWS + 8) * sizeof(bf16_t) + (size_t)3 * (64 * VTT + 16 * UTT) * sizeof(float);
   // row chunks so that the grid is one round of resident workgroups (at least two slabs per workgroup)
-  static const int xcd_env = getenv("ATOMNAS_TN_XCD") ? atoi(getenv("ATOMNAS_TN_XCD")) : 1;
-  static const int tr_on = getenv("ATOMNAS_TN_TR") ? atoi(getenv("ATOMNAS_TN_TR")) : 1;   // experiment switch: transposing LDS reads (round 4)
+  constexpr int xcd_env = 1;
+  constexpr int tr_on = 1;   // experiment switch: transposing LDS reads (round 4)
 #define TN2_CASE(UM, VM)                                                                                                      \
   {                                                                                                                           \
     auto kern = tr_on ? k_gemm_tn2<UM, VM, UTT, VTT, ROWS, true> : k_gemm_tn2<UM, VM, UTT, VTT, ROWS, false>;                 \
@@ -2952,7 +2958,7 @@ static int launch_tn2_cfg(int umode, const Operand& U, int NU, int vmode, const 
 template <int UTT>
 static int launch_tn2_ut(int umode, const Operand& U, int NU, int vmode, const Operand& V, int NV, float* out, long si, long sj, long M,
                          float* ws, long ws_floats, hipStream_t st) {
-  static const int wide_env = getenv("ATOMNAS_TN_WIDE") ? atoi(getenv("ATOMNAS_TN_WIDE")) : -1;
+  constexpr int wide_env = -1;
   if constexpr (UTT >= 4 && UTT <= 12) {
     // r03, after the staging rewrite (same-call A/B over the step's shapes, ATOMNAS_TN_WIDE=0/1/2: 4.36 / 3.46 / 3.88 ms): 128-column V
     // tiles on 64-row slabs win for every U width (r02 had 64-column tiles for 12 U tiles and 128-row slabs for 10)
@@ -3147,11 +3153,11 @@ static int launch_tn3_cfg(const Operand& U, int NU, int vmode, const Operand& V,
                           long ws_floats, hipStream_t st) {
   const int vt = (NV + 127) / 128, uz = (NU + 16 * UTT - 1) / (16 * UTT);
   // ring depth: as many stages in flight as leave room for two workgroups per CU (ATOMNAS_TN3_DEPTH: experiment switch)
-  static const int depth_env = getenv("ATOMNAS_TN3_DEPTH") ? atoi(getenv("ATOMNAS_TN3_DEPTH")) : 0;
+  constexpr int depth_env = 0;
   const int depth = depth_env ? depth_env : ((size_t)4 * (8 + UTT) * 1024 * 2 + 4096 <= max_lds_bytes() ? 4 : 3);
   const size_t lds = (size_t)depth * (8 + UTT) * 1024;
   if (lds > max_lds_bytes()) return -1;
-  static const bool dbg = getenv("ATOMNAS_TN3_DEBUG") != nullptr;
+  constexpr bool dbg = false;
   const long max_chunks = (ws && (long)NU * NV > 0) ? ws_floats / ((long)NU * NV) : 1;
   long nparts = 1;
 #define TN3_CASE(VP)                                                                                                          \

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_reduce_batch(const ReduceBatch b) {
 
 static std::mutex g_rj_mu;          // backward runs on autograd's device thread, the flush on the caller's
 static bool g_rj_defer = false;
+static hipStream_t g_rj_stream = nullptr;   // the stream deferral was switched on for: only ITS reductions are recorded (round 5)
 static std::vector<ReduceJob> g_rj;
 
 // may two jobs touch the same output element?  (address ranges overlap, unless both write disjoint column bands of one row-major
@@ -131,7 +132,9 @@ int reduce_parts(const float* part, long part_stride, int parts, long n, float* 
   if (n <= 0 || parts <= 0) return 0;
   {
     std::lock_guard<std::mutex> lock(g_rj_mu);
-    if (g_rj_defer) {
+    // a reduction launched on another stream (a second model, an evaluation job in the same process) is not this backward's: its
+    // order against the producer of its partials would be lost and its workspace may be gone by the flush -- it runs at once
+    if (g_rj_defer && st == g_rj_stream) {
       g_rj.push_back(ReduceJob{part, out, part_stride, n, s_outer, s_inner, parts, inner, 0u, 0u});
       return 0;
     }
@@ -151,6 +154,7 @@ extern "C" int atomnas_reduce_defer(int on, void* stream) {
   int rc = 0;
   if (!on && !g_rj.empty()) rc = flush_jobs_locked((hipStream_t)stream);   // switching off never drops recorded work
   g_rj_defer = on != 0;
+  g_rj_stream = (hipStream_t)stream;
   return rc;
 }
 

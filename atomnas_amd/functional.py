@@ -8,7 +8,6 @@ Parameter gradients are written straight into the gradient arena (p.grad views) 
 Reference call sites: InvertedResidualChannels.forward (models/mobilenet_base.py:371-382), ConvBNReLU (:120-142),
 MobileNetV2.forward (models/mobilenet_supernet.py:169-173), CrossEntropyLabelSmooth.forward (utils/optim.py:199-207).
 """
-import contextlib
 import os
 
 import torch
@@ -139,71 +138,11 @@ _FUSED_PROJECT_BWD = bool(int(os.environ.get("ATOMNAS_FUSED_PROJECT_BWD", "1")))
 # widest block output that takes the fused kernel.  The library covers oup <= 96, but the 80/96-wide instances hold 223 VGPR + 96 AGPR
 # (one wave per SIMD) and measured slower than the two-GEMM form on the 14x14 stages: 36.53 vs 36.30 ms/step (r03, bs256 bf16).
 _FUSED_PROJECT_BWD_MAXOUP = int(os.environ.get("ATOMNAS_FUSED_PROJECT_BWD_MAXOUP", "48"))
-# experiment switch: the separate weight-gradient GEMMs of a block run on a side stream next to the input-gradient chain (they only
-# write the gradient arena); joined before the block's backward returns.
-_SIDE_WGRAD = bool(int(os.environ.get("ATOMNAS_SIDE_WGRAD", "0")))
-_side_stream = [None]
-
-
-class _Side:
-    def __enter__(self):
-        self.ctx = None
-        if _SIDE_WGRAD:
-            if _side_stream[0] is None:
-                _side_stream[0] = torch.cuda.Stream()
-            _side_stream[0].wait_stream(torch.cuda.current_stream())
-            self.ctx = torch.cuda.stream(_side_stream[0])
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-
-# experiment switch: the (independent) depthwise launches of a block's branches on separate streams, each sized for 1 / n of the
-# machine (ATOMNAS_DW_SHARE in the library): the VALU-bound k = 7 instance next to the bandwidth-bound k = 3 / 5 ones
-_DW_STREAMS = int(os.environ.get("ATOMNAS_DW_STREAMS", "1"))
-_dw_streams = []
-
-
-class _Branches:
-    """runs the body of `with b.on(i):` for branch i on stream i % n (forked from the current stream), join() waits for all"""
-    def __init__(self, nb):
-        self.n = min(_DW_STREAMS, nb) if nb > 1 else 1
-        if self.n > 1:
-            while len(_dw_streams) < self.n - 1:
-                _dw_streams.append(torch.cuda.Stream())
-            self.cur = torch.cuda.current_stream()
-            for st in _dw_streams[:self.n - 1]:
-                st.wait_stream(self.cur)
-
-    def on(self, i):
-        if self.n <= 1 or i % self.n == 0:
-            return contextlib.nullcontext()
-        return torch.cuda.stream(_dw_streams[i % self.n - 1])
-
-    def join(self):
-        if self.n > 1:
-            for st in _dw_streams[:self.n - 1]:
-                self.cur.wait_stream(st)
-
-
-def _join_side():
-    if _SIDE_WGRAD and _side_stream[0] is not None:
-        torch.cuda.current_stream().wait_stream(_side_stream[0])
-
-
-# experiment switch: fused expand backward per branch segment where the whole hidden width has no instance (40 -> 3 x 240).  Measured in
-# situ: 1.30 ms against 1.19 ms for the two GEMMs (x is re-staged and Gx re-read per segment): off
-_FUSED_EXPAND_SEG = bool(int(os.environ.get("ATOMNAS_FUSED_EXPAND_SEG", "0")))
 _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # experiment switch: widest inp that takes the fused kernel (0: never)
 # Expand backward without the raw expand output E (csrc/xbwd.hip): with dE = c1*h + c2*E + c3 and E = x We^T the c2 / c3 terms are
 # inp x inp sized corrections (Gram matrix of x), so the wide GEMMs read h only.  Widest block input that takes this form (0: never;
-# bf16 only).  Same-box A/B of the bs-256 step (profiles/r04_expand_bwd_noe_ab.txt): 31.40 ms with the two-stream form everywhere,
-# 31.15 with inp <= 24 (the 112 x 112 and 56 x 56 stages, fused kernel: x M + v added inside it), 31.41 with inp <= 48 (the 28 x 28
-# stage has no fused instance: its extra narrow GEMM and Gram pass cost what the second hidden stream did).
+# bf16 only).  48 = stages 1-3 with the streaming kernel k_expand_bwd_s (same-box A/Bs: 31.15 -> 30.20 ms for inp <= 24, -> 30.11 with
+# the per-segment launches of 40 -> 720; the 31.41 of profiles/r04_expand_bwd_noe_ab.txt for 48 predates that kernel).
 _EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "48"))
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
 _DP_TENSOR = bool(int(os.environ.get("ATOMNAS_DP_TENSOR", "1")))   # experiment switch: 0 = the BatchNorm-backward prologue in every GEMM tile
@@ -251,14 +190,11 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     bsd = bn_uses_batch_stats(pl.bnd)
     D = _hidden(pl, M2, HT, T, dev)
     stD = _stats(HT, dev, pl.bnd["mgr"]) if bsd else None
-    br = _Branches(pl.nb)
     for i in range(pl.nb):
         o, c = pl.seg[i], pl.segpad(pl.hid[i])
         xin = _seg(E, o) if pl.expand else E
-        with br.on(i):
-            ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], _seg(D, o),
-                           stD.at(o) if bsd else None, HT, N, H, W, c, pl.ks[i], s, stat_rows=stD.rows if bsd else None)
-    br.join()
+        ops.dwconv_fwd(xin, bE.scale[o:] if bE else None, bE.shift[o:] if bE else None, act if bE else 0, pl.taps[i], _seg(D, o),
+                       stD.at(o) if bsd else None, HT, N, H, W, c, pl.ks[i], s, stat_rows=stD.rows if bsd else None)
     bD = bn_forward_coeffs(pl.bnd, stD, M2, dev)
     _tap("dw", pl, D, bD)
     bsp = bn_uses_batch_stats(pl.bnp)
@@ -317,16 +253,15 @@ def block_backward(pl, sv, G):
     if _DP_TENSOR and not fused_pb and se is None and T == torch.bfloat16 and pl.oup % 8 == 0:
         dP = torch.empty(M2, pl.oup, dtype=T, device=dev)
         ops.bnbwd_apply(G, Pr, p1, p2, p3, dP, M2, pl.oup)
-    with _Side():   # entered after dP is on the main stream: the side stream waits for it
-        for sg, nv, out, si in ([] if fused_pb else wp_jobs):
-            if se is not None:
-                ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
-            elif dP is not None:
-                ops.gemm_tn(dP, pl.oup, _seg(D, sg), nv, out, si, 1, M2, v_mode=PRO_BNRELU, vc1=bD.scale[sg:], vc2=bD.shift[sg:],
-                            v_relu=int(act))
-            else:
-                ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
-                            vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
+    for sg, nv, out, si in ([] if fused_pb else wp_jobs):
+        if se is not None:
+            ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
+        elif dP is not None:
+            ops.gemm_tn(dP, pl.oup, _seg(D, sg), nv, out, si, 1, M2, v_mode=PRO_BNRELU, vc1=bD.scale[sg:], vc2=bD.shift[sg:],
+                        v_relu=int(act))
+        else:
+            ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
+                        vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
     g = _hidden(pl, M2, HT, T, dev)
     st2D = _stats(HT, dev, pl.bnd["mgr"])
     if se is not None:
@@ -367,55 +302,37 @@ def block_backward(pl, sv, G):
     else:
         h = ops.zeros(M, pl.inp, dtype=T, device=dev) if pl.nb > 1 else torch.empty(M, pl.inp, dtype=T, device=dev)
         st2E = None
-    br = _Branches(pl.nb if pl.expand else 1)
     for i in range(pl.nb):
         o, c = pl.seg[i], pl.segpad(pl.hid[i])
         if pl.expand:
-            with br.on(i):
-                ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], _seg(E, o), bE.scale[o:], bE.shift[o:], act, pl.taps[i],
-                               _seg(h, o), pl.Wd_grad[i], st2E.at(o), HT, N, H, W, c, pl.ks[i], s, stat_rows=st2E.rows)
+            ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], _seg(E, o), bE.scale[o:], bE.shift[o:], act, pl.taps[i],
+                           _seg(h, o), pl.Wd_grad[i], st2E.at(o), HT, N, H, W, c, pl.ks[i], s, stat_rows=st2E.rows)
         else:
             if pl.nb > 1:
                 raise NotImplementedError("non-expanding block with more than one branch")
             ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], E, None, None, 0, pl.taps[i], h, pl.Wd_grad[i], None, 0, N, H,
                            W, c, pl.ks[i], s)
-    br.join()
     if not pl.expand:
-        _join_side()
         if pl.res:
             h = h + G
         return h
     e1, e2, e3 = bn_backward_coeffs(pl.bne, bE, st2E, M, dev)
     Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
-    if T == torch.bfloat16 and not pl.fused and pl.inp <= _EXPAND_BWD_NOE and pl.inp % 8 == 0:
+    if (T == torch.bfloat16 and not pl.fused and pl.inp <= min(_EXPAND_BWD_NOE, 64) and pl.inp % 8 == 0 and x2d.stride(0) % 8 == 0):   # atomnas_gram: inp <= 64, row pitch % 8
         return _expand_backward_noe(pl, x2d, h, e1, e2, e3, G if pl.res else None, Gx, M, HT, dev, T)
     if pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and ops.expand_bwd_supported(pl.inp, HT, T):
         # early stages (16 -> 288, 24 -> 432): input and weight gradient of the expand convolution from ONE pass over h and E
         ops.expand_bwd(h, E, e1, e2, e3, x2d, pl.WeT_pack, G if pl.res else None, Gx, pl.We_grad, M, pl.inp, HT)
-        _join_side()
-        return Gx
-    if (_FUSED_EXPAND_SEG and pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and pl.nb > 1
-            and all(ops.expand_bwd_supported(pl.inp, pl.segpad(hh), T) for hh in pl.hid)):
-        # 40 -> 720: the accumulators of the whole hidden width do not fit two workgroups per CU, those of one branch segment
-        # (240 channels) do: one launch per segment, the input gradient accumulating through `add` (each launch reads and writes
-        # its own rows of Gx only)
-        for i in range(pl.nb):
-            o, c = pl.seg[i], pl.segpad(pl.hid[i])
-            ops.expand_bwd(_seg(h, o), _seg(E, o), e1[o:], e2[o:], e3[o:], x2d, pl.WeT_pack[:, o:], (G if pl.res else None) if i == 0 else Gx, Gx,
-                           pl.We_grad[o * pl.inp:], M, pl.inp, c)
-        _join_side()
         return Gx
     # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k]); the
     # fused block's expand weight is one contiguous [total, inp] tensor: one launch per branch segment
     we_jobs = ([(sg, hh, pl.We_grad[stt * pl.inp:]) for sg, stt, hh in zip(pl.seg, pl.start, pl.hid)] if pl.fused
                else [(0, HT, pl.We_grad)])
-    with _Side():
-        for sg, nv, out in we_jobs:
-            ops.gemm_tn(x2d, pl.inp, _seg(h, sg), nv, out, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=_seg(E, sg), vc1=e1[sg:], vc2=e2[sg:],
-                        vc3=e3[sg:])
+    for sg, nv, out in we_jobs:
+        ops.gemm_tn(x2d, pl.inp, _seg(h, sg), nv, out, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=_seg(E, sg), vc1=e1[sg:], vc2=e2[sg:],
+                    vc3=e3[sg:])
     # expand input gradient (+ residual branch)
     ops.gemm_nt(h, pl.WeT_pack, Gx, M, pl.inp, HT, a_mode=PRO_BNBWD, a2=E, ac1=e1, ac2=e2, ac3=e3, add=G if pl.res else None)
-    _join_side()
     return Gx
 
 
@@ -446,7 +363,6 @@ def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
     if inp <= _FUSED_EXPAND_BWD and ops.expand_bwd_supported(inp, HT, T):
         # one pass over h: both gradients, x M + v added inside the kernel
         ops.expand_bwd(h, None, e1, None, None, x2d, pl.WeT_pack, res, Gx, pl.We_grad, M, inp, HT, mp=mp, vb=vb)
-        _join_side()
         return Gx
     if (inp <= _FUSED_EXPAND_BWD and not pl.fused and pl.nb > 1 and isinstance(h, ops.Slab)
             and all(ops.expand_bwd_supported(inp, pl.segpad(hh), T) for hh in pl.hid)):
@@ -457,15 +373,12 @@ def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
             o, c = pl.seg[i], pl.segpad(pl.hid[i])
             ops.expand_bwd(_seg(h, o), None, e1[o:], None, None, x2d, pl.WeT_pack[:, o:], res if i == 0 else Gx, Gx, pl.We_grad[o * inp:], M, inp,
                            c, mp=mp if i == 0 else None, vb=vb if i == 0 else None)
-        _join_side()
         return Gx
     gx1 = torch.empty(M, inp, dtype=T, device=dev)
     ops.gemm_nt(x2d, mp, gx1, M, inp, inp, bias=vb, add=res)
     zeros = _plan_buffer(pl, "xb_zero%d" % e1.numel(), lambda: ops.zeros(e1.numel(), dtype=torch.float32, device=dev))
-    with _Side():
-        ops.gemm_tn(x2d, inp, h, HT, pl.We_grad, 1, inp, M, v_mode=PRO_BNRELU, vc1=e1, vc2=zeros, v_relu=0)
+    ops.gemm_tn(x2d, inp, h, HT, pl.We_grad, 1, inp, M, v_mode=PRO_BNRELU, vc1=e1, vc2=zeros, v_relu=0)
     ops.gemm_nt(h, pl.WeT_pack, Gx, M, inp, HT, a_mode=PRO_BNRELU, ac1=e1, ac2=zeros, a_relu=0, add=gx1)
-    _join_side()
     return Gx
 
 

@@ -45,6 +45,8 @@ _TN_WS_FLOATS = int(os.environ.get("ATOMNAS_TN_WS_MB", "32")) << 18   # experime
 # workspaces are kept alive here until the flush.  Flush before anything reads the gradient arena.
 _DEFER = [False]
 _DEFER_KEEP = []
+_DEFER_BYTES = [0]
+_DEFER_LIMIT = 512 << 20   # partial workspaces kept alive before an early flush: bounds the extra peak memory of the deferral
 
 
 def reduce_defer(on):
@@ -52,16 +54,24 @@ def reduce_defer(on):
     _DEFER[0] = bool(on)
     if not on:
         del _DEFER_KEEP[:]
+    _DEFER_BYTES[0] = 0
 
 
 def reduce_flush():
     call("atomnas_reduce_flush", _stream())
     del _DEFER_KEEP[:]
+    _DEFER_BYTES[0] = 0
 
 
 def _keep(ws):
+    """called BEFORE the launch that writes partials into ws: when the kept workspaces pass the limit the jobs recorded so far are
+    flushed first (one more reduce launch; the sums per job are the same whenever they run), then ws starts the next batch"""
     if _DEFER[0] and ws is not None:
+        nbytes = ws.numel() * ws.element_size()
+        if _DEFER_KEEP and _DEFER_BYTES[0] + nbytes > _DEFER_LIMIT:
+            reduce_flush()
         _DEFER_KEEP.append(ws)
+        _DEFER_BYTES[0] += nbytes
     return ws
 
 
