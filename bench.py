@@ -297,6 +297,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--input-pipeline", default="resident", choices=["resident", "uint8"], help="resident: the synthetic fp32 batch "
+                    "stays in HBM (the headline protocol); uint8: every step takes a fresh batch from the GPU input pipeline -- decoded "
+                    "uint8 images from pinned host memory, H2D + crop / PIL-exact resize / flip / normalize on a side stream "
+                    "(utils/dataflow.py DevicePrefetcher), then set_batch.  Value then includes the hand-over; a different random "
+                    "batch per step, so the `trained` check does not apply")
     ap.add_argument("--allow-untrained", action="store_true", help="print the line even when the cross entropy on the fixed batch did not "
                     "go down over a run of >= 100 steps (fatal otherwise)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (the measured path); gloo only to "
@@ -355,17 +360,30 @@ def main():
         shrink_info = dict(fraction=args.shrink, shrink_ms=round(ms_shrink, 1), macs_before=macs0, macs_after=macs1)
         note("shrink: %.0f ms, MACs %d -> %d" % (ms_shrink, macs0, macs1))
 
+    pipeline = None
+    if args.input_pipeline == "uint8":
+        from atomnas_amd.utils import dataflow as DF
+        nsteps = max(args.warmup, 1) + args.steps
+        pipeline = iter(DF.DevicePrefetcher(DF.SyntheticDecodedImages(args.batch, nsteps + 1, image_size=hp['image_size'], seed=1995 + rank),
+                                            image_size=hp['image_size']))
+
+    def one_step():
+        if pipeline is not None:
+            xb, yb = next(pipeline)
+            ts.set_batch(xb, yb)
+        ts.step(lr=lr0, rho=rho)
+
     note("warm-up (graph capture)")
     first_loss = None
     for i in range(max(args.warmup, 1)):
-        ts.step(lr=lr0, rho=rho)
+        one_step()
         if i == 0:
             first_loss = float(ts.loss[0].item())
     barrier()
     note("timing %d steps" % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ts.step(lr=lr0, rho=rho)
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     note("timed: %.2f ms/step" % (dt / args.steps * 1e3))
@@ -388,7 +406,7 @@ def main():
     # that many RMSprop updates on ONE batch a working step always gets below its first loss), unless --allow-untrained says the
     # caller knows why (e.g. the first steps after a forced shrink).  Shorter runs (10..99 steps: a handful of small updates need not
     # outweigh the dropout-mask noise of the loss) are reported; `trained` is in the headline object, not buried in config.
-    trained = (loss[0] < first_loss) if args.steps + args.warmup >= 10 else None
+    trained = (loss[0] < first_loss) if (args.steps + args.warmup >= 10 and pipeline is None) else None
     if trained is False:
         msg = ("the cross entropy did not go down over %d steps on a fixed batch (%.4f -> %.4f)"
                % (args.steps + max(args.warmup, 1), first_loss, loss[0]))
@@ -406,7 +424,8 @@ def main():
             metric=metric,
             value=round(args.batch * world * args.steps / dt, 1), unit="images/sec", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="bf16" if dtype == torch.bfloat16 else "f32", data="synthetic",
+            dtype="bf16" if dtype == torch.bfloat16 else "f32",
+            data="synthetic" if pipeline is None else "synthetic uint8 images through the GPU input pipeline (H2D + crop / resize / flip / normalize per step)",
             config=dict(workload="%s full training step (fwd + CE-smooth/L2/L1 + bwd + grad all-reduce + RMSprop + EMA), 224x224" % args.model,
                         per_gpu_batch=args.batch, global_batch=args.batch * world, parallelism="dp%d" % world,
                         hip_graph=bool(ts.use_graph), lr=lr0, first_loss=round(first_loss, 4), final_loss=[round(v, 4) for v in loss],

@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 6   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported */
+#define ATOMNAS_ABI_VERSION 7   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -276,6 +276,23 @@ int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_a
 /* re-pack fp32 master weights into kernel layouts; jobs_dev: device array of
  *   struct { long src_off, dst_off; int rows, cols, src_ld, dst_ld, c_off, mode; }  (mode 0 [N][K], 1 transposed, 2 depthwise taps) */
 int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream);
+
+/* ---- input pipeline (utils/dataflow.py:92-170 'imagenet1k_mnas_bilinear', utils/transforms.py:54-177): decoded uint8
+ *      HWC images -> crop -> PIL-exact bilinear resize (antialiased triangle filter, 22-bit coefficients, horizontal pass rounded to
+ *      uint8, then vertical: libImaging/Resample.c) -> horizontal flip -> ToTensor -> Normalize, one launch per batch.
+ * pool: the images, packed (3 channels, row pitch 3 W);  desc: device array of N atomnas_img_desc;  S: output side;
+ * mean3 / std3: HOST arrays of three floats (read at the call);  out_mode 0: fp32 NCHW [N][3][S][S] (what atomnas_im2col_stem reads),
+ * 1: bf16 NHWC with a channel pitch of 8 (padding zero), 2: uint8 [N][S][S][3], the resized and flipped image before ToTensor
+ * (parity against PIL).  The crop box must lie inside the image and be at most 9 S on a side (host-side check: utils/dataflow.py). */
+typedef struct atomnas_img_desc {
+  long off;                 /* byte offset of the image in the pool */
+  int H, W;                 /* decoded size */
+  int bi, bj, bh, bw;       /* crop box: top, left, height, width */
+  int flip;                 /* mirror the resized image horizontally */
+  int pad_;
+} atomnas_img_desc;
+int atomnas_image_preprocess(const void* pool, const void* desc, int N, int S, const float* mean3, const float* std3, void* out,
+                             int out_mode, void* stream);
 
 /* ---- deferred fixed-order reductions (ABI 5).  The weight-gradient entry points (atomnas_pw_gemm_tn, atomnas_dwconv_bwd,
  *   atomnas_expand_bwd, atomnas_project_bwd) write per-workgroup partials to their workspace and sum them in a fixed order with one

@@ -1,0 +1,129 @@
+"""Input pipeline, CPU side: the crop-parameter logic of the reference's transforms (utils/transforms.py:54-177)
+restated in atomnas_amd/utils/transforms.py, and the oracle's restatement of PIL's bilinear resize (oracle/pil_resize.py) pinned
+against PIL itself and against the committed fixture.
+
+torchvision is not installed in this image, so the reference's module cannot be imported: the known answers below come from the
+reference's FORMULAS, transcribed here independently of the product file (every line cites the reference line it restates)."""
+import math
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pil_resize as pr  # noqa: E402
+
+from atomnas_amd.utils import transforms as T  # noqa: E402
+
+
+def ref_center_crop_padding(width, height, size, crop_padding):
+    side = int(size / (size + crop_padding) * min(width, height))          # utils/transforms.py:69-71
+    top = int(round((height - side) / 2.0))                                  # torchvision F.center_crop
+    left = int(round((width - side) / 2.0))
+    return top, left, side, side
+
+
+def ref_get_params(rng, ow, oh, scale, min_cov, ratio, log_ratio, max_attempts):
+    """utils/transforms.py:117-160, with `rng` in place of the module-level `random`"""
+    area0 = ow * oh
+    min_area, max_area = area0 * scale[0], area0 * scale[1]
+    for _ in range(max_attempts):
+        ar = math.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1]))) if log_ratio else rng.uniform(ratio[0], ratio[1])   # :122-126
+        min_h = int(round(math.sqrt(min_area / ar)))                                                                          # :128
+        max_h = int(round(math.sqrt(max_area / ar)))                                                                          # :129
+        if max_h * ar > ow:                                                                                                     # :130-132
+            max_h = int((ow + 0.5 - 0.0000001) / ar)
+        max_h = min(max_h, oh)                                                                                                  # :133
+        min_h = min(max_h, min_h)                                                                                               # :134
+        h = rng.randint(min_h, max_h)                                                                                           # :135
+        w = int(round(h * ar))                                                                                                  # :136
+        a = h * w                                                                                                               # :140
+        if a < min_area:
+            h += 1
+        if a > max_area:
+            h -= 1
+        w = int(round(h * ar))                                                                                                  # :145
+        a = h * w
+        if a < min_area or a > max_area or a < min_cov * area0:                                                                 # :148-151
+            continue
+        if w > ow or h > oh or w < 0 or h < 0:                                                                                  # :152-154
+            continue
+        return rng.randint(0, oh - h), rng.randint(0, ow - w), h, w, True                                                     # :157-159
+    return None, None, None, None, False
+
+
+def test_center_crop_padding_known_answers():
+    # by hand: int(224 / 256 * 375) = 328; (500 - 328) / 2 = 86; (375 - 328) / 2 = 23.5 -> round-half-even 24
+    assert T.CenterCropPadding(224, 32)((500, 375)) == (24, 86, 328, 328)
+    assert T.CenterCropPadding(224, 0)((224, 224)) == (0, 0, 224, 224)
+    for (w, h) in [(500, 375), (375, 500), (333, 500), (640, 480), (100, 37), (1, 1), (4032, 3024)]:
+        for size, pad in [(224, 32), (224, 0), (192, 32), (299, 40)]:
+            assert T.CenterCropPadding(size, pad)((w, h)) == ref_center_crop_padding(w, h, size, pad)
+
+
+@pytest.mark.parametrize("log_ratio", [False, True])
+def test_random_resized_crop_padding_draws_the_reference_boxes(log_ratio):
+    """same seed -> the same boxes as the reference's formulas, for the 'imagenet1k_mnas_bilinear' settings and a few others; the
+    module-level random stream is consumed exactly as the reference consumes it (the next draw after a call agrees as well)"""
+    sizes = [(500, 375), (375, 500), (640, 480), (333, 500), (224, 224), (100, 37), (37, 100), (2000, 30)]
+    for scale, cov, ratio in [((0.08, 1.0), 0.1, (3. / 4., 4. / 3.)), ((0.25, 1.0), None, (0.5, 2.0)), ((0.9, 1.0), 0.95, (0.99, 1.01))]:
+        t = T.RandomResizedCropPadding(224, scale=scale, min_object_covered=cov, ratio=ratio, log_ratio=log_ratio, crop_padding=32)
+        n_fail = 0
+        for seed in range(40):
+            for (w, h) in sizes:
+                random.seed(seed * 7 + w)
+                got = t.get_params((w, h))
+                nxt = random.random()
+                rng = random.Random(seed * 7 + w)
+                want = ref_get_params(rng, w, h, scale, cov or scale[0], ratio, log_ratio, 10)
+                assert got == want, (seed, w, h, got, want)
+                assert nxt == rng.random()
+                if want[4]:
+                    i, j, hh, ww = want[:4]
+                    assert 0 <= i and 0 <= j and i + hh <= h and j + ww <= w
+                    assert t.__class__(224, scale=scale, min_object_covered=cov, ratio=ratio, log_ratio=log_ratio, crop_padding=32) is not None
+                else:
+                    n_fail += 1
+                    random.seed(seed * 7 + w)
+                    assert t((w, h)) == ref_center_crop_padding(w, h, 224, 32)    # utils/transforms.py:162-168: the fall-back crop
+        assert n_fail > 0 or scale[0] < 0.5   # the extreme aspect ratios do exercise the fall-back
+
+
+def test_mnas_transform_settings():
+    (crop, flip), (vcrop, vflip) = T.mnas_bilinear_transforms(224)
+    assert crop.scale == (0.08, 1.0) and crop.min_object_covered == 0.1 and crop.ratio == (3. / 4., 4. / 3.) and crop.log_ratio is False
+    assert crop.crop_padding == 32 and vcrop.crop_padding == 32 and vflip is None and flip.p == 0.5     # utils/dataflow.py:125-160
+    assert T.IMAGENET_MEAN == (0.485, 0.456, 0.406) and T.IMAGENET_STD == (0.229, 0.224, 0.225)
+
+
+def test_pil_resize_restatement_is_bit_identical_to_pil():
+    """oracle/pil_resize.py against PIL itself on random images, boxes and output sizes (up- and down-scaling up to 9x)"""
+    from PIL import Image
+    rng = np.random.RandomState(3)
+    n = 0
+    for t in range(30):
+        H, W = int(rng.randint(8, 260)), int(rng.randint(8, 260))
+        img = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        h, w = int(rng.randint(4, H + 1)), int(rng.randint(4, W + 1))
+        i, j = int(rng.randint(0, H - h + 1)), int(rng.randint(0, W - w + 1))
+        S = int(rng.choice([17, 32, 64, 224]))
+        if h > 9 * S or w > 9 * S:
+            continue
+        ref = np.asarray(Image.fromarray(img).crop((j, i, j + w, i + h)).resize((S, S), Image.BILINEAR))
+        assert np.array_equal(pr.resize_bilinear_u8(img[i:i + h, j:j + w], S, S), ref), (t, H, W, (i, j, h, w), S)
+        n += 1
+    assert n >= 25
+
+
+def test_pil_resize_restatement_matches_the_committed_fixture():
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "input_pipeline.pt"), weights_only=False)
+    assert len(g["cases"]) >= 8
+    for c in g["cases"]:
+        got = pr.crop_resize_flip(c["image"].numpy(), c["box"], c["size"], c["flip"])
+        assert np.array_equal(got, c["resized"].numpy()), (c["box"], c["size"], c["flip"])
+        t = pr.to_tensor_normalize(got, g["mean"], g["std"])
+        assert t.dtype == np.float32 and t.shape == (3, c["size"], c["size"])
