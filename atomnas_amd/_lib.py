@@ -55,6 +55,7 @@ SIGNATURES = {
     "atomnas_gamma_mask": [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp],
     "atomnas_mask_index": [vp, i32, vp, vp, vp],
     "atomnas_gather_dim": [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp],
+    "atomnas_gather_jobs": [vp, i32, i64, vp],
     "atomnas_gram": [vp, i32, i64, i32, vp, i64, vp, vp, i32, vp],
     "atomnas_image_preprocess": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
     "atomnas_xb_coeffs": [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp],
@@ -67,7 +68,7 @@ NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version":
              "atomnas_dwconv_mm_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
              "atomnas_se_pool_parts": (i32, [i32, i32, i32])}
 
-ABI_VERSION = 7   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
+ABI_VERSION = 8   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None
 
 

@@ -107,6 +107,47 @@ __global__ __launch_bounds__(256) void k_gather_dim(const float* __restrict__ sr
 }
 }  // namespace atomnas
 
+// ---- job-list repack (SURVEY K12 / 8(b) `channel_repack (job list)`; models/compress_utils.py:31-37, utils/rmsprop.py:134-165,
+// utils/optim.py:134-153): every gather of one shrink -- model weights, BatchNorm vectors, RMSprop state, EMA shadows -- as ONE launch
+// over a table in device memory.  A workgroup finds its job by binary search over the jobs' first block numbers; a job is
+// k_gather_dim's (index == NULL: the identity, a plain strided copy -- the shared pw_bn keeps every channel).
+namespace atomnas {
+struct GatherJob {
+  const float* src;
+  float* dst;
+  const int* index;
+  long src_os, src_ds, dst_os, dst_ds;
+  int outer, n_kept, inner;
+  unsigned blk0;   // first workgroup of the job (ascending over the table)
+};
+static_assert(sizeof(GatherJob) == 72, "atomnas_gather_job layout");
+
+__global__ __launch_bounds__(256) void k_gather_jobs(const GatherJob* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {   // the last job whose first block is <= blockIdx.x (uniform)
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const GatherJob jb = jobs[lo];
+  const long total = (long)jb.outer * jb.n_kept * jb.inner;
+  const long e = (long)(blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int i = (int)(e % jb.inner);
+  const int j = (int)((e / jb.inner) % jb.n_kept);
+  const int o = (int)(e / ((long)jb.inner * jb.n_kept));
+  const long sj = jb.index ? (long)jb.index[j] : (long)j;
+  jb.dst[o * jb.dst_os + j * jb.dst_ds + i] = jb.src[o * jb.src_os + sj * jb.src_ds + i];
+}
+}  // namespace atomnas
+
+// jobs_dev: device array of njobs atomnas_gather_job (include/atomnas_hip.h) with blk0 filled in ascending order, one workgroup per 256
+// elements of a job; nblocks = the sum.  Jobs must not overlap in their destinations (a shrink writes every new tensor once).
+extern "C" int atomnas_gather_jobs(const void* jobs_dev, int njobs, long nblocks, void* stream) {
+  ATOMNAS_REQUIRE(jobs_dev && njobs > 0 && nblocks > 0 && nblocks < (1L << 31), "gather_jobs: bad arguments");
+  hipLaunchKernelGGL(atomnas::k_gather_jobs, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const atomnas::GatherJob*)jobs_dev, njobs);
+  return atomnas::check_launch("gather_jobs");
+}
+
 extern "C" int atomnas_mask_index(const unsigned char* mask, int count, int* index, int* kept, void* stream) {
   ATOMNAS_REQUIRE(mask && index && kept && count > 0, "mask_index: bad arguments");
   hipLaunchKernelGGL(atomnas::k_mask_index, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, count, index, kept);

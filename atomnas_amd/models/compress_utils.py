@@ -19,6 +19,28 @@ from .. import ops
 from ..utils.common import add_prefix
 
 
+class _build_on(object):
+    """Builds replacement modules directly on the device, without running their initialisers: every parameter and buffer of a rebuilt
+    branch is overwritten by the shrink's gathers / copies (the reference builds on the host, initialises, then moves: ~630 small
+    host-to-device copies and as many random initialisations per shrink of the supernet, for values that are thrown away)."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+
+    def __enter__(self):
+        self.saved = (nn.Conv2d.reset_parameters, nn.modules.batchnorm._NormBase.reset_parameters)
+        nn.Conv2d.reset_parameters = lambda self_: None
+        nn.modules.batchnorm._NormBase.reset_parameters = lambda self_: None
+        self.ctx = self.dev
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        nn.Conv2d.reset_parameters, nn.modules.batchnorm._NormBase.reset_parameters = self.saved
+        return False
+
+
 def _mask_along_dim(lhs, rhs, mask, dim=0):
     """lhs <- rhs[mask] (dim 0) / rhs[:, mask] (dim 1), on device."""
     if dim not in (0, 1):
@@ -75,6 +97,8 @@ def compress_bn(m_new, m_old, mask, prefix_new=None, prefix_old=None):
 def adjust_bn(m_new, m_old, post_hook_params, **kwargs):
     """The shared pw_bn keeps every channel; the reference attaches (and then disables) a running-mean correction."""
     mask = torch.ones_like(m_new.weight, dtype=torch.bool)
+    if ops.gather_deferring():
+        ops.register_mask(mask, None, mask.numel())   # every channel kept: a strided copy in the shrink's job table, no index
     infos = compress_bn(m_new, m_old, mask, **kwargs)
     for info in infos:
         if 'running_mean' in info['var_old_name']:
@@ -120,12 +144,11 @@ def copmress_inverted_residual_channels(m, masks, ema=None, optimizer=None, prun
 
     assert len(m.kernel_sizes) == len(masks)
     device = m.pw_bn.weight.device
-    hidden = [int(mask.detach().sum().item()) for mask in masks]
+    hidden = [ops.mask_count(mask) for mask in masks]   # from the shrink's one mask launch when it registered them, else mask.sum().item()
     keeps = [h > 0 for h in hidden]
     m.channels, m.kernel_sizes = [list(itertools.compress(x, keeps)) for x in (hidden, m.kernel_sizes)]
-    new_ops, new_pw_bn = m._build(m.channels, m.kernel_sizes, m.expand)
-    new_ops.to(device)
-    new_pw_bn.to(device)
+    with _build_on(device):
+        new_ops, new_pw_bn = m._build(m.channels, m.kernel_sizes, m.expand)
     for mod in list(new_ops.modules()) + [new_pw_bn]:   # train / eval state follows the block
         mod.training = m.training
     idx_depth, idx_proj = (1, 2) if m.expand else (0, 1)

@@ -445,6 +445,85 @@ def reg_value(p, jobs_dev, njobs, use_abs, mult_ptr, post_scale, out, ws=None):
     call("atomnas_reg_value", _p(p), _p(jobs_dev), njobs, int(use_abs), _p(mult_ptr), float(post_scale), _p(out), _p(ws), _stream())
 
 
+# ---- shrink plumbing.  A shrink computes ALL alive masks, their ascending kept-channel indices and counts in one launch
+# (atomnas_gamma_mask); register_masks() makes them known here, so that the per-tensor protocol of the reference
+# (info['mask_hook'](new, old, mask): models/compress_utils.py:31-37) neither recomputes an index per tensor nor synchronises for a count.
+# While gather_defer(True) is on, gathers are RECORDED and run as one launch at gather_flush() (atomnas_gather_jobs).
+_MASKS = {}        # (data_ptr, numel) -> (mask tensor kept alive, index tensor or None = identity, kept count)
+_GATHER = [None]   # list of recorded jobs while deferring
+
+
+def register_mask(mask, index, kept):
+    """mask: bool / uint8 device tensor; index: int32 device tensor of its kept positions (None: every channel kept); kept: int"""
+    _MASKS[(mask.data_ptr(), mask.numel())] = (mask, index, int(kept))
+
+
+def clear_masks():
+    _MASKS.clear()
+
+
+def mask_count(mask):
+    """number of kept channels: from the registry, else one device -> host synchronisation (the reference's mask.sum().item())"""
+    r = _MASKS.get((mask.data_ptr(), mask.numel()))
+    return r[2] if r is not None else int(mask.detach().sum().item())
+
+
+def gather_deferring():
+    return _GATHER[0] is not None
+
+
+def gather_defer(on):
+    if on:
+        _GATHER[0] = []
+    else:
+        gather_flush()
+        _GATHER[0] = None
+
+
+def gather_flush():
+    """runs every recorded gather in one launch (job table in device memory); a no-op when nothing is recorded"""
+    import numpy as np
+    jobs = _GATHER[0]
+    if not jobs:
+        return 0
+    dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("index", "<u8"), ("s_os", "<i8"), ("s_ds", "<i8"), ("d_os", "<i8"), ("d_ds", "<i8"),
+                   ("outer", "<i4"), ("n_kept", "<i4"), ("inner", "<i4"), ("blk0", "<u4")])
+    tab = np.zeros(len(jobs), dtype=dt)
+    blk = 0
+    for q, (src, dst, index, s_os, s_ds, d_os, d_ds, outer, n_kept, inner) in enumerate(jobs):
+        tab[q] = (src.data_ptr(), dst.data_ptr(), index.data_ptr() if index is not None else 0, s_os, s_ds, d_os, d_ds, outer, n_kept, inner, blk)
+        blk += (outer * n_kept * inner + 255) // 256
+    dev = jobs[0][1].device
+    table = torch.from_numpy(tab.view(np.uint8)).to(dev)
+    call("atomnas_gather_jobs", _p(table), len(jobs), blk, _stream())
+    n = len(jobs)
+    _GATHER[0] = [] if _GATHER[0] is not None else None
+    _keepalive = (table, jobs)   # the launch is asynchronous: the table and the tensors live until the stream has passed it
+    torch.cuda.current_stream().synchronize()
+    del _keepalive
+    return n
+
+
+def copy_job(dst, src):
+    """dst <- src as an identity job of the deferred gather table (runtime.ArenaManager.materialize migrates ~2,500 tensors per arena
+    rebuild).  fp32 tensors on the same GPU, src contiguous, dst contiguous or a 2-D band [rows][cols(,1,1)] of a wider matrix;
+    returns False when the pair is not of that form or nothing is being deferred (the caller copies with torch then)."""
+    if _GATHER[0] is None or dst.dtype != torch.float32 or src.dtype != torch.float32 or not dst.is_cuda or src.device != dst.device:
+        return False
+    if dst.numel() == 0:
+        return True
+    if dst.shape != src.shape or not src.is_contiguous():
+        return False
+    if dst.is_contiguous():
+        _GATHER[0].append((src, dst, None, 0, 1, 0, 1, 1, dst.numel(), 1))
+        return True
+    if dst.dim() >= 2 and all(d == 1 for d in dst.shape[2:]) and dst.stride(1) == 1:
+        rows, cols = dst.shape[0], dst.shape[1]
+        _GATHER[0].append((src, dst, None, cols, 1, dst.stride(0), 1, rows, cols, 1))
+        return True
+    return False
+
+
 def gather_by_mask(dst, src, mask, dim):
     """dst <- src[mask] (dim 0) or src[:, mask] (dim 1) on device, fp32, arbitrary strides: mask -> ascending kept-channel
     index (atomnas_mask_index), then an index-packed gather (atomnas_gather_dim).  The integer index is bit-exact with
@@ -453,13 +532,27 @@ def gather_by_mask(dst, src, mask, dim):
     if src.dtype != torch.float32 or dst.dtype != torch.float32:
         raise TypeError("gather_by_mask moves fp32 master tensors")
     n = src.shape[dim]
-    m8 = mask.to(torch.uint8).contiguous()
-    index = torch.empty(n, dtype=torch.int32, device=src.device)
-    kept = torch.zeros(1, dtype=torch.int32, device=src.device)
-    call("atomnas_mask_index", _p(m8), n, _p(index), _p(kept), _stream())
+    reg = _MASKS.get((mask.data_ptr(), mask.numel()))
+    if reg is not None:
+        index, kept = reg[1], None
+    else:
+        m8 = mask.to(torch.uint8).contiguous()
+        index = torch.empty(n, dtype=torch.int32, device=src.device)
+        kept = torch.zeros(1, dtype=torch.int32, device=src.device)
+        call("atomnas_mask_index", _p(m8), n, _p(index), _p(kept), _stream())
     n_kept = dst.shape[dim]
+    if reg is not None and reg[2] != n_kept:
+        raise ValueError("gather_by_mask: the destination keeps %d channels, the registered mask %d" % (n_kept, reg[2]))
     if n_kept == 0:
         return index, kept
+
+    def run(sv_, dv_, s_os, s_ds, d_os, d_ds, outer, inner):
+        if _GATHER[0] is not None:
+            _GATHER[0].append((sv_, dv_, index, s_os, s_ds, d_os, d_ds, outer, n_kept, inner))
+        elif index is None:
+            raise RuntimeError("identity masks are only registered for deferred gathers")
+        else:
+            call("atomnas_gather_dim", _p(sv_), _p(dv_), _p(index), s_os, s_ds, d_os, d_ds, outer, n_kept, inner, _stream())
     if dim == 0:
         inner = 1
         for s_ in src.shape[1:]:
@@ -467,7 +560,7 @@ def gather_by_mask(dst, src, mask, dim):
         sv, dv = src.reshape(n, inner) if src.is_contiguous() else None, dst.reshape(n_kept, inner) if dst.is_contiguous() else None
         if sv is None or dv is None:
             raise ValueError("dim-0 gather needs contiguous tensors")
-        call("atomnas_gather_dim", _p(sv), _p(dv), _p(index), 0, inner, 0, inner, 1, n_kept, inner, _stream())
+        run(sv, dv, 0, inner, 0, inner, 1, inner)
     elif dim == 1:
         outer = src.shape[0]
         inner = 1
@@ -477,7 +570,7 @@ def gather_by_mask(dst, src, mask, dim):
             raise ValueError("dim-1 gather of strided tensors supports trailing singleton dimensions only")
         s_os, s_ds = (src.stride(0), src.stride(1)) if inner == 1 else (src.shape[1] * inner, inner)
         d_os, d_ds = (dst.stride(0), dst.stride(1)) if inner == 1 else (dst.shape[1] * inner, inner)
-        call("atomnas_gather_dim", _p(src), _p(dst), _p(index), s_os, s_ds, d_os, d_ds, outer, n_kept, inner, _stream())
+        run(src, dst, s_os, s_ds, d_os, d_ds, outer, inner)
     else:
         raise NotImplementedError()
     return index, kept

@@ -387,13 +387,22 @@ class ArenaManager:
         name_of.update({id(b): n for n, b in model.named_buffers()})
         self.param_slots = collections.OrderedDict()
         self.buffer_slots = collections.OrderedDict()
+        # The value migration is ~2,500 small copies per rebuild (every parameter, its RMSprop state, its EMA shadow, every BatchNorm
+        # buffer): recorded and run as ONE launch of the shrink's job-table kernel (ops.copy_job -> atomnas_gather_jobs) where the pair
+        # is fp32 on this device; anything else (the first build from host tensors, int64 counters) is a torch copy as before.
+        def move(dst, src):
+            if not ops.copy_job(dst, src):
+                dst.copy_(src.to(dev))
+        was_deferring = ops.gather_deferring()
+        if not was_deferring:
+            ops.gather_defer(True)
         with torch.no_grad():
             for arena_name, mod, attr, off, shape, strides in binds:
                 if arena_name == "P":
                     p = mod._parameters[attr]
                     nm = name_of.get(id(p))
                     newv = view(newP, off, shape, strides)
-                    newv.copy_(p.data.to(dev))
+                    move(newv, p.data)
                     # optimizer state and EMA shadows follow the parameter
                     for opt in self.optimizers:
                         st = opt.state.get(p)
@@ -401,12 +410,12 @@ class ArenaManager:
                             for key, arena in (("square_avg", newSQ), ("momentum_buffer", newBUF)):
                                 if key in st and arena is not None:
                                     nv = view(arena, off, shape, strides)
-                                    nv.copy_(st[key].to(dev))
+                                    move(nv, st[key])
                                     st[key] = nv
                     for ema in self.emas:
                         if nm is not None and nm in ema._shadow:
                             nv = view(newEMA, off, shape, strides)
-                            nv.copy_(ema._shadow[nm].to(dev))
+                            move(nv, ema._shadow[nm])
                             ema._shadow[nm] = nv
                     p.data = newv
                     p.grad = view(newG, off, shape, strides)
@@ -419,11 +428,11 @@ class ArenaManager:
                     nm = name_of.get(id(b))
                     if arena_name == "S":
                         newv = view(newS, off, shape, None)
-                        newv.copy_(b.to(dev))
+                        move(newv, b)
                         for ema in self.emas:
                             if nm is not None and nm in ema._shadow:
                                 nv = view(newSEMA, off, shape, None)
-                                nv.copy_(ema._shadow[nm].to(dev))
+                                move(nv, ema._shadow[nm])
                                 ema._shadow[nm] = nv
                     else:
                         newv = newC[off:off + 1].view(shape)
@@ -432,6 +441,10 @@ class ArenaManager:
                     if nm is not None:
                         self.buffer_slots[nm] = (arena_name, off, shape)
 
+        if not was_deferring:
+            ops.gather_defer(False)   # the migration runs here (one launch), before anything reads the new arenas
+        else:
+            ops.gather_flush()
         self.P, self.G, self.S, self.CNT = newP, newG, newS, newC
         self.SQ, self.BUF, self.EMA, self.SEMA = newSQ, newBUF, newEMA, newSEMA
         self.nP, self.nS = nP, nS

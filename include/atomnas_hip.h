@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 7   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess */
+#define ATOMNAS_ABI_VERSION 8   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess; 8: + atomnas_gather_jobs */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -317,6 +317,19 @@ int atomnas_gamma_mask(const float* params, const float* ema, const void* jobs_d
 int atomnas_mask_index(const unsigned char* mask, int count, int* index, int* kept, void* stream);
 int atomnas_gather_dim(const float* src, float* dst, const int* index, long src_os, long src_ds, long dst_os, long dst_ds, int outer,
                        int n_kept, int inner, void* stream);
+/* Job-list repack: every gather of one shrink (model weights, BatchNorm vectors, RMSprop state, EMA shadows;
+ * models/compress_utils.py:31-37, utils/rmsprop.py:134-165, utils/optim.py:134-153) in ONE launch over a table in device memory.
+ * A job is atomnas_gather_dim's arguments (index == NULL: identity, a strided copy); blk0 = the job's first workgroup, ascending, one
+ * workgroup per 256 elements (outer * n_kept * inner); nblocks = the total.  Destinations must not overlap. */
+typedef struct atomnas_gather_job {
+  const float* src;
+  float* dst;
+  const int* index;
+  long src_os, src_ds, dst_os, dst_ds;
+  int outer, n_kept, inner;
+  unsigned blk0;
+} atomnas_gather_job;
+int atomnas_gather_jobs(const void* jobs_dev, int njobs, long nblocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,13 +48,24 @@ def shrink_model(model_wrapper, ema, optimizer, prune_info, threshold=1e-3, ema_
         gammas.extend(bn.weight for bn in bns)
     if ema is not None:
         ema.attach(runtime.manager_of(model))
-    all_masks = prune.alive_masks(gammas, threshold, mode=0 if ema is None else (2 if ema_only else 1))
+    from atomnas_amd import ops
+    all_masks, all_index, kept = prune.alive_masks(gammas, threshold, mode=0 if ema is None else (2 if ema_only else 1), with_index=True)
     all_masks = [m.clone() for m in all_masks]   # the arenas are rebuilt while the blocks are compressed
-    pos = 0
-    for (block_name, block), n in zip(blocks, per_block):
-        masks = all_masks[pos:pos + n]
-        pos += n
-        block.compress_by_mask(masks, ema=ema, optimizer=optimizer, prune_info=prune_info, prefix=block_name, verbose=False)
+    # Job-list repack: the masks' kept-channel indices and counts are known from that one launch (one device -> host copy for the counts);
+    # every gather of the shrink -- weights, BatchNorm vectors, RMSprop state, EMA shadows (models/compress_utils.py:31-37,
+    # utils/rmsprop.py:134-165, utils/optim.py:134-153) -- is recorded by the per-tensor protocol and runs as ONE launch at the end
+    for m, idx, k in zip(all_masks, all_index, kept.tolist() if kept is not None else []):
+        ops.register_mask(m, idx, k)
+    ops.gather_defer(True)
+    try:
+        pos = 0
+        for (block_name, block), n in zip(blocks, per_block):
+            masks = all_masks[pos:pos + n]
+            pos += n
+            block.compress_by_mask(masks, ema=ema, optimizer=optimizer, prune_info=prune_info, prefix=block_name, verbose=False)
+    finally:
+        ops.gather_defer(False)   # flush
+        ops.clear_masks()
     if optimizer is not None:
         assert set(id(p) for p in optimizer.param_groups[0]['params']) == set(id(p) for p in model.parameters())
     mc.profiling(model)
