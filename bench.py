@@ -452,6 +452,14 @@ def main():
                                avg_launch_us=round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
                                algorithmic_bytes_per_step=dom["bytes"], kernel_ms_per_step=round(dom["ms"], 3),
                                share_of_step=round(dom["ms"] / tot, 3))
+        if dom_name == "atomnas_dwconv_bwd":
+            # SURVEY 8(d) charges the depthwise backward three streams (2|x| + |y|); fused with the BatchNorm backward of the next BN and
+            # the activation mask of the previous one it MOVES four (g, yraw and x in, h out: xhat is needed where the ReLU mask is
+            # zero), so the algorithmic fraction cannot pass 3/4 of whatever the memory system streams: 0.75 of the 8 TB/s spec, 0.50
+            # of the 5.3 TB/s a 3-read-1-write probe reaches on this chip (profiles/r02_membw_probe.txt)
+            out["roofline"]["four_stream"] = dict(moved_GBps=round(ach * 4 / 3 / 1e9, 1), frac_of_peak_moved=round(ach * 4 / 3 / HBM_PEAK, 4),
+                                                  algorithmic_ceiling_at_spec_peak=0.75, algorithmic_ceiling_at_measured_3r1w=round(0.75 * 5.3e12 / HBM_PEAK, 3),
+                                                  frac_of_measured_ceiling=round((ach * 4 / 3) / 5.3e12, 4))
         # the pointwise (1x1) layers against BOTH of their rooflines -- all GEMM-type entries of the step
         pw = [a for k, a in agg.items() if k in GEMM_ENTRIES]
         pw_ms, pw_fl, pw_by = sum(a["ms"] for a in pw), sum(a["flops"] for a in pw), sum(a["bytes"] for a in pw)
@@ -464,8 +472,11 @@ def main():
         dwk = [a for k, a in agg.items() if k.startswith("atomnas_dwconv")]
         dw_ms, dw_by = sum(a["ms"] for a in dwk), sum(a["bytes"] for a in dwk)
         if dw_ms > 0:
+            bwd = agg.get("atomnas_dwconv_bwd")
+            moved = dw_by + (bwd["bytes"] / 3 if bwd else 0)   # the backward moves a fourth stream (see roofline.four_stream)
             out["depthwise"] = dict(ms_per_step=round(dw_ms, 3), algorithmic_bytes_per_step=dw_by,
-                                    GBps=round(dw_by / (dw_ms * 1e-3) / 1e9, 1), frac_hbm=round(dw_by / (dw_ms * 1e-3) / HBM_PEAK, 4))
+                                    GBps=round(dw_by / (dw_ms * 1e-3) / 1e9, 1), frac_hbm=round(dw_by / (dw_ms * 1e-3) / HBM_PEAK, 4),
+                                    moved_GBps=round(moved / (dw_ms * 1e-3) / 1e9, 1), frac_of_measured_streaming=round(moved / (dw_ms * 1e-3) / 5.3e12, 4))
         out["kernels"] = {k[8:]: dict(n=a["launches"], ms=round(a["ms"], 3), GBps=(round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["bytes"] else None))
                           for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
     if world > 1:
