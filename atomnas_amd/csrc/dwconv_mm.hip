@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
 //     (tools/probe/ldsmis.hip), so the activated input is kept twice, the second copy shifted by one element, and a fragment is
 //     four dword reads from the copy in which its start is dword aligned.  The accumulator lives across all tiles of the worker and
 //     is the worker's partial row: no cross-lane reduction at the end (the MFMA summed over the pixels).
-template <int K, int AM, int WPS>
+template <int K, int AM, int WPS, int MAXG>
 __global__ __launch_bounds__(256, WPS) void k_dwb_mm(const bf16_t* __restrict__ gup, long gss, const bf16_t* __restrict__ yraw, long yrss,
                                                   const float* __restrict__ c1, const float* __restrict__ c2p, const float* __restrict__ c3,
                                                   const bf16_t* __restrict__ x, long xss, const float* __restrict__ in_scale,
@@ -358,12 +358,12 @@ __global__ __launch_bounds__(256, WPS) void k_dwb_mm(const bf16_t* __restrict__ 
 
   // per-lane decode of the input-gradient tile groups, as in k_dwf_mm
   const int nl = lane & 15, q = lane >> 4;
-  int t_row[MM_MAXG], t_im[MM_MAXG], t_pp[MM_MAXG], t_ao[MM_MAXG];
-  unsigned t_cm[MM_MAXG];
+  int t_row[MAXG], t_im[MAXG], t_pp[MAXG], t_ao[MAXG];
+  unsigned t_cm[MAXG];
   {
     const int per_im = mg.nrp * mg.ncb;
 #pragma unroll
-    for (int G = 0; G < MM_MAXG; ++G) {
+    for (int G = 0; G < MAXG; ++G) {
       const int t = 16 * G + nl;
       const bool tv = t < mg.ntl;
       const int tc = tv ? t : 0;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, WPS) void k_dwb_mm(const bf16_t* __restrict__ 
       }
       // ---- input gradient
 #pragma unroll
-      for (int G = 0; G < MM_MAXG; ++G) {
+      for (int G = 0; G < MAXG; ++G) {
         if (G < mg.ngroups) {
           f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -735,9 +735,10 @@ static int mm_launch_bwd(const void* gup, long gss, const void* yraw, long yrss,
   if (!mm_geometry(g, mg, N, H, W, C, K, true) || !mm_bwd_wanted(g, K)) return -1;
   const size_t lds = mm_lds(g, mg, K, true);
   if (lds > max_lds_bytes()) return -1;
+  const bool two = mg.ngroups <= 2;   // row-ring tiles have at most two MFMA tile groups: the instance with two per-lane decodes (10 registers less: no spill at k = 7)
 #define MM_BWD(AMV)                                                                                                         \
   {                                                                                                                         \
-    auto kern = k_dwb_mm<K, AMV, 3>;                                                                                        \
+    auto kern = two ? k_dwb_mm<K, AMV, 3, 2> : k_dwb_mm<K, AMV, 3, MM_MAXG>;                                                                                      \
     cw_workers(g, resident_per_cu(kern, 256, lds), (stats || dw) ? part_rows : 0, 4);                                       \
     hipLaunchKernelGGL(kern, dim3(cw_grid(g, 4)), dim3(256), lds, st, (const bf16_t*)gup, gss, (const bf16_t*)yraw, yrss, c1, c2, c3, \
                        (const bf16_t*)x, xss, sc, sh, relu, w, ldw, (bf16_t*)h, hss, dw ? dw_ws : nullptr, stats, stat_ld, part_rows, g, mg); \
