@@ -215,6 +215,10 @@ int dwconv_mm_bwd(const void* gup, long gss, const void* yraw, long yrss, const 
                   float* dw, float* stats, int stat_ld, int part_rows, float* dw_ws, int N, int H, int W, int C, int k, int stride,
                   int dtype, hipStream_t st);
 int dwconv_mm_supported(int N, int H, int W, int C, int k, int dir);
+// dwconv_mm2.hip: the stride-2 forward on the matrix cores
+int dwconv_mm2_fwd(const void* x, long xss, const float* sc, const float* sh, int relu, const float* w, int ldw, void* y, long yss,
+                   float* stats, int stat_ld, int stat_rows, int N, int H, int W, int C, int k, int dtype, hipStream_t st);
+int dwconv_mm2_supported(int N, int H, int W, int C, int k);
 
 // End of one stage of an LDS-DMA ring (all of the stage's global_load_lds copies of this wave have been issued).  An assembler
 // comment, no code: tools/check_asm_waits.py models the ring as a queue of stages and checks every counted `s_waitcnt vmcnt(N)`

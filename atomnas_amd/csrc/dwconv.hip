@@ -1057,6 +1057,9 @@ extern "C" int atomnas_dwconv_fwd(const void* x, int ldx, long x_ss, const float
     if (rc >= 0) return rc;
     rc = dwconv_cw_fwd(x, x_ss, in_scale, in_shift, in_relu, w, ldw, y, y_ss, stats, stat_ld, stat_rows, N, H, W, C, k, dtype, st);
     if (rc >= 0) return rc;
+  } else {
+    const int rc = dwconv_mm2_fwd(x, x_ss, in_scale, in_shift, in_relu, w, ldw, y, y_ss, stats, stat_ld, stat_rows, N, H, W, C, k, dtype, st);
+    if (rc >= 0) return rc;
   }
   DW_DISPATCH(launch_fwd, x, ldx, x_ss, in_scale, in_shift, in_relu, w, ldw, y, ldy, y_ss, stats, stat_ld, stat_rows, N, H, W, C, st);
   return 1;

@@ -776,8 +776,9 @@ int dwconv_mm_supported(int N, int H, int W, int C, int k, int dir) {
 }  // namespace atomnas
 
 // 1 when atomnas_dwconv_fwd (dir = 0) / atomnas_dwconv_bwd (dir = 1) take the matrix-core kernels of this file for the shape (bf16
-// slab-major tensors, stride 1).  Tests build the oracle's storage model from it (oracle/atomnas_oracle.py bf16_storage_mm).
+// slab-major tensors; stride 2: the forward of dwconv_mm2.hip).  Tests build the oracle's storage model from it (oracle/atomnas_oracle.py bf16_storage_mm).
 extern "C" int atomnas_dwconv_mm_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir) {
-  if (stride != 1 || dtype != atomnas::DT_BF16) return 0;
-  return atomnas::dwconv_mm_supported(N, H, W, C, k, dir);
+  if (dtype != atomnas::DT_BF16) return 0;
+  if (stride == 2) return dir == 0 ? atomnas::dwconv_mm2_supported(N, H, W, C, k) : 0;
+  return stride == 1 ? atomnas::dwconv_mm_supported(N, H, W, C, k, dir) : 0;
 }

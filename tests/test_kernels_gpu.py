@@ -421,6 +421,45 @@ def test_dwconv_bench_shapes_against_torch(gpu_lib, H, C, k):
     assert rel(s2[0], h.sum((0, 2, 3))) < 1e-4 and rel(s2[1], (h * x4.detach()).sum((0, 2, 3))) < 1e-4
 
 
+@pytest.mark.parametrize("N,H,C,k", [(256, 112, 96, 7), (256, 112, 96, 3), (256, 56, 144, 5), (256, 28, 240, 7), (256, 14, 576, 5),
+                                     (3, 112, 16, 5), (5, 56, 24, 7), (5, 112, 40, 3), (7, 28, 20, 5), (11, 14, 40, 7), (1, 14, 8, 5)])
+def test_dwconv_stride2_forward_on_the_matrix_cores(gpu_lib, N, H, C, k):
+    """csrc/dwconv_mm2.hip: the stride-2 depthwise forward (bf16 slab-major) as a Toeplitz product on the matrix cores, at the bench's
+    sizes (many bands per worker: row ring, image starts inside a worker's walk) and at small batches (one band per worker: every
+    worker but the first of an image starts inside it; partial last image groups; channel counts that are not multiples of 16),
+    against torch's convolution in fp32: output (one bf16 rounding + the fp16 operand roundings) and the statistics of the stored
+    values.  The library must say that it takes that kernel for the shape (otherwise this test checks nothing new)."""
+    ops = _ops()
+    from atomnas_amd.ops import Slab
+    s, P, Ho = 2, (k - 1) // 2, H // 2
+    assert gpu_lib.atomnas_dwconv_mm_supported(N, H, H, C, k, 2, 1, 0) == 1
+    g = torch.Generator(device="cuda").manual_seed(N * 7 + H * 1000 + C + k)
+    rn = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    x2 = rn(N * H * H, C).bfloat16()
+    w = rn(C, 1, k, k) * 0.3
+    tp = w.reshape(C, k * k).t().contiguous()
+    sc, sh = torch.rand(C, device="cuda", generator=g) + 0.5, rn(C) * 0.3
+    rows = ops.stat_rows_for(C)
+    for relu in (True, False):
+        xs = Slab.from_plain(x2)
+        ys = Slab(N * Ho * Ho, C, torch.bfloat16, "cuda")
+        ys.t.fill_(float("nan"))
+        st = torch.full((rows, 2, C), float("nan"), device="cuda")
+        ops.dwconv_fwd(xs, sc, sh, relu, tp, ys, st, C, N, H, H, C, k, s, stat_rows=rows)
+        x4 = x2.float().reshape(N, H, H, C).permute(0, 3, 1, 2)
+        xa = x4 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        yref = F.conv2d(torch.relu(xa) if relu else xa, w, None, s, P, 1, C)
+        yp = ys.to_plain()
+        cpad = (C + 7) // 8 * 8
+        assert float(yp[:, C:cpad].float().abs().max() if cpad > C else 0) == 0.0      # padding channels of the last 8-channel group are zero
+        y = yp[:, :C].float().reshape(N, Ho, Ho, C).permute(0, 3, 1, 2)
+        assert torch.isfinite(y).all()
+        assert float((y - yref).norm() / yref.norm()) < 2.5e-3          # one bf16 rounding is 1.7e-3
+        assert float((y - yref).abs().max()) < 2e-2 * float(yref.abs().max())
+        ssum = st.sum(0)
+        assert torch.allclose(ssum[0], y.sum((0, 2, 3)), rtol=1e-4, atol=1.0) and torch.allclose(ssum[1], (y * y).sum((0, 2, 3)), rtol=1e-4, atol=1.0)
+
+
 def test_dwconv_long_tile_walks():
     """The depthwise kernels keep the halo rows of the tile above in their LDS ring when a workgroup walks down a column of
     tiles.  With the small tensors of the tests every workgroup normally gets a single tile, so the same cases are re-run
