@@ -85,8 +85,17 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
   }
   const bool ch0_ok = ch < g.C, ch1_ok = ch + 1 < g.C;
 
-  CwSlots sl;
-  cw_decode<P, NT, CGS>(sl, g, tid, cg);
+  // Tile-independent decode of the two staging slots.  A tile's pieces (8 channels of a pixel) run over (image, row, column) and are
+  // contiguous in the slab: piece tid + 256 i is 16 (tid + 256 i) elements behind the tile's first one, and the VALID pieces (rows inside
+  // the image, images inside the batch) are a prefix -- one comparison per slot; only the window offset needs the decode.
+  int x_wo[2];   // (im * RH + row) * LWp + col + P
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pp = tid + i * NT;
+    const int col = pp % g.W, t2 = pp / g.W;
+    const int rr = t2 % g.TH, im = t2 / g.TH;
+    x_wo[i] = (im * g.RH + rr) * g.LWp + col + P;
+  }
 
   // per-lane decode of the MFMA tile groups: lane (n = lane & 15, q = lane >> 4) of group G works on tile 16 G + n; as the B operand it
   // supplies patch row 2 j + (q >> 1), columns 8 (q & 1) .. + 7 of MFMA j, as the D operand it receives output row q >> 1, columns
@@ -117,22 +126,22 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
 
   float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
   piece_t pfx[2];
-  unsigned pxmask = 0;
+  int pxn = 0;   // valid pieces of the prefetched tile
 #pragma unroll
   for (int i = 0; i < 2; ++i) X::zero(pfx[i]);
 
   const int t_beg = (int)((long)worker * g.ntiles / g.nworkers), t_end = (int)((long)(worker + 1) * g.ntiles / g.nworkers);
   const long slab_x = (long)slab * xss, slab_y = (long)slab * yss;
 
-  auto issue = [&](int n0, int ho0) {   // branch-free, see k_dwb_cw
+  auto issue = [&](int n0, int ho0) {   // branch-free: invalid pieces load the tile's (or, with no valid piece at all, the slab's) first one
     const int hi_s = g.ring ? ho0 + P : 0;
-    const long px = ((long)n0 * g.H + hi_s) * g.W * 16;
-    pxmask = 0;
+    const int rows_ok = g.H - hi_s < g.TH ? g.H - hi_s : g.TH, ims_ok = g.N - n0 < g.NI ? g.N - n0 : g.NI;
+    pxn = cg_ok ? (g.ring ? rows_ok * g.W : ims_ok * g.TH * g.W) : 0;
+    const bf16_t* src = x + slab_x + (pxn > 0 ? ((long)n0 * g.H + hi_s) * g.W * 16 : 0) + cg * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool okx = sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N && hi_s + sl.rr[i] < g.H;
-      X::load(pfx[i], x + slab_x + (okx ? px + sl.goff[i] : 0));
-      pxmask |= okx ? 1u << i : 0u;
+      const int pp = tid + i * NT;
+      X::load(pfx[i], src + (pp < pxn ? (unsigned)pp * 16u : 0u));
     }
   };
   // one piece (8 channels of a pixel) -> the 8 channel planes
@@ -144,19 +153,21 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
     for (int qq = 0; qq < 4; ++qq) {
       const pair_t xq = X::pair(p, qq);
       float a0 = X::lo(xq) * q1[2 * qq] + q2[2 * qq], a1 = X::hi(xq) * q1[2 * qq + 1] + q2[2 * qq + 1];
-      a0 = mm_clamp16(cw_act(a0, in_relu, AM)); a1 = mm_clamp16(cw_act(a1, in_relu, AM));
+      a0 = cw_act(a0, in_relu, AM); a1 = cw_act(a1, in_relu, AM);
+      if (AM != ACT_RELU6) { a0 = mm_clamp16(a0); a1 = mm_clamp16(a1); }   // (ReLU6: [0, 6])
       d[(2 * qq) * g.plane] = ok ? (f16_t)a0 : (f16_t)0.f;
       d[(2 * qq + 1) * g.plane] = ok ? (f16_t)a1 : (f16_t)0.f;
     }
   };
   auto commit = [&](int base) {
+    // window row of tile row rr: (ring ? 2 P : P) + rr + base, modulo LH (ring: rr = pp / W, the rows that wrap are a suffix of the pieces)
+    const int rowbase = (g.ring ? 2 * P : P) + base;
+    const int wrap_pp = g.ring ? (g.LH - rowbase) * g.W : 0x7fffffff;
+    const int o0 = rowbase * g.LWp, o1 = o0 - g.LH * g.LWp;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (sl.pp[i] >= 0) {
-        int slot = (g.ring ? 2 * P : P) + sl.rr[i] + base;
-        if (slot >= g.LH) slot -= g.LH;
-        put_in(pfx[i], (pxmask >> i) & 1u, s_in + sl.dyo[i] + slot * g.LWp);
-      }
+      const int pp = tid + i * NT;
+      if (pp < g.TPIX) put_in(pfx[i], pp < pxn, s_in + x_wo[i] + (pp >= wrap_pp ? o1 : o0));
     }
   };
   auto halo_sync = [&](int n0, int ho0) {
@@ -171,16 +182,19 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
       put_in(a, ok, s_in + wr * g.LWp + col + P);
     }
   };
-  auto store_y = [&](int n0, int ho0) {
-    const long py = ((long)n0 * g.H + ho0) * g.W * 16;
+  auto store_y = [&](int n0, int ho0) {   // the tile's output pieces are contiguous in the slab as well
+    const int rows_ok = g.H - ho0 < g.TH ? g.H - ho0 : g.TH, ims_ok = g.N - n0 < g.NI ? g.N - n0 : g.NI;
+    const int nv = cg_ok ? (g.ring ? rows_ok * g.W : ims_ok * g.TH * g.W) : 0;
+    bf16_t* dst = y + slab_y + ((long)n0 * g.H + ho0) * g.W * 16 + cg * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (sl.pp[i] >= 0 && cg_ok && n0 + sl.im[i] < g.N && ho0 + sl.rr[i] < g.H) {
+      const int pp = tid + i * NT;
+      if (pp < nv) {
         piece_t v;
-        const pair_t* sy_ = s_y + sl.pp[i];
+        const pair_t* sy_ = s_y + pp;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) X::set_pair(v, qq, sy_[qq * g.TPIXp]);
-        X::store(v, y + slab_y + py + sl.goff[i]);
+        X::store(v, dst + (unsigned)pp * 16u);
       }
     }
   };
@@ -218,7 +232,6 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
     const int n0 = nb * g.NI, ho0 = ty * g.TH;
     const bool fresh = g.ring && (tile == t_beg || ty == 0);
     if (fresh) base = 0;
-    asm volatile("" : "+v"(sl.goff[0]), "+v"(sl.goff[1]), "+v"(sl.pp[0]), "+v"(sl.pp[1]), "+v"(sl.dyo[0]), "+v"(sl.dyo[1]));   // see k_dwb_cw
     __syncthreads();   // (A) previous tile consumed, its output complete in s_y
     X::touch(pfx[0]); X::touch(pfx[1]);   // see k_dwb_cw
     if (pn0 >= 0) store_y(pn0, pho0);
@@ -234,15 +247,19 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
       for (int G = 0; G < MM_MAXG; ++G) {
         if (G < mg.ngroups) {
           f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+          f16x8 b0[NJ], b1[NJ];   // all B fragments of the group first: the reads overlap instead of a read -> MFMA chain per j
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             int r = t_row[G] + 2 * j + base;
             if (r >= g.LH) r -= g.LH;
             const f16_t* bp = in0 + t_ao[G] + r * g.LWp;
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(bp);
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(bp + g.plane);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta0[j], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta1[j], b1, acc1, 0, 0, 0);
+            b0[j] = *reinterpret_cast<const f16x8*>(bp);
+            b1[j] = *reinterpret_cast<const f16x8*>(bp + g.plane);
+          }
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta0[j], b0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta1[j], b1[j], acc1, 0, 0, 0);
           }
           const bool ok = n0 + t_im[G] < g.N && ho0 + t_row[G] < g.H;
           const unsigned cm = ok ? t_cm[G] : 0u;

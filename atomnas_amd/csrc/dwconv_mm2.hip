@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm2(const bf16_t* __restrict__
     const int hi_s = g.ring ? 2 * hd0 - P + HALO : 0;
     const int rows_ok = g.H - hi_s < g.TH ? g.H - hi_s : g.TH, ims_ok = g.N - n0 < g.NI ? g.N - n0 : g.NI;
     pxn = cg_ok ? (g.ring ? rows_ok * g.W : ims_ok * g.TH * g.W) : 0;
-    const bf16_t* src = x + slab_x + ((long)n0 * g.H + hi_s) * g.W * 16 + cg * 8;
+    const bf16_t* src = x + slab_x + (pxn > 0 ? ((long)n0 * g.H + hi_s) * g.W * 16 : 0) + cg * 8;   // (no valid piece: the slab's first one)
 #pragma unroll
     for (int i = 0; i < M2_XS; ++i) {
       const int pp = tid + i * NT;
