@@ -89,8 +89,8 @@ int atomnas_dwconv_bwd(const void* g, int ldg, long g_ss, const void* yraw, int 
  *   either way; a query for tests and launch-geometry tools. */
 int atomnas_dwconv_cw_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir);
 
-/* 1 when they run the matrix-core kernels (csrc/dwconv_mm.hip: bf16, stride 1, slab-major tensors; the tap arithmetic as MFMAs
- *   against a Toeplitz operand of the taps) for this shape; dir: 0 forward, 1 backward.  Those kernels round the MFMA operands
+/* 1 when they run the matrix-core kernels (csrc/dwconv_mm.hip: bf16, stride 1, slab-major tensors; csrc/dwconv_mm2.hip: the stride-2
+ *   forward; the tap arithmetic as MFMAs against a Toeplitz operand of the taps) for this shape; dir: 0 forward, 1 backward.  Those kernels round the MFMA operands
  *   (forward: activated input and taps to fp16; backward: the gradient of the raw output, the taps and the activated input to bf16),
  *   which oracle/atomnas_oracle.py restates where this query says so (bf16_storage_mm). */
 int atomnas_dwconv_mm_supported(int N, int H, int W, int C, int k, int stride, int dtype, int dir);

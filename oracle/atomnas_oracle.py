@@ -65,7 +65,7 @@ class Bf16Storage:
 
 
 class _DwMatrixCore(torch.autograd.Function):
-    """The depthwise convolution as atomnas_amd/csrc/dwconv_mm.hip computes it in bf16 storage mode (tap arithmetic on the matrix
+    """The depthwise convolution as atomnas_amd/csrc/dwconv_mm.hip (stride 2 forward: dwconv_mm2.hip) computes it in bf16 storage mode (tap arithmetic on the matrix
     cores), restated: forward operands -- the activated input, clamped to the fp16 range, and the taps -- rounded to fp16, fp32
     accumulation; backward (where the backward kernel of that file runs): the gradient of the raw output and the taps rounded to bf16
     for the input gradient, the gradient and the activated input rounded to bf16 for the weight gradient.  The operation itself is

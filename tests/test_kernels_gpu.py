@@ -515,8 +515,16 @@ def test_dwconv_slab_layout_is_bit_identical_to_plain(gpu_lib, dtype, k, stride,
     # stride 2: the slab-major backward of a supported shape runs the channel-pair kernel (csrc/dwconv_cw.hip, other FMA order), the
     # plain one the tile kernel: the input gradient then agrees to rounding of the bf16 result, not bit for bit
     cw_bwd = stride == 2 and _cw_supported(N, H, W, C, k, dtype, 1, stride=2)
+    # ... and the slab-major bf16 forward of a supported stride-2 shape runs on the matrix cores (csrc/dwconv_mm2.hip: fp16 operands):
+    # output and its statistics agree to the operand roundings
+    mm_fwd = stride == 2 and dtype == torch.bfloat16 and gpu_lib.atomnas_dwconv_mm_supported(N, H, W, C, k, 2, 1, 0) == 1
     for i, (a, b) in enumerate(zip(*res)):
-        if i == 1 and cw_bwd:
+        if i == 0 and mm_fwd:
+            assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2 * float(b.float().abs().max()))
+            assert float((a != b).float().mean()) < 0.2
+        elif i == 2 and mm_fwd:
+            assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max())), (i, float((a - b).abs().max()))
+        elif i == 1 and cw_bwd:
             if dtype == torch.bfloat16:
                 assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2 * float(b.float().abs().max()))
                 assert float((a != b).float().mean()) < 0.2
