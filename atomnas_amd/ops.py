@@ -37,7 +37,9 @@ def _rows(stats, stat_rows):
     return stats.shape[0]
 
 
-_TN_WS_FLOATS = int(os.environ.get("ATOMNAS_TN_WS_MB", "32")) << 18   # experiment switch: cap of the partial-output scratch
+# cap of the partial-output scratch of the weight-gradient GEMM (MiB).  The scratch bounds the number of row chunks = workgroups per
+# output tile: 64 MiB measured 27.62 / 27.78 ms per step against 27.84 / 28.01 at 32 (two boxes, round 5), 16: 28.46, 128 / 256: as 64
+_TN_WS_FLOATS = int(os.environ.get("ATOMNAS_TN_WS_MB", "64")) << 18
 
 
 # ---- deferred fixed-order reductions (csrc/reduce.hip): while on, the weight-gradient kernels leave their per-workgroup partials in
@@ -76,7 +78,7 @@ def _keep(ws):
 
 
 def tn_workspace(nu, nv, dev):
-    """scratch for the per-row-chunk partial outputs of atomnas_pw_gemm_tn (at most 32 MiB)"""
+    """scratch for the per-row-chunk partial outputs of atomnas_pw_gemm_tn (at most 64 MiB)"""
     return torch.empty(max(2 * nu * nv, min(256 * nu * nv, _TN_WS_FLOATS)), dtype=torch.float32, device=dev)
 
 
