@@ -155,6 +155,27 @@ ACT_TAP = None
 def _tap(kind, pl, raw, st):
     if ACT_TAP is not None and st is not None:
         ACT_TAP.append((kind, pl, raw, st.scale, st.shift))
+
+
+# set to a list by tests to receive (name, tensor) for every intermediate an executor produces in a step: activations, gradients,
+# BatchNorm coefficients ("<plan>.<bn>.invstd" etc.) -- tests/test_bench_shapes_gpu.py checks them for finiteness at the bench's sizes
+STEP_TAP = None
+
+
+def _stap(pl, **tensors):
+    if STEP_TAP is not None:
+        for what, t in tensors.items():
+            if t is None:
+                continue
+            if isinstance(t, BNState):
+                for f in ("scale", "shift", "mean", "invstd"):
+                    if getattr(t, f) is not None:
+                        STEP_TAP.append(("%s.%s.%s" % (pl.name, what, f), getattr(t, f)))
+            elif isinstance(t, (tuple, list)):
+                for q, u in enumerate(t):
+                    STEP_TAP.append(("%s.%s%d" % (pl.name, what, q + 1), u))
+            else:
+                STEP_TAP.append(("%s.%s" % (pl.name, what), t))
 _CHECK_LOSS_SEED = bool(int(os.environ.get("ATOMNAS_CHECK_LOSS_SEED", "0")))   # experiment switch (same-box A/B of the two layouts)
 
 
@@ -221,6 +242,7 @@ def block_forward(pl, x2d, N, H, W, need_grad):
     bP = bn_forward_coeffs(pl.bnp, stP, M2, dev)
     out = torch.empty(M2, pl.oup, dtype=T, device=dev)
     ops.bn_apply(Pr, bP.scale, bP.shift, False, x2d if pl.res else None, out, M2, pl.oup)
+    _stap(pl, E=E if pl.expand else None, bne=bE, D=D, bnd=bD, P=Pr, bnp=bP, out=out)
     if need_grad:
         sv = dict(x=x2d, E=E, D=D, P=Pr, bE=bE, bD=bD, bP=bP, dims=(N, H, W, Ho, Wo), se=se)
         return out, sv
@@ -312,11 +334,13 @@ def block_backward(pl, sv, G):
                 raise NotImplementedError("non-expanding block with more than one branch")
             ops.dwconv_bwd(_seg(g, o), _seg(D, o), d1[o:], d2[o:], d3[o:], E, None, None, 0, pl.taps[i], h, pl.Wd_grad[i], None, 0, N, H,
                            W, c, pl.ks[i], s)
+    _stap(pl, p=(p1, p2, p3), dP=dP, g=g, d=(d1, d2, d3), h=h)
     if not pl.expand:
         if pl.res:
             h = h + G
         return h
     e1, e2, e3 = bn_backward_coeffs(pl.bne, bE, st2E, M, dev)
+    _stap(pl, e=(e1, e2, e3))
     Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
     if (T == torch.bfloat16 and not pl.fused and pl.inp <= min(_EXPAND_BWD_NOE, 64) and pl.inp % 8 == 0 and x2d.stride(0) % 8 == 0):   # atomnas_gram: inp <= 64, row pitch % 8
         return _expand_backward_noe(pl, x2d, h, e1, e2, e3, G if pl.res else None, Gx, M, HT, dev, T)
@@ -401,6 +425,7 @@ class BlockFunction(torch.autograd.Function):
         G, _ = to_2d(gout, pl.mgr.compute_dtype)
         N, H, W, _, _ = sv["dims"]
         gx = block_backward(pl, sv, G)
+        _stap(pl, gx=gx)
         ctx.sv = None
         pl.mgr.grad_done(pl)
         return to_4d(gx, N, H, W, pl.inp), None, None
@@ -528,6 +553,7 @@ def convbn_forward(pl, x, need_grad):
         _tap("convbn", pl, Y, b)
     out = torch.empty(M, Cp, dtype=T, device=dev)
     ops.bn_apply(Y, b.scale, b.shift, int(act), None, out, M, pl.cout)
+    _stap(pl, Y=Y, bn=b, out=out)
     if need_grad:
         sv.update(a=a2d, Y=Y, b=b, dims=(N, H, W, Ho, Wo), K=K if sv["kind"] != "dw" else 0)
     return out, (N, Ho, Wo), sv
@@ -543,6 +569,7 @@ def convbn_backward(pl, sv, G, need_input_grad):
     st2 = _stats(pl.cout, dev, pl.bn["mgr"])
     ops.act_bwd_stats(G, Y, b.scale if act else None, b.shift if act else None, int(act), g, st2.t, M, pl.cout, stat_rows=st2.rows)
     c1, c2, c3 = bn_backward_coeffs(pl.bn, b, st2, M, dev)
+    _stap(pl, g=g, c=(c1, c2, c3))
     if sv["kind"] == "dw":
         h = ops.zeros(N * H * W, pad8(pl.cout), dtype=T, device=dev)
         ops.dwconv_bwd(g, Y, c1, c2, c3, a2d, None, None, 0, pl.taps, h, pl.W_grad, None, 0, N, H, W, pl.cout, pl.k, pl.stride)
@@ -614,6 +641,7 @@ def tail_forward(lp, fp, x, drop_p, training, seed, step_ptr, need_grad):
     Kc = fp.cout
     logits = torch.empty(N, pad8(Kc), dtype=torch.float32, device=dev)
     ops.gemm_nt(pooled, fp.W_pack, logits, N, Kc, fp.cin, bias=fp.bias)
+    _stap(lp, L=L, bn=b, pooled=pooled, logits=logits[:, :Kc])
     sv = None
     if need_grad:
         sv = dict(a=a2d, L=L, b=b, pooled=pooled, keep=keep, p=p, dims=(N, H, W))
@@ -650,6 +678,7 @@ def tail_backward(lp, fp, sv, dlogits, dl_padded=None):
     ops.gemm_tn(sv["a"], lp.cin, gL, lp.cout, lp.W_grad, 1, lp.cin, M, v_mode=PRO_BNBWD, v2=L, vc1=c1, vc2=c2, vc3=c3)
     Gx = torch.empty(M, lp.cin, dtype=T, device=dev)
     ops.gemm_nt(gL, lp.WT_pack, Gx, M, lp.cin, lp.cout, a_mode=PRO_BNBWD, a2=L, ac1=c1, ac2=c2, ac3=c3)
+    _stap(lp, dpooled=dpooled, gL=gL, c=(c1, c2, c3), gx=Gx)
     return Gx
 
 

@@ -28,16 +28,16 @@ class _build_on(object):
         self.dev = torch.device(device)
 
     def __enter__(self):
+        self.ctx = self.dev
+        self.ctx.__enter__()   # first: if the device context cannot be entered nothing has been patched yet
         self.saved = (nn.Conv2d.reset_parameters, nn.modules.batchnorm._NormBase.reset_parameters)
         nn.Conv2d.reset_parameters = lambda self_: None
         nn.modules.batchnorm._NormBase.reset_parameters = lambda self_: None
-        self.ctx = self.dev
-        self.ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
-        self.ctx.__exit__(*exc)
         nn.Conv2d.reset_parameters, nn.modules.batchnorm._NormBase.reset_parameters = self.saved
+        self.ctx.__exit__(*exc)
         return False
 
 

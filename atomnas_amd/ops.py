@@ -17,6 +17,25 @@ STAT_NONE, STAT_SQ, STAT_Z = 0, 1, 2
 HYP_LR, HYP_RHO, HYP_EMA_DECAY, HYP_GRAD_SCALE = 0, 1, 2, 3
 
 
+# Launch recorder (tools/make_bench_shapes.py -> tests/golden/bench_shapes.json -> tests/test_bench_shapes_gpu.py): when RECORD is a
+# list every wrapper below appends a dict that names its entry point and everything that selects a kernel instance or a launch geometry
+# (sizes, prologue / epilogue / statistics modes, layouts, pitches, workspace sizes) -- no pointers, no data.
+RECORD = None
+
+
+def _lay(t):
+    """layout descriptor of an activation argument: None (absent), "slab" or the row pitch of a plain tensor"""
+    if t is None:
+        return None
+    return "slab" if isinstance(t, Slab) else int(t.stride(0))
+
+
+def _rec(entry, **kw):
+    if RECORD is not None:
+        kw["entry"] = entry
+        RECORD.append(kw)
+
+
 def stat_rows_for(c):
     """Partial rows of a statistics buffer [rows][2][c] (include/atomnas_hip.h): every producing workgroup owns one row, so
     more rows allow more concurrent workgroups; few-channel tensors (one or two channel slabs) need the most."""
@@ -179,6 +198,8 @@ def dwconv_fwd(x, in_scale, in_shift, in_relu, w_taps, y, stats, stat_ld, N, H, 
     _chk_cuda(x, y, w_taps)
     if _lib.PROFILE is not None:
         _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
+    _rec("dwconv_fwd", N=N, H=H, W=W, C=C, k=k, stride=stride, x=_lay(x), y=_lay(y), fused_in=in_scale is not None, act=int(in_relu),
+         ldw=int(w_taps.stride(0)), stats=stats is not None, stat_ld=int(stat_ld), stat_rows=_rows(stats, stat_rows), dt=dt_code(x.dtype))
     call("atomnas_dwconv_fwd", _p(x), _ld(x), _ss(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(y),
          _ld(y), _ss(y), _p(stats), stat_ld, _rows(stats, stat_rows), N, H, W, C, k, stride, dt_code(x.dtype), _stream())
 
@@ -193,6 +214,9 @@ def dwconv_bwd(g, yraw, c1, c2, c3, x, in_scale, in_shift, in_relu, w_taps, h, d
     _keep(dw_ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("N%d H%d C%d k%d s%d" % (N, H, C, k, stride))
+    _rec("dwconv_bwd", N=N, H=H, W=W, C=C, k=k, stride=stride, g=_lay(g), yraw=_lay(yraw), x=_lay(x), h=_lay(h), fused_in=in_scale is not None,
+         act=int(in_relu), ldw=int(w_taps.stride(0)), dw=dw is not None, stats=stats is not None, stat_ld=int(stat_ld), part_rows=int(rows),
+         dt=dt_code(x.dtype))
     call("atomnas_dwconv_bwd", _p(g), _ld(g), _ss(g), _p(yraw), _ld(yraw) if yraw is not None else 0, _ss(yraw), _p(c1), _p(c2), _p(c3),
          _p(x), _ld(x), _ss(x), _p(in_scale), _p(in_shift), int(in_relu), _p(w_taps), w_taps.stride(0), _p(h), _ld(h), _ss(h), _p(dw),
          _p(stats), stat_ld, rows,
@@ -206,11 +230,13 @@ def gram(x, M, inp, gram_out, sx_out, ws=None):
         ws = torch.empty(2048 * (inp * inp + inp), dtype=torch.float32, device=x.device)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d inp%d" % (M, inp))
+    _rec("gram", M=int(M), inp=int(inp), x=_lay(x), ws_floats=int(ws.numel()), dt=dt_code(x.dtype))
     call("atomnas_gram", _p(x), _ld(x), M, inp, _p(ws), ws.numel(), _p(gram_out), _p(sx_out), dt_code(x.dtype), _stream())
 
 
 def xb_coeffs(c2, c3, wexp, gram, sx, inp, C, mp, vb, dwe):
     """inp x inp sized corrections of the expand backward without E (include/atomnas_hip.h)"""
+    _rec("xb_coeffs", inp=int(inp), C=int(C), ldwe=int(wexp.stride(0)), ldm=int(mp.stride(0)))
     call("atomnas_xb_coeffs", _p(c2), _p(c3), _p(wexp), wexp.stride(0), _p(gram), inp, _p(sx), inp, C, _p(mp), mp.stride(0), _p(vb), _p(dwe),
          _stream())
 
@@ -221,6 +247,9 @@ def gemm_nt(a, wp, c, M, N, K, a_mode=PRO_NONE, a2=None, ac1=None, ac2=None, ac3
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d pro%d st%d%s%s" % (M, N, K, a_mode, stat_mode, "+add" if add is not None else "", "+mask" if mask else ""))
     out_f32 = 1 if (c.dtype == torch.float32 and a.dtype != torch.float32) else 0
+    _rec("pw_gemm_nt", M=int(M), N=int(N), K=int(K), a_mode=int(a_mode), a=_lay(a), a2=_lay(a2), a_relu=int(a_relu), ldw=int(wp.stride(0)), c=_lay(c),
+         out_f32=out_f32, add=_lay(add), z=_lay(z), mask=int(mask), bias=bias is not None, stat_mode=int(stat_mode) if stats is not None else 0,
+         stat_rows=_rows(stats, stat_rows), dt=dt_code(a.dtype))
     call("atomnas_pw_gemm_nt", a_mode, _p(a), _ld(a), _ss(a), _p(a2), _ld(a2) if a2 is not None else 0, _ss(a2), _p(ac1), _p(ac2), _p(ac3),
          int(a_relu), _p(wp), wp.stride(0), _p(c), _ld(c), _ss(c), out_f32, _p(add), _ld(add) if add is not None else 0, _p(z),
          _ld(z) if z is not None else 0, _ss(z), _p(zscale), _p(zshift), int(mask), _p(bias), _p(stats), stat_mode, _rows(stats, stat_rows),
@@ -238,6 +267,8 @@ def gemm_tn(u, NU, v, NV, out, si, sj, M, u_mode=PRO_NONE, u2=None, uc1=None, uc
     _keep(ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d NU%d NV%d pro%d,%d" % (M, NU, NV, u_mode, v_mode))
+    _rec("pw_gemm_tn", M=int(M), NU=int(NU), NV=int(NV), u_mode=int(u_mode), u=_lay(u), u2=_lay(u2), u_relu=int(u_relu), v_mode=int(v_mode), v=_lay(v),
+         v2=_lay(v2), v_relu=int(v_relu), si=int(si), sj=int(sj), ws_floats=int(ws.numel()) if ws is not None else 0, dt=dt_code(u.dtype))
     call("atomnas_pw_gemm_tn", u_mode, _p(u), _ld(u), _ss(u), _p(u2), _ld(u2) if u2 is not None else 0, _ss(u2), _p(uc1), _p(uc2), _p(uc3),
          int(u_relu), NU, v_mode, _p(v), _ld(v), _ss(v), _p(v2), _ld(v2) if v2 is not None else 0, _ss(v2), _p(vc1), _p(vc2), _p(vc3), int(v_relu),
          NV, _p(out), si, sj, M, _p(ws), ws.numel() if ws is not None else 0, dt_code(u.dtype), _stream())
@@ -262,6 +293,8 @@ def expand_bwd(h, e, c1, c2, c3, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None,
     _keep(ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d fusedbwd" % (M, inp, hid))
+    _rec("expand_bwd", M=int(M), inp=int(inp), hid=int(hid), h=_lay(h), e=_lay(e), x=_lay(x), ldw=int(ldw), add=_lay(add), gx=_lay(gx), ws_floats=int(ws.numel()),
+         mp=mp is not None, ldm=int(mp.stride(0)) if mp is not None else 0, vb=vb is not None, dt=dt_code(x.dtype))
     call("atomnas_expand_bwd", _p(h), _ld(h), _ss(h), _p(e), _ld(e) if e is not None else 0, _ss(e), _p(c1), _p(c2), _p(c3), _p(x), _ld(x), _p(wt), ldw,
          _p(add), _ld(add) if add is not None else 0, _p(gx), _ld(gx), _p(dwe), _p(ws), ws.numel(), _p(mp), mp.stride(0) if mp is not None else 0,
          _p(vb), M, inp, hid, dt_code(x.dtype), _stream())
@@ -287,6 +320,8 @@ def project_bwd(g, p, c1, c2, c3, wpt_pack, z, zscale, zshift, act, gh, stats, d
     _keep(ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d fusedbwd%s" % (M, hid, oup, "" if p is not None else "+dP"))
+    _rec("project_bwd", M=int(M), oup=int(oup), hid=int(hid), g=_lay(g), p=_lay(p), ldw=int(wpt_pack.stride(0)), z=_lay(z), act=int(act), gh=_lay(gh),
+         stat_rows=_rows(stats, stat_rows), si=int(si), sj=int(sj), ws_floats=int(ws.numel()), dt=dt_code(g.dtype))
     call("atomnas_project_bwd", _p(g), _ld(g), _p(p), _ld(p) if p is not None else 0, _p(c1), _p(c2), _p(c3), _p(wpt_pack), wpt_pack.stride(0), _p(z), _ld(z), _ss(z),
          _p(zscale), _p(zshift), int(act), _p(gh), _ld(gh), _ss(gh), _p(stats), _rows(stats, stat_rows), _p(dwp), si, sj, _p(ws), ws.numel(),
          M, oup, hid, dt_code(g.dtype), _stream())
@@ -294,6 +329,8 @@ def project_bwd(g, p, c1, c2, c3, wpt_pack, z, zscale, zshift, act, gh, stats, d
 
 def bn_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, save_mean,
                     save_invstd, C, stat_rows=None, stat_ld=None, cmap=None):
+    _rec("bn_finalize_fwd", C=int(C), stat_rows=_rows(stats, stat_rows), stat_ld=int(pad8(C) if stat_ld is None else stat_ld), count=float(count),
+         momentum=-1.0 if momentum is None else float(momentum), running=running_mean is not None, cmap=cmap is not None)
     call("atomnas_bn_finalize_fwd", _p(stats), _rows(stats, stat_rows), pad8(C) if stat_ld is None else stat_ld, float(count), _p(gamma), _p(beta), eps,
          -1.0 if momentum is None else momentum,
          _p(running_mean), _p(running_var), _p(nbt), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), C, _p(cmap), _stream())
@@ -305,12 +342,15 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, scale, shift, C,
 
 def bn_finalize_bwd(stats2, count, gamma, save_mean, save_invstd, rho_ptr, penalty, dgamma, dbeta, c1, c2, c3, C, stat_rows=None,
                     stat_ld=None, cmap=None):
+    _rec("bn_finalize_bwd", C=int(C), stat_rows=_rows(stats2, stat_rows), stat_ld=int(pad8(C) if stat_ld is None else stat_ld), count=float(count),
+         cmap=cmap is not None)
     call("atomnas_bn_finalize_bwd", _p(stats2), _rows(stats2, stat_rows), pad8(C) if stat_ld is None else stat_ld, float(count), _p(gamma), _p(save_mean), _p(save_invstd),
          _p(rho_ptr), _p(penalty),
          _p(dgamma), _p(dbeta), _p(c1), _p(c2), _p(c3), C, _p(cmap), _stream())
 
 
 def bn_apply(x, scale, shift, relu, res, y, M, C):
+    _rec("bn_apply", M=int(M), C=int(C), x=_lay(x), act=int(relu), res=_lay(res), y=_lay(y), dt=dt_code(x.dtype))
     call("atomnas_bn_apply", _p(x), _ld(x), _p(scale), _p(shift), int(relu), _p(res), _ld(res) if res is not None else 0, _p(y),
          _ld(y), M, C, dt_code(x.dtype), _stream())
 
@@ -318,20 +358,26 @@ def bn_apply(x, scale, shift, relu, res, y, M, C):
 def bnbwd_apply(g, x, c1, c2, c3, y, M, C):
     """y = c1*g + c2*x + c3 (plain [M, C] tensors): the differentiated BatchNorm output, materialised once"""
     _chk_cuda(g, x, y)
+    _rec("bnbwd_apply", M=int(M), C=int(C), g=_lay(g), x=_lay(x), y=_lay(y), dt=dt_code(g.dtype))
     call("atomnas_bnbwd_apply", _p(g), _ld(g), _p(x), _ld(x), _p(c1), _p(c2), _p(c3), _p(y), _ld(y), M, C, dt_code(g.dtype), _stream())
 
 
 def bn_act_pool(x, scale, shift, relu, pooled, keep, drop_p, seed, step_ptr, N, HW, C):
+    _rec("bn_act_pool", N=int(N), HW=int(HW), C=int(C), x=_lay(x), act=int(relu), drop_p=float(drop_p), keep=keep is not None, dt=dt_code(x.dtype))
     call("atomnas_bn_act_pool", _p(x), _ld(x), _p(scale), _p(shift), int(relu), _p(pooled), _ld(pooled), _p(keep), float(drop_p),
          int(seed) & 0xFFFFFFFFFFFFFFFF, _p(step_ptr), N, HW, C, dt_code(x.dtype), _stream())
 
 
 def pool_act_bwd(dpooled, keep, drop_p, x, scale, shift, relu, g, stats2, N, HW, C, stat_rows=None):
+    _rec("pool_act_bwd", N=int(N), HW=int(HW), C=int(C), x=_lay(x), act=int(relu), drop_p=float(drop_p), keep=keep is not None,
+         stat_rows=_rows(stats2, stat_rows), dt=dt_code(x.dtype))
     call("atomnas_pool_act_bwd", _p(dpooled), _ld(dpooled), _p(keep), float(drop_p), _p(x), _ld(x), _p(scale), _p(shift), int(relu),
          _p(g), _ld(g), _p(stats2), _rows(stats2, stat_rows), N, HW, C, dt_code(x.dtype), _stream())
 
 
 def act_bwd_stats(dy, z, scale, shift, relu, g, stats2, M, C, stat_rows=None):
+    _rec("act_bwd_stats", M=int(M), C=int(C), dy=_lay(dy), z=_lay(z), masked=scale is not None, act=int(relu), g=_lay(g), stat_rows=_rows(stats2, stat_rows),
+         dt=dt_code(dy.dtype))
     call("atomnas_act_bwd_stats", _p(dy), _ld(dy), _p(z), _ld(z), _p(scale), _p(shift), int(relu), _p(g),
          _ld(g) if g is not None else 0, _p(stats2), _rows(stats2, stat_rows), M, C, dt_code(dy.dtype), _stream())
 
@@ -375,17 +421,20 @@ def se_bwd_apply(ds, d, scale, shift, act, gate, dpooled, g, stats2, M, HW, C, s
 
 def im2col_stem(img, col, N, H, W):
     assert img.dtype == torch.float32 and img.is_contiguous()
+    _rec("im2col_stem", N=int(N), H=int(H), W=int(W), col=_lay(col), dt=dt_code(col.dtype))
     call("atomnas_im2col_stem", _p(img), _p(col), _ld(col), N, H, W, dt_code(col.dtype), _stream())
 
 
 def ce_smooth(logits, target, eps, B, K, loss_per_sample, dlogits, gscale, topk):
     assert logits.dtype == torch.float32 and target.dtype == torch.int64
+    _rec("ce_smooth", B=int(B), K=int(K), ldl=_lay(logits), dl=_lay(dlogits), dt=dt_code(dlogits.dtype) if dlogits is not None else 0)
     call("atomnas_ce_smooth", _p(logits), _ld(logits), _p(target), float(eps), B, K, _p(loss_per_sample), _p(dlogits),
          _ld(dlogits) if dlogits is not None else 0, float(gscale), _p(topk),
          dt_code(dlogits.dtype) if dlogits is not None else 0, _stream())
 
 
 def colsum(x, out, M, C):
+    _rec("colsum", M=int(M), C=int(C), x=_lay(x), dt=dt_code(x.dtype))
     call("atomnas_colsum", _p(x), _ld(x), _p(out), M, C, dt_code(x.dtype), _stream())
 
 

@@ -393,58 +393,66 @@ class ArenaManager:
         def move(dst, src):
             if not ops.copy_job(dst, src):
                 dst.copy_(src.to(dev))
+        # A rebuild inside a deferral window (a forward, profiling pass or optimizer call between a shrink's gathers and their flush):
+        # the pending gathers WRITE the module tensors the migration below READS, and one job-table launch has no order between its
+        # workgroups -- run them first.  The migration's own jobs are flushed before anything reads the new arenas, and the deferral
+        # state is restored even when the walk raises.
         was_deferring = ops.gather_deferring()
-        if not was_deferring:
+        if was_deferring:
+            ops.gather_flush()
+        else:
             ops.gather_defer(True)
-        with torch.no_grad():
-            for arena_name, mod, attr, off, shape, strides in binds:
-                if arena_name == "P":
-                    p = mod._parameters[attr]
-                    nm = name_of.get(id(p))
-                    newv = view(newP, off, shape, strides)
-                    move(newv, p.data)
-                    # optimizer state and EMA shadows follow the parameter
-                    for opt in self.optimizers:
-                        st = opt.state.get(p)
-                        if st:
-                            for key, arena in (("square_avg", newSQ), ("momentum_buffer", newBUF)):
-                                if key in st and arena is not None:
-                                    nv = view(arena, off, shape, strides)
-                                    move(nv, st[key])
-                                    st[key] = nv
-                    for ema in self.emas:
-                        if nm is not None and nm in ema._shadow:
-                            nv = view(newEMA, off, shape, strides)
-                            move(nv, ema._shadow[nm])
-                            ema._shadow[nm] = nv
-                    p.data = newv
-                    p.grad = view(newG, off, shape, strides)
-                    p._atomnas_off = off
-                    p._atomnas_mgr = self
-                    if nm is not None:
-                        self.param_slots[nm] = (off, shape, strides)
-                else:
-                    b = mod._buffers[attr]
-                    nm = name_of.get(id(b))
-                    if arena_name == "S":
-                        newv = view(newS, off, shape, None)
-                        move(newv, b)
+        try:
+            with torch.no_grad():
+                for arena_name, mod, attr, off, shape, strides in binds:
+                    if arena_name == "P":
+                        p = mod._parameters[attr]
+                        nm = name_of.get(id(p))
+                        newv = view(newP, off, shape, strides)
+                        move(newv, p.data)
+                        # optimizer state and EMA shadows follow the parameter
+                        for opt in self.optimizers:
+                            st = opt.state.get(p)
+                            if st:
+                                for key, arena in (("square_avg", newSQ), ("momentum_buffer", newBUF)):
+                                    if key in st and arena is not None:
+                                        nv = view(arena, off, shape, strides)
+                                        move(nv, st[key])
+                                        st[key] = nv
                         for ema in self.emas:
                             if nm is not None and nm in ema._shadow:
-                                nv = view(newSEMA, off, shape, None)
+                                nv = view(newEMA, off, shape, strides)
                                 move(nv, ema._shadow[nm])
                                 ema._shadow[nm] = nv
+                        p.data = newv
+                        p.grad = view(newG, off, shape, strides)
+                        p._atomnas_off = off
+                        p._atomnas_mgr = self
+                        if nm is not None:
+                            self.param_slots[nm] = (off, shape, strides)
                     else:
-                        newv = newC[off:off + 1].view(shape)
-                        newv.copy_(b.to(dev))
-                    mod._buffers[attr] = newv
-                    if nm is not None:
-                        self.buffer_slots[nm] = (arena_name, off, shape)
+                        b = mod._buffers[attr]
+                        nm = name_of.get(id(b))
+                        if arena_name == "S":
+                            newv = view(newS, off, shape, None)
+                            move(newv, b)
+                            for ema in self.emas:
+                                if nm is not None and nm in ema._shadow:
+                                    nv = view(newSEMA, off, shape, None)
+                                    move(nv, ema._shadow[nm])
+                                    ema._shadow[nm] = nv
+                        else:
+                            newv = newC[off:off + 1].view(shape)
+                            newv.copy_(b.to(dev))
+                        mod._buffers[attr] = newv
+                        if nm is not None:
+                            self.buffer_slots[nm] = (arena_name, off, shape)
 
-        if not was_deferring:
-            ops.gather_defer(False)   # the migration runs here (one launch), before anything reads the new arenas
-        else:
-            ops.gather_flush()
+        finally:
+            if not was_deferring:
+                ops.gather_defer(False)   # the migration runs here (one launch), before anything reads the new arenas
+            else:
+                ops.gather_flush()
         self.P, self.G, self.S, self.CNT = newP, newG, newS, newC
         self.SQ, self.BUF, self.EMA, self.SEMA = newSQ, newBUF, newEMA, newSEMA
         self.nP, self.nS = nP, nS

@@ -55,6 +55,10 @@ class DevicePrefetcher(object):
         self.stream = torch.cuda.Stream()
         self.max_image_bytes = int(max_image_bytes)
         self.slots = [None, None]   # per slot: (device pool, device descriptors, pinned descriptors, output) sized on first use
+        # per slot: event behind the last host-to-device copy that READ the slot's pinned descriptors.  The host rewrites them for the
+        # batch after next; nothing else orders the host against that copy (the reference's prefetcher never reuses host staging
+        # memory), and a caller that does not synchronise per step (graph replay) runs several steps ahead of the device.
+        self.desc_read = [None, None]
         self.k = 0
         self.stop = False
         self.preload()
@@ -82,6 +86,9 @@ class DevicePrefetcher(object):
         # the slot's previous batch was handed out two iterations ago; its consumer ran on the current stream before this call
         self.stream.wait_stream(torch.cuda.current_stream())
         pool, desc_dev, desc_pin, out = self._slot(n, int(offs[-1]))
+        ev = self.desc_read[self.k & 1]
+        if ev is not None:
+            ev.synchronize()   # the copy queued two batches ago has read desc_pin (normally long done: no wait in steady state)
         d = np.frombuffer(desc_pin.numpy(), dtype=DESC_DTYPE)
         for q, (im, box, fl) in enumerate(zip(images, boxes, flips)):
             H, W = int(im.shape[0]), int(im.shape[1])
@@ -91,6 +98,8 @@ class DevicePrefetcher(object):
             for q, im in enumerate(images):
                 pool[int(offs[q]):int(offs[q]) + sizes[q]].copy_(im.reshape(-1), non_blocking=True)
             desc_dev.copy_(desc_pin, non_blocking=True)
+            ev = self.desc_read[self.k & 1] = self.desc_read[self.k & 1] or torch.cuda.Event()
+            ev.record(self.stream)
             preprocess(pool, desc_dev, n, self.size, self.mean, self.std, out, 0, self.stream)
             self.next_target = target.cuda(non_blocking=True)
         self.next_input = out

@@ -21,6 +21,20 @@ def _size_of(img):
     return int(w), int(h)
 
 
+def _interp_name(interpolation):
+    """'bilinear' / 'bicubic' / ... for a PIL resampling constant (int or enum), a torchvision InterpolationMode or a string"""
+    pil = {0: "nearest", 1: "lanczos", 2: "bilinear", 3: "bicubic", 4: "box", 5: "hamming"}   # PIL.Image resampling filters
+    if isinstance(interpolation, str):
+        return interpolation.lower()
+    name = getattr(interpolation, "name", None)
+    if isinstance(name, str):
+        return name.lower()
+    try:
+        return pil.get(int(interpolation), str(interpolation))
+    except (TypeError, ValueError):
+        return str(interpolation)
+
+
 def center_crop_box(width, height, crop_h, crop_w):
     """torchvision.transforms.functional.center_crop's box (top, left, height, width) for a crop that fits inside the image"""
     top = int(round((height - crop_h) / 2.0))
@@ -55,7 +69,12 @@ class RandomResizedCropPadding(object):
                  max_attempts=10, crop_padding=0):
         self.size = size if isinstance(size, tuple) else (size, size)
         assert (scale[0] < scale[1]) and (ratio[0] < ratio[1])
-        self.interpolation = interpolation   # the kernel resizes bilinearly (PIL's BILINEAR): the 'imagenet1k_mnas_bilinear' transform
+        # the kernel implements PIL's BILINEAR resampler only (the 'imagenet1k_mnas_bilinear' transform); the reference's default
+        # yaml uses 'imagenet1k_mnas_bicubic' (apps/mobilenet/default_mnas_scheduler.yml), which this pipeline does not reproduce:
+        # asking for another filter is an error, not a silent substitution
+        if interpolation is not None and _interp_name(interpolation) != "bilinear":
+            raise NotImplementedError("atomnas_image_preprocess resizes with PIL's BILINEAR filter only (got %r)" % (interpolation,))
+        self.interpolation = interpolation
         self.max_attempts = max_attempts
         self.scale = scale
         self.min_object_covered = min_object_covered or scale[0]
@@ -64,43 +83,54 @@ class RandomResizedCropPadding(object):
         self.crop_padding = crop_padding
         self.center = CenterCropPadding(size if not isinstance(size, tuple) else size[0], crop_padding=crop_padding)
 
+    # ---- one attempt of the reference's sampler (utils/transforms.py:117-160), split into its three decisions.  What the drop-in
+    # contract fixes is the ORDER and KIND of the random draws (uniform -> randint height -> randint top -> randint left) and the
+    # integer arithmetic between them; tests/test_input_pipeline.py pins both against a transcription of the reference's formulas.
+    def _draw_ratio(self):
+        lo, hi = self.ratio
+        if self.log_ratio:
+            return math.exp(random.uniform(math.log(lo), math.log(hi)))
+        return random.uniform(lo, hi)
+
+    @staticmethod
+    def _height_bounds(ratio, img_w, img_h, area_lo, area_hi):
+        """heights (inclusive) whose crop of this aspect ratio has an area in [area_lo, area_hi] and fits the image"""
+        tallest = int(round(math.sqrt(area_hi / ratio)))
+        if tallest * ratio > img_w:                       # too wide at that height: the tallest crop that still fits across
+            tallest = int((img_w + 0.5 - 0.0000001) / ratio)
+        tallest = min(tallest, img_h)
+        shortest = min(tallest, int(round(math.sqrt(area_lo / ratio))))
+        return shortest, tallest
+
+    @staticmethod
+    def _nudge(h, ratio, area_lo, area_hi):
+        """rounding of width = round(h * ratio) can push the area just outside the range: one row more / less, judged on the area of
+        the height as drawn (both tests look at that same area)"""
+        drawn_area = h * int(round(h * ratio))
+        if drawn_area < area_lo:
+            h += 1
+        if drawn_area > area_hi:
+            h -= 1
+        return h, int(round(h * ratio))
+
     def get_params(self, img):
-        original_width, original_height = _size_of(img)
-        original_area = original_width * original_height
-        min_area, max_area = [original_area * scale for scale in self.scale]
-        for attempt in range(self.max_attempts):
-            if self.log_ratio:
-                log_ratio = (math.log(self.ratio[0]), math.log(self.ratio[1]))
-                aspect_ratio = math.exp(random.uniform(*log_ratio))
-            else:
-                aspect_ratio = random.uniform(*self.ratio)
-            min_height = int(round(math.sqrt(min_area / aspect_ratio)))
-            max_height = int(round(math.sqrt(max_area / aspect_ratio)))
-            if max_height * aspect_ratio > original_width:
-                max_height = int((original_width + 0.5 - 0.0000001) / aspect_ratio)
-            max_height = min(max_height, original_height)
-            min_height = min(max_height, min_height)
-            height = random.randint(min_height, max_height)
-            width = int(round(height * aspect_ratio))
-            assert width <= original_width
-            # try to fix rounding errors
-            area = height * width
-            if area < min_area:
-                height += 1
-            if area > max_area:
-                height -= 1
-            width = int(round(height * aspect_ratio))
-            area = height * width
-            if area < min_area or area > max_area:
+        img_w, img_h = _size_of(img)
+        whole = img_w * img_h
+        area_lo, area_hi = whole * self.scale[0], whole * self.scale[1]
+        covered = self.min_object_covered * whole
+        for _ in range(self.max_attempts):
+            ratio = self._draw_ratio()
+            shortest, tallest = self._height_bounds(ratio, img_w, img_h, area_lo, area_hi)
+            h = random.randint(shortest, tallest)
+            assert int(round(h * ratio)) <= img_w   # the reference asserts the drawn crop's width before adjusting it
+            h, w = self._nudge(h, ratio, area_lo, area_hi)
+            area = h * w
+            fits = 0 <= w <= img_w and 0 <= h <= img_h
+            if not (area_lo <= area <= area_hi) or area < covered or not fits:
                 continue
-            if area < self.min_object_covered * original_area:
-                continue
-            if width > original_width or height > original_height or width < 0 or height < 0:
-                continue
-            if width <= original_width and height <= original_height:
-                i = random.randint(0, original_height - height)
-                j = random.randint(0, original_width - width)
-                return i, j, height, width, True
+            top = random.randint(0, img_h - h)
+            left = random.randint(0, img_w - w)
+            return top, left, h, w, True
         return None, None, None, None, False
 
     def __call__(self, img):

@@ -95,3 +95,61 @@ def test_shrink_matches_reference(gpu_lib):
         l.append(ts.loss[0].item())
     assert all(v == v for v in l) and l[-1] < l[0], l
     assert set(id(p) for p in opt.param_groups[0]["params"]) == set(id(p) for p in model.parameters())
+
+
+def test_arena_rebuild_inside_a_gather_deferral_window(gpu_lib):
+    """ArenaManager.materialize() while a shrink's gathers are still only RECORDED (ops.gather_defer): the pending gathers write the
+    rebuilt modules' tensors, which the rebuild's value migration reads -- they must run first (one job-table launch has no order between
+    its workgroups).  A forward, a profiling pass or an optimizer call inside the window triggers exactly that; the result must equal
+    the ordinary order (flush, then rebuild) bit for bit."""
+    sys.path.insert(0, ROOT)
+    from atomnas_amd import ops, runtime
+    from atomnas_amd.models import mobilenet_supernet as ms
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "shrink.pt"), weights_only=False)
+
+    def shrunk(ensure_inside):
+        model = ms.Model(**g["kw"])
+        model.set_compute_dtype(torch.float32)
+        model.load_state_dict(g["sd_pre"])
+        model.cuda().train()
+        mgr = runtime.manager_of(model)
+        mgr.ensure()
+        ops.gather_defer(True)
+        try:
+            for bname, blk in model.get_named_block_list().items():
+                blk.compress_by_mask([m.cuda() for m in g["masks"][bname]], prefix=bname)
+            assert mgr.dirty
+            if ensure_inside:
+                mgr.ensure()                      # rebuild with recorded, not yet executed gathers
+                assert ops.gather_deferring()     # the window is still open afterwards
+        finally:
+            ops.gather_defer(False)
+        mgr.ensure()
+        torch.cuda.synchronize()
+        return collections.OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+
+    a, b = shrunk(False), shrunk(True)
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for k, dg in g["sd_post"].items():
+        check_digest("post " + k, b[k], dg, rtol=1e-6)
+
+
+def test_arena_rebuild_restores_the_deferral_state_when_it_raises(gpu_lib, monkeypatch):
+    sys.path.insert(0, ROOT)
+    from atomnas_amd import ops, runtime
+    from atomnas_amd.models import mobilenet_supernet as ms
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "shrink.pt"), weights_only=False)
+    model = ms.Model(**g["kw"])
+    model.cuda()
+    mgr = runtime.manager_of(model)
+    calls = []
+
+    def boom(dst, src):
+        calls.append(1)
+        raise RuntimeError("injected")
+    monkeypatch.setattr(ops, "copy_job", boom)
+    with pytest.raises(RuntimeError, match="injected"):
+        mgr.ensure()
+    assert calls and not ops.gather_deferring()   # a failed rebuild must not leave gathers deferred for ever
