@@ -38,6 +38,8 @@ def _id(r):
         if k in skip or r[k] is None or r[k] is False:
             continue
         v = r[k]
+        if isinstance(v, list):
+            v = "+".join(str(e) for e in v)
         parts.append("%s%s" % (k, "" if v is True else v))
     return "-".join(str(p) for p in parts)
 
@@ -327,54 +329,72 @@ def run_dwconv_fwd(ctx, r):
     assert all(torch.equal(ctx.read(outs[0], C), ctx.read(o, C)) for o in outs[1:]), "repeated launches differ"
 
 
-def run_dwconv_bwd(ctx, r):
-    ops = ctx.ops
+def _dw_bwd_case(ctx, r):
+    """inputs, kernel arguments and torch references of one depthwise backward (a launch of its own or a branch of a fused launch)"""
     d = _dw_reference(ctx, r, "bwd")
-    N, H, W, C, k, s, T = d["N"], d["H"], d["W"], d["C"], d["k"], d["s"], d["T"]
+    C, k, s, T = d["C"], d["k"], d["s"], d["T"]
     M, M2 = d["M"], d["M2"]
     gq = (ctx.randn(M2, C) * 1e-2).to(T).float()
-    garg, _ = ctx.act_in(gq, r["g"], T)
+    d["garg"], _ = ctx.act_in(gq, r["g"], T)
     if r["yraw"] is not None:
         yq = ctx.randn(M2, C).to(T).float()
-        yarg, _ = ctx.act_in(yq, r["yraw"], T)
+        d["yarg"], _ = ctx.act_in(yq, r["yraw"], T)
         c1, c2, c3 = ctx.rand(C) + 0.5, ctx.randn(C) * 1e-3, ctx.randn(C) * 1e-3
         dy = c1 * gq + c2 * yq + c3
-        cc = [ctx.cvec(c1), ctx.cvec(c2), ctx.cvec(c3)]
+        d["cc"] = [ctx.cvec(c1), ctx.cvec(c2), ctx.cvec(c3)]
     else:
-        yarg, dy, cc = None, gq, [None, None, None]
+        d["yarg"], dy, d["cc"] = None, gq, [None, None, None]
     pre = d["pre"].detach().requires_grad_(True)
     xa = act_fwd(pre, r["act"]) if r["fused_in"] else pre
     wr = d["w"].clone().requires_grad_(True)
     y = F.conv2d(xa, wr, None, s, (k - 1) // 2, 1, C)
     (y * d["nchw"](dy, d["Ho"], d["Wo"])).sum().backward()
-    href = pre.grad.permute(0, 2, 3, 1).reshape(M, C)     # = dwconv^T(dY) * act'(pre)
-    dwref = wr.grad.reshape(C, k * k)
-    outs = []
-    hold = busy()
-    for _ in range(REPEATS):
-        h = ctx.act_out(M, C, r["h"], T)
-        dw = torch.full((C * k * k,), 0.25, dtype=torch.float32, device="cuda") if r["dw"] else None
-        st = ctx.stats(r["part_rows"], r["stat_ld"]) if r["stats"] else None
-        ws = torch.full((r["part_rows"] * C * k * k,), float("nan"), dtype=torch.float32, device="cuda") if r["dw"] else None
-        ops.dwconv_bwd(garg, yarg, cc[0], cc[1], cc[2], d["xarg"], d["sc"], d["sh"], r["act"], d["taps"], h, dw, st, r["stat_ld"], N, H, W, C, k, s,
-                       stat_rows=r["part_rows"], dw_ws=ws)
-        outs.append((h, dw, st))
-    torch.cuda.synchronize()
-    del hold
+    d["href"] = pre.grad.permute(0, 2, 3, 1).reshape(M, C)     # = dwconv^T(dY) * act'(pre)
+    d["dwref"] = wr.grad.reshape(C, k * k)
+    del d["pre"]
+    return d
+
+
+def _dw_bwd_outputs(ctx, r, d):
+    C, k = d["C"], d["k"]
+    h = ctx.act_out(d["M"], C, r["h"], d["T"])
+    dw = torch.full((C * k * k,), 0.25, dtype=torch.float32, device="cuda") if r["dw"] else None
+    st = ctx.stats(r["part_rows"], r["stat_ld"]) if r["stats"] else None
+    ws = torch.full((r["part_rows"] * C * k * k,), float("nan"), dtype=torch.float32, device="cuda") if r["dw"] else None
+    return h, dw, st, ws
+
+
+def _dw_bwd_check(ctx, d, outs, tag=""):
+    C, k = d["C"], d["k"]
     for i, (h, dw, st) in enumerate(outs):
         got = ctx.read(h, C)
         # the matrix-core backward (k = 7, row-ring tiles) rounds dYraw and the taps to bf16: single large terms put the extreme
         # elements of 1e8 at 2.2 % of the rms (measured: 61 of 115 M beyond 2 %); a corrupted store is off by >= the rms itself
-        check("h[%d]" % i, got, href, rtol=1.2e-2, afrac=4e-2)
+        check("%sh[%d]" % (tag, i), got, d["href"], rtol=1.2e-2, afrac=4e-2)
         if dw is not None:
-            check("dw[%d]" % i, dw.view(C, k * k) - 0.25, dwref, rtol=3e-3, afrac=5e-3)
+            check("%sdw[%d]" % (tag, i), dw.view(C, k * k) - 0.25, d["dwref"], rtol=3e-3, afrac=5e-3)
         if st is not None:
             sm = stat_sum(st[:, :, :C])
-            check_sums("sum h[%d]" % i, sm[0], got)
-            check_sums("sum h*x[%d]" % i, sm[1], got * d["xq"])
+            check_sums("%ssum h[%d]" % (tag, i), sm[0], got)
+            check_sums("%ssum h*x[%d]" % (tag, i), sm[1], got * d["xq"])
     assert all(torch.equal(ctx.read(outs[0][0], C), ctx.read(o[0], C)) for o in outs[1:]), "repeated launches differ"
     if outs[0][1] is not None:
         assert all(torch.equal(outs[0][1], o[1]) for o in outs[1:]), "weight gradients of repeated launches differ"
+
+
+def run_dwconv_bwd(ctx, r):
+    ops = ctx.ops
+    d = _dw_bwd_case(ctx, r)
+    outs = []
+    hold = busy()
+    for _ in range(REPEATS):
+        h, dw, st, ws = _dw_bwd_outputs(ctx, r, d)
+        ops.dwconv_bwd(d["garg"], d["yarg"], d["cc"][0], d["cc"][1], d["cc"][2], d["xarg"], d["sc"], d["sh"], r["act"], d["taps"], h, dw, st,
+                       r["stat_ld"], d["N"], d["H"], d["W"], d["C"], d["k"], d["s"], stat_rows=r["part_rows"], dw_ws=ws)
+        outs.append((h, dw, st))
+    torch.cuda.synchronize()
+    del hold
+    _dw_bwd_check(ctx, d, outs)
 
 
 def run_expand_bwd(ctx, r):
