@@ -20,10 +20,8 @@ SIGNATURES = {
                            i32, vp, vp, i32, i32, i64, i32, i32, i32, vp],
     "atomnas_pw_gemm_tn": [i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i32,
                            vp, i64, i64, i64, vp, i64, i32, vp],
-    "atomnas_expand_bwd": [vp, i32, i64, vp, i32, i64, vp, vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, i64, i32, i32, i32,
-                           vp],
-    "atomnas_project_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, i32, vp, i64, i64, vp, i64, i64,
-                            i32, i32, i32, vp],
+    "atomnas_expand_bwd": [vp, i32, i64, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, i64, i32, i32, i32, vp],
+    "atomnas_project_bwd": [vp, i32, vp, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, vp],
     "atomnas_bn_finalize_fwd": [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
     "atomnas_bn_eval_coeffs": [vp, vp, vp, vp, f32, vp, vp, i32, vp, vp],
     "atomnas_bn_finalize_bwd": [vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
@@ -68,7 +66,7 @@ NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version":
              "atomnas_dwconv_mm_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
              "atomnas_se_pool_parts": (i32, [i32, i32, i32])}
 
-ABI_VERSION = 8   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
+ABI_VERSION = 9   # include/atomnas_hip.h ATOMNAS_ABI_VERSION
 _lib = None
 
 

@@ -460,216 +460,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* 
   }
 }
 
-// ------------------------------------------------------------------------------------------------ gemm_nt, column-stationary
-// For the expand-like shapes (K <= 192, N large: the 6x-wide hidden tensor is the OUTPUT).  A wave owns one 64-channel
-// chunk of the output and a range of 16-row tiles: the weight fragments of the chunk stay in registers for the whole range
-// (no weight traffic in the row loop), and the per-channel statistics are accumulated per lane across the rows and reduced
-// once at the end (the row-stationary kernel pays 128 cross-lane operations per tile for them).  A is re-read once per
-// chunk, from L2: it is the narrow operand (K/N of the output bytes).
-#ifndef CS_PREFETCH
-#define CS_PREFETCH 1   // experiment switch: 0 = every tile waits for its own loads
-#endif
-template <int MODE, int KSTEPS>
-__global__ __launch_bounds__(256) void k_gemm_nt_cs(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K,
-                                                    int nchunks, int tiles_per_item) {
-  using T = bf16_t;
-  using MM = Mma<T>;
-  const int lane = threadIdx.x & 63;
-  const int q = lane >> 4, j = lane & 15;
-  const int wrow = 16 * (j >> 2) + (j & 3);
-  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long mtiles = (M + 15) / 16;
-  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
-  if (item >= nranges * nchunks) return;
-  // consecutive items share the row range and differ in the chunk: the waves of a workgroup (and its XCD neighbours) then
-  // re-read the same rows of A from L2 while they are hot
-  const int chunk = (int)(item % nchunks);
-  const long range = item / nchunks;
-  const int nc = chunk * 64;
-  const int nb = nc + 16 * q;
-  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
-
-  typename MM::frag wf[KSTEPS][4];
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wf[ks][t] = MM::raw(Wp + (long)(nc + wrow + 4 * t) * ldw + ks * 32 + 8 * q);
-
-  float s1[16], s2[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
-
-  const long mt_beg = range * tiles_per_item;
-  const long mt_end = mt_beg + tiles_per_item < mtiles ? mt_beg + tiles_per_item : mtiles;
-  // The raw operands of the NEXT tile (A, its second stream, the epilogue's z) are in flight while the current tile is computed
-  // (up to 3 k-steps: with 6 the registers are gone).  Without it a wave waits out a full memory round trip per tile.
-  // Only where it does not cost a wave per SIMD: the plain-operand instances (the expand forward); with a prologue the extra
-  // registers take k_gemm_nt_cs<BNBWD, 3> from two waves per SIMD to one.
-  // Measured in situ (same box): K = 40 -8 %, K = 80 / 96 -6 / -14 %; K = 16 / 24 (one k-step, already 3 TB/s) 0 / +7 %: two and
-  // three k-steps only.
-  constexpr bool PF = CS_PREFETCH && (KSTEPS == 2 || KSTEPS == 3) && MODE == PRO_NONE;
-  struct Raw { bf16x8 a[KSTEPS], x[KSTEPS], z[2]; };
-  Raw nx;
-  auto fetch = [&](long mt) {
-    const long row = mt * 16 + j;
-    bf16x8 zero8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) zero8[e] = (bf16_t)0.f;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int k = ks * 32 + 8 * q;
-      nx.a[ks] = zero8;
-      nx.x[ks] = zero8;
-      if (row < M && k < K) {
-        nx.a[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row, k, A.ld1, A.ss1));
-        if constexpr (MODE == PRO_BNBWD)
-          nx.x[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row, k, A.ld2, A.ss2));
-      }
-    }
-#pragma unroll
-    for (int h8 = 0; h8 < 2; ++h8) {
-      const int n8 = nb + 8 * h8;
-      nx.z[h8] = zero8;
-      if (ep.z && row < M && n8 < N) nx.z[h8] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss));
-    }
-  };
-  if constexpr (PF) {
-    if (mt_beg < mt_end) fetch(mt_beg);
-  }
-  for (long mt = mt_beg; mt < mt_end; ++mt) {
-    const long row = mt * 16 + j;
-    const bool rowvalid = row < M;
-    Raw cur;
-    if constexpr (PF) {
-      cur = nx;
-      if (mt + 1 < mt_end) fetch(mt + 1);
-    }
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      float av[8];
-      if constexpr (PF) {
-        const int k = ks * 32 + 8 * q;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) av[e] = (float)cur.a[ks][e];
-        if (rowvalid && k < K) {
-          if constexpr (MODE == PRO_BNRELU) {
-            float sc[8], sh[8];
-            VecIO<float, 8>::load(A.c1 + k, sc);
-            VecIO<float, 8>::load(A.c2 + k, sh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = av[e] * sc[e] + sh[e];
-            act_apply_v<8>(av, act_of(A.relu));
-          } else if constexpr (MODE == PRO_BNBWD) {
-            float a1[8], a2[8], a3[8];
-            VecIO<float, 8>::load(A.c1 + k, a1);
-            VecIO<float, 8>::load(A.c2 + k, a2);
-            VecIO<float, 8>::load(A.c3 + k, a3);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = a1[e] * av[e] + a2[e] * (float)cur.x[ks][e] + a3[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (k + e >= K) av[e] = 0.f;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) av[e] = 0.f;
-        }
-      } else {
-        load_pro<T, MODE>(A, row, rowvalid, ks * 32 + 8 * q, K, av);
-      }
-      const typename MM::frag af = MM::pack(av);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
-    }
-    if (!rowvalid) continue;
-    float c[16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[4 * t + r] = acc[t][r];
-#pragma unroll
-    for (int h8 = 0; h8 < 2; ++h8) {
-      const int n8 = nb + 8 * h8;
-      if (n8 >= N) continue;
-      float zv[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) zv[i] = 0.f;
-      if (ep.bias) {
-        float bs[8];
-        VecIO<float, 8>::load(ep.bias + n8, bs);  // per-channel vectors are readable up to N rounded up to 8
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c[8 * h8 + i] += bs[i];
-      }
-      if (ep.add) {
-        float tmp[8];
-        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.add) + row * ep.ldadd + n8, tmp);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c[8 * h8 + i] += tmp[i];
-      }
-      if (ep.z) {
-        if constexpr (PF) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) zv[i] = (float)cur.z[h8][i];
-        } else {
-          VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss), zv);
-        }
-        if (ep.mask) {
-          float zs[8], zh[8];
-          VecIO<float, 8>::load(ep.zscale + n8, zs);
-          VecIO<float, 8>::load(ep.zshift + n8, zh);
-          float a8[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) a8[i] = zv[i] * zs[i] + zh[i];
-          act_bwd_v<8>(&c[8 * h8], a8, act_of(ep.mask));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (n8 + i >= N) c[8 * h8 + i] = 0.f;
-      float o8[8];
-      if (ep.out_f32) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
-        VecIO<float, 8>::store(reinterpret_cast<float*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
-        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
-      }
-      if (do_stats) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          s1[8 * h8 + i] += o8[i];
-          s2[8 * h8 + i] += (ep.stat_mode == STAT_SQ) ? o8[i] * o8[i] : o8[i] * zv[i];
-        }
-      }
-    }
-  }
-
-  if (do_stats) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float a = s1[i], b = s2[i];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-      }
-      if (j == 0 && nb + i < N) {   // this wave is the only writer of (row `range`, channel nb + i): plain stores
-        ep.stats[(long)range * 2 * N + nb + i] = a;
-        ep.stats[(long)range * 2 * N + N + nb + i] = b;
-        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, nb + i);
-        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, (long)N + nb + i);
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ gemm_nt, column-stationary, streaming
-// Round 3.  k_gemm_nt_cs above spends its time waiting, not moving bytes (3.3 TB/s on the 56x56 expand forward, where a bare write
+// Round 3.  The first column-stationary kernel (k_gemm_nt_cs, removed in round 6) spent its time waiting, not moving bytes (3.3 TB/s on the 56x56 expand forward, where a bare write
 // stream of the same shape and order reaches 5.3 TB/s, tools/probe/stpat.hip): s_waitcnt vmcnt counts loads AND stores in issue
 // order, and every load or store that sits behind a branch (row / channel validity, the optional epilogue streams) makes the number
 // of operations issued after a load unknown to the compiler, which then waits with vmcnt(0) -- i.e. for the PREVIOUS tile's stores
@@ -1176,165 +968,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   }
 }
 
-// ------------------------------------------------------------------------------------------------ fused project backward
-// Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) for the early stages (oup <= 48): the
-// column-stationary input-gradient GEMM  g = mask(dP * Wp)  already holds, per 16-row tile, dP (as its MFMA operand) and the raw
-// depthwise output z of its 64 channels (for the activation mask and the BatchNorm statistics).  The weight gradient
-// dWp[o][n] = sum_m dP[m][o] * act(bn(z))[m][n] needs exactly those two, so the wave also transposes both through a PRIVATE LDS
-// region (no workgroup barrier: LDS operations of one wave complete in order) and accumulates R[oup][64] with 16x16x16 MFMAs
-// (contraction over the tile's 16 rows).  One partial per (row range, chunk) in the caller's workspace, summed in range order by
-// reduce_parts.  This removes atomnas_pw_gemm_tn's second pass over z.
-
-template <int KSTEPS, int UT>
-__global__ __launch_bounds__(256) void k_project_bwd_cs(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, float* __restrict__ ws,
-                                                        long M, int N, int K, int nchunks, int tiles_per_item) {
-  using T = bf16_t;
-  using MM = Mma<T>;
-  constexpr int MODE = PRO_BNBWD;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_pb[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* s_p = reinterpret_cast<T*>(smem_pb) + wave * (16 * UT + 64) * PB_RP;   // [16*UT][PB_RP] dP of the tile, transposed
-  T* s_a = s_p + 16 * UT * PB_RP;                                           // [64][PB_RP] act(bn(z)) of the tile, transposed
-  const int q = lane >> 4, j = lane & 15;
-  const int wrow = 16 * (j >> 2) + (j & 3);
-  const long item = (long)blockIdx.x * 4 + wave;
-  const long mtiles = (M + 15) / 16;
-  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
-  if (item >= nranges * nchunks) return;
-  const int chunk = (int)(item % nchunks);
-  const long range = item / nchunks;
-  const int nc = chunk * 64;
-  const int nb = nc + 16 * q;
-  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
-
-  typename MM::frag wf[KSTEPS][4];
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wf[ks][t] = MM::raw(Wp + (long)(nc + wrow + 4 * t) * ldw + ks * 32 + 8 * q);
-
-  float s1[16], s2[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
-  f32x4 racc[UT][4];
-#pragma unroll
-  for (int t = 0; t < UT; ++t)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) racc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // rows of s_p beyond the k positions the lanes write (K rounded up to 32 per k-step covers 16*UT whenever 32*KSTEPS >= 16*UT)
-  const long mt_beg = range * tiles_per_item;
-  const long mt_end = mt_beg + tiles_per_item < mtiles ? mt_beg + tiles_per_item : mtiles;
-  for (long mt = mt_beg; mt < mt_end; ++mt) {
-    const long row = mt * 16 + j;
-    const bool rowvalid = row < M;
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      float av[8];
-      load_pro<T, MODE>(A, row, rowvalid, ks * 32 + 8 * q, K, av);
-      const typename MM::frag af = MM::pack(av);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
-      // dP transposed: s_p[o][row j], o = ks*32 + 8q + e (rows >= 16*UT do not exist: those o are >= K rounded up to 16)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int o = ks * 32 + 8 * q + e;
-        if (o < 16 * UT) s_p[o * PB_RP + j] = af[e];
-      }
-    }
-    float c[16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[4 * t + r] = acc[t][r];
-#pragma unroll
-    for (int h8 = 0; h8 < 2; ++h8) {
-      const int n8 = nb + 8 * h8;
-      float zv[8], a8[8], o8[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) zv[i] = a8[i] = o8[i] = 0.f;
-      if (rowvalid && n8 < N) {
-        VecIO<T, 8>::load(reinterpret_cast<const T*>(ep.z) + lay_off(row, n8, ep.ldz, ep.zss), zv);
-        float zs[8], zh[8];
-        VecIO<float, 8>::load(ep.zscale + n8, zs);
-        VecIO<float, 8>::load(ep.zshift + n8, zh);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = zv[i] * zs[i] + zh[i];
-        act_bwd_v<8>(&c[8 * h8], a8, act_of(ep.mask));
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (n8 + i >= N) c[8 * h8 + i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o8[i] = to_f32(from_f32<T>(c[8 * h8 + i]));
-        VecIO<T, 8>::store(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css), o8);
-        if (do_stats) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            s1[8 * h8 + i] += o8[i];
-            s2[8 * h8 + i] += o8[i] * zv[i];
-          }
-        }
-        act_apply_v<8>(a8, act_of(ep.mask));   // the projection's forward operand act(bn(z))
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (n8 + i >= N) a8[i] = 0.f;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s_a[(16 * q + 8 * h8 + i) * PB_RP + j] = from_f32<T>(a8[i]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // R[o][n] += sum over the tile's 16 rows: A = dP^T (lane: o = 16t + j, rows 4q..4q+3), B = act(bn(z)) (lane: n = 16u + j)
-    s16x4 bfr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bfr[u] = *reinterpret_cast<const s16x4*>(s_a + (16 * u + j) * PB_RP + 4 * q);
-#pragma unroll
-    for (int t = 0; t < UT; ++t) {
-      const s16x4 afr = *reinterpret_cast<const s16x4*>(s_p + (16 * t + j) * PB_RP + 4 * q);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) racc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afr, bfr[u], racc[t][u], 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();   // the next tile overwrites s_p / s_a
-  }
-
-  if (do_stats) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float a = s1[i], b = s2[i];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-      }
-      if (j == 0 && nb + i < N) {
-        ep.stats[(long)range * 2 * N + nb + i] = a;
-        ep.stats[(long)range * 2 * N + N + nb + i] = b;
-        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, nb + i);
-        stat_zero_tail(ep.stats, 2L * N, (int)(range + nranges), (int)nranges, ep.stat_rows, (long)N + nb + i);
-      }
-    }
-  }
-  // partial of the weight gradient: (o, n) at ws[(range * K + o) * N + n]
-#pragma unroll
-  for (int t = 0; t < UT; ++t)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = nc + 16 * u + j;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 16 * t + 4 * q + r;
-        if (o < K && n < N) ws[((long)range * K + o) * N + n] = racc[t][u][r];
-      }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ gemm_nt, weights shared in LDS
 // For the contraction-heavy shapes (K > 192: the linear projection forward, the expand input-gradient): the 6x-wide hidden
 // tensor is the INPUT, streamed once from HBM straight into MFMA B fragments (prologue applied in registers).  In the
@@ -1632,9 +1265,9 @@ constexpr int XB_DP = 64 + 8;   // transposed LDS pitch (elements): rows of the 
 #ifndef EB_MINWG
 #define EB_MINWG 2   // workgroups per CU the registers are allocated for (experiment switch)
 #endif
-// NOE: dE = c1*h only -- the form of the E-elimination (xdw.hip): the c2*E + c3 part of the BatchNorm backward reaches dX / dWe
-// through inp x inp sized corrections (atomnas_xb_coeffs), so the raw expand output is neither read nor does it exist.
-template <int UT, int NCH, bool NOE>
+// dE = c1*h only (round 4; the two-stream form that read the raw expand output E as well was removed in round 6): the c2*E + c3 part
+// of the BatchNorm backward reaches dX / dWe through inp x inp sized corrections (atomnas_xb_coeffs), so E is not read.
+template <int UT, int NCH>
 __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const bf16_t* __restrict__ Wp, int ldw, int wrows, const bf16_t* __restrict__ x,
                                                     int ldx, Epilogue ep, float* __restrict__ ws, long M, int N, int K,
                                                     const bf16_t* __restrict__ mpk, int ldm) {
@@ -1727,7 +1360,6 @@ __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const b
         anx[ks].x = z;
         if (rowvalid && k < K) {
           anx[ks].a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p1) + lay_off(row, k, A.ld1, A.ss1));
-          if constexpr (!NOE) anx[ks].x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(A.p2) + lay_off(row, k, A.ld2, A.ss2));
         }
       }
     };
@@ -1771,7 +1403,7 @@ __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const b
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            v[e] = rowvalid ? (NOE ? c1v[e] * (float)acur[ks].a[e] : c1v[e] * (float)acur[ks].a[e] + c2v[e] * (float)acur[ks].x[e] + c3v[e]) : 0.f;
+            v[e] = rowvalid ? c1v[e] * (float)acur[ks].a[e] : 0.f;
           const bf16x8 af = MM::pack(v);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -1787,7 +1419,7 @@ __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const b
         __builtin_amdgcn_sched_barrier(0);   // the chunk loop is unrolled for static accumulator indices only: no motion across chunks
       }
     }
-    if constexpr (NOE) {
+    {
       // + x M (mpk: M = We^T diag(c2) We packed [N rounded up to 64][ldm], zero padded): the c2 term of the BatchNorm backward, a
       // product of the narrow input with an inp x inp matrix; its bias v rides in the epilogue
       if (mpk) {
@@ -2314,34 +1946,6 @@ static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, co
 #undef ST_CASE
 }
 
-template <int KSTEPS>
-static void launch_nt_cs(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
-  const int nchunks = (N + 63) / 64;
-  const long mtiles = (M + 15) / 16;
-  const bf16_t* W = (const bf16_t*)Wp;
-  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
-  const long min_tpi = do_stats ? (mtiles + ep.stat_rows - 1) / ep.stat_rows : 1;   // every row range owns one partial row
-  // one item per resident wave (a single round of workgroups), but at least 8 row tiles per item so that the
-  // register-resident weights pay off
-#define CS_CASE(MODE)                                                                                                   \
-  {                                                                                                                     \
-    auto kern = k_gemm_nt_cs<MODE, KSTEPS>;                                                                             \
-    const long waves = (long)num_cus() * resident_per_cu(kern, 256, 0) * 4;                                             \
-    long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;                                                       \
-    if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
-    if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;                                                             \
-    /* whole row ranges per chunk: ceil(mtiles / tpi) * nchunks items must still fit in one round (784 row tiles x 54   \
-       chunks on 2048 waves gave 38 ranges = 2052 items: one workgroup too many, i.e. a second round) */                \
-    const long max_ranges = waves / nchunks > 0 ? waves / nchunks : 1;                                                  \
-    if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges; \
-    const long items = ((mtiles + tiles_per_item - 1) / tiles_per_item) * nchunks;                                      \
-    dim3 grid((unsigned)((items + 3) / 4)), block(256);                                                                 \
-    hipLaunchKernelGGL(kern, grid, block, 0, st, A, W, ldw, ep, M, N, K, nchunks, (int)tiles_per_item);                 \
-  }
-  if (mode == PRO_NONE) CS_CASE(PRO_NONE) else if (mode == PRO_BNRELU) CS_CASE(PRO_BNRELU) else CS_CASE(PRO_BNBWD)
-#undef CS_CASE
-}
-
 static int launch_nt_ws(int mode, const Operand& A, const void* Wp, int ldw, const Epilogue& ep, long M, int N, int K, hipStream_t st) {
   const bf16_t* W = (const bf16_t*)Wp;
   const int wrows = (N + 63) / 64 * 64;   // rows of the packed weight matrix
@@ -2843,11 +2447,7 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
         else launch_nt_st<6>(kind, A, Wp, ldw, ep, M, N, K, st);
         return check_launch("gemm_nt_st");
       }
-      if (ksteps == 1) launch_nt_cs<1>(mode, A, Wp, ldw, ep, M, N, K, st);
-      else if (ksteps == 2) launch_nt_cs<2>(mode, A, Wp, ldw, ep, M, N, K, st);
-      else if (ksteps == 3) launch_nt_cs<3>(mode, A, Wp, ldw, ep, M, N, K, st);
-      else launch_nt_cs<6>(mode, A, Wp, ldw, ep, M, N, K, st);
-      return check_launch("gemm_nt_cs");
+      // anything else in this shape class (a prologue, a bias / residual epilogue, K not a multiple of 8) takes the kernels below
     }
   }
   if constexpr (sizeof(T) == 2) {
@@ -3271,33 +2871,6 @@ static int launch_project_bwd_st(const Operand& A, const bf16_t* W, int ldw, con
   return reduce_parts(ws, (long)K * N, (int)nranges, (long)K * N, dwp, N, si, sj, st);
 }
 
-template <int KSTEPS, int UT>
-static int launch_project_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, const Epilogue& ep, float* dwp, long si, long sj, float* ws,
-                                  long ws_floats, long M, int N, int K, hipStream_t st) {
-  const int nchunks = (N + 63) / 64;
-  const long mtiles = (M + 15) / 16;
-  const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
-  auto kern = k_project_bwd_cs<KSTEPS, UT>;
-  const size_t lds = (size_t)4 * (16 * UT + 64) * PB_RP * sizeof(bf16_t);
-  const long waves = (long)num_cus() * resident_per_cu(kern, 256, lds) * 4;
-  long tiles_per_item = (mtiles * nchunks + waves - 1) / waves;
-  if (tiles_per_item < 8) tiles_per_item = 8;
-  if (do_stats) {
-    const long min_tpi = (mtiles + ep.stat_rows - 1) / ep.stat_rows;   // every row range owns one partial row of the statistics
-    if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;
-  }
-  const long max_parts = ws_floats / ((long)K * N);   // ... and one partial of the weight gradient
-  ATOMNAS_REQUIRE(max_parts >= 1, "project_bwd: workspace too small for one partial (%ld floats)", (long)K * N);
-  long max_ranges = waves / nchunks > 0 ? waves / nchunks : 1;
-  if (max_ranges > max_parts) max_ranges = max_parts;
-  if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges;
-  const long nranges = (mtiles + tiles_per_item - 1) / tiles_per_item;
-  const long items = nranges * nchunks;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, A, W, ldw, ep, ws, M, N, K, nchunks, (int)tiles_per_item);
-  if (int rc = check_launch("project_bwd")) return rc;
-  return reduce_parts(ws, (long)K * N, (int)nranges, (long)K * N, dwp, N, si, sj, st);
-}
-
 // ------------------------------------------------------------------------------------------------ streaming expand backward (e == NULL)
 // The one-stream form of the expand backward (dE = c1 * h, atomnas_expand_bwd with e == NULL) as a pure stream of h:
 //   gx[m][n]  = sum_k h[m][k] * (c1[k] We[k][n])  (+ x M + v + add)          -- c1 folded into the RESIDENT weights, once per workgroup
@@ -3583,7 +3156,7 @@ static inline int xb_nch(int HT) {
 template <int UT, int NCH>
 static int launch_expand_bwd_cfg(const Operand& A, const bf16_t* W, int ldw, int wrows, const bf16_t* x, int ldx, const Epilogue& ep, float* dwe,
                                  float* ws, long ws_floats, long M, int N, int K, const bf16_t* mpk, int ldm, hipStream_t st) {
-  auto kern = A.p2 ? k_expand_bwd<UT, NCH, false> : k_expand_bwd<UT, NCH, true>;
+  auto kern = k_expand_bwd<UT, NCH>;
   const size_t lds = (size_t)2 * 64 * WS_WP * sizeof(bf16_t) + 2 * 3 * WS_KC * sizeof(float) + (size_t)2 * 64 * XB_DP * sizeof(bf16_t) +
                      (size_t)16 * UT * XB_DP * sizeof(bf16_t);
   const long rblocks = (M + 63) / 64;
@@ -3687,31 +3260,29 @@ extern "C" int atomnas_expand_bwd_supported(int inp, int hid, int dtype) {
   return 4 * ((inp + 15) / 16) * xb_nch(hid) <= XB_MINB2_LIMIT;
 }
 
-// Backward of the expand convolution (models/mobilenet_base.py:316-320), both gradients from ONE pass over the hidden streams:
-//   dE = c1*h + c2*e + c3 (BatchNorm backward of h = dL/d act(bn(E)) masked, e = E raw);  gx[M, inp] = dE * We (+ add);
+// Backward of the expand convolution (models/mobilenet_base.py:316-320) without its raw output E, both gradients from ONE pass over h:
+//   dE = c1*h (the c2*E + c3 part of the BatchNorm backward: atomnas_xb_coeffs);  gx[M, inp] = dE * We (+ x M + v) (+ add);
 //   dwe[n * inp + k] += sum_m dE[m][n] * x[m][k].   wt: We^T packed by atomnas_pack_weights ([inp padded to 64][ldw >= hid]).
-extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde, long e_ss, const float* c1, const float* c2,
-                                  const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx,
-                                  int ldgx, float* dwe, float* ws, long ws_floats, const void* mp, int ldm, const float* vb, long M, int inp,
-                                  int hid, int dtype, void* stream) {
+extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const float* c1, const void* x, int ldx, const void* wt, int ldw,
+                                  const void* add, int ldadd, void* gx, int ldgx, float* dwe, float* ws, long ws_floats, const void* mp, int ldm,
+                                  const float* vb, long M, int inp, int hid, int dtype, void* stream) {
   ATOMNAS_REQUIRE(atomnas_expand_bwd_supported(inp, hid, dtype), "expand_bwd: unsupported shape inp=%d hid=%d dtype=%d", inp, hid, dtype);
-  ATOMNAS_REQUIRE(h && c1 && x && wt && gx && dwe && ws && M > 0 && (!e || (c2 && c3)), "expand_bwd: bad arguments");
-  ATOMNAS_REQUIRE((h_ss >= M * 16 || (h_ss == 0 && ldh >= hid && ldh % 8 == 0)) && (!e || e_ss >= M * 16 || (e_ss == 0 && lde >= hid && lde % 8 == 0)),
-                  "expand_bwd: bad hidden layout");
-  if (!e) { c2 = c1; c3 = c1; }   // e == NULL: dE = c1*h (the kernel stages, but does not use, the other two coefficient vectors)
-  ATOMNAS_REQUIRE(!mp || (!e && ldm >= (inp + 31) / 32 * 32 && ldm % 8 == 0), "expand_bwd: the x M term belongs to the e == NULL form (ldm=%d)", ldm);
+  ATOMNAS_REQUIRE(h && c1 && x && wt && gx && dwe && ws && M > 0, "expand_bwd: bad arguments");
+  ATOMNAS_REQUIRE(h_ss >= M * 16 || (h_ss == 0 && ldh >= hid && ldh % 8 == 0), "expand_bwd: bad hidden layout");
+  ATOMNAS_REQUIRE(!mp || (ldm >= (inp + 31) / 32 * 32 && ldm % 8 == 0), "expand_bwd: bad pitch of the x M term (ldm=%d)", ldm);
   ATOMNAS_REQUIRE(ldx >= inp && ldx % 8 == 0 && ldgx >= inp && ldgx % 8 == 0 && (!add || (ldadd >= inp && ldadd % 8 == 0)), "expand_bwd: bad pitch");
   ATOMNAS_REQUIRE(ldw >= (hid + 31) / 32 * 32 && ldw % 8 == 0, "expand_bwd: packed weight pitch %d too small for hid=%d", ldw, hid);
-  Operand A{h, ldh, e, lde, h_ss, e_ss, c1, c2, c3, 0};
+  const float *c2 = c1, *c3 = c1;   // the register-prefetch kernel stages three coefficient vectors per chunk; only the first is used
+  Operand A{h, ldh, nullptr, 0, h_ss, 0, c1, c2, c3, 0};
   Epilogue ep{gx, ldgx, 0, add, ldadd, nullptr, 0, 0, 0, nullptr, nullptr, 0, mp ? vb : nullptr, nullptr, STAT_NONE, 0};
   hipStream_t st = (hipStream_t)stream;
   const int ut = (inp + 15) / 16, nch = xb_nch(hid);
   const bf16_t* W = (const bf16_t*)wt;
   const bf16_t* X = (const bf16_t*)x;
   const int wrows = (inp + 63) / 64 * 64;
-  // e == NULL on slab-major h: the streaming kernel (ATOMNAS_XB_STREAM=0: experiment switch back to k_expand_bwd)
+  // slab-major h: the streaming kernel (ATOMNAS_XB_STREAM=0: experiment switch back to k_expand_bwd)
   static const int xs_on = getenv("ATOMNAS_XB_STREAM") ? atoi(getenv("ATOMNAS_XB_STREAM")) : 1;
-  if (xs_on && !e && h_ss > 0 && M >= 64 && ldx >= 8 && (!add || ldadd >= 8)) {
+  if (xs_on && h_ss > 0 && M >= 64 && ldx >= 8 && (!add || ldadd >= 8)) {
 #define XS_CASE(UTV, NCHV)                                                                                                             \
   if (ut == UTV && nch == NCHV) {                                                                                                      \
     const int rc = launch_expand_bwd_s<UTV, NCHV>((const bf16_t*)h, h_ss, c1, W, ldw, X, ldx, (const bf16_t*)add, ldadd, (bf16_t*)gx, ldgx, \
@@ -3729,17 +3300,17 @@ extern "C" int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void*
   return 1;
 }
 
-// 1 when atomnas_project_bwd has an instance for this shape (bf16 storage, oup <= 48, hid >= 96 and >= 2 * oup)
+// 1 when atomnas_project_bwd has an instance for this shape: bf16 storage, oup a multiple of 8 and <= 64 (one to four 16-channel
+// accumulator tiles of the weight gradient per wave), hid >= 96 and >= 2 * oup
 extern "C" int atomnas_project_bwd_supported(int oup, int hid, int dtype) {
-  return dtype == DT_BF16 && oup >= 1 && oup <= 96 && hid >= 96 && hid >= 2 * oup && hid <= NT_MAX_STAT;
+  return dtype == DT_BF16 && oup >= 8 && oup <= 64 && oup % 8 == 0 && hid >= 96 && hid >= 2 * oup && hid <= NT_MAX_STAT;
 }
 
-// 1 when atomnas_project_bwd takes its dP form (p = c1 = c2 = c3 = NULL: g is the differentiated BatchNorm output) for these layouts:
-// the streaming kernel's conditions (nt_st_kind: switch, 2 GB per 64-channel chunk, 4096 tiles per statistics row).  Callers gate the
-// form on this query and use the prologue form otherwise.
+// 1 when atomnas_project_bwd serves these layouts: the streaming kernel's conditions (nt_st_kind: switch, 2 GB per 64-channel chunk,
+// 4096 tiles per statistics row).  Callers gate the fused form on this query and use the two GEMMs otherwise.
 extern "C" int atomnas_project_bwd_dp_supported(long M, int oup, int hid, int ldg, int ldz, long z_ss, int ldgh, long gh_ss, int stat_rows,
                                                 int dtype) {
-  if (!atomnas_project_bwd_supported(oup, hid, dtype) || oup % 8 != 0 || oup > 64 || M <= 0 || stat_rows <= 0) return 0;
+  if (!atomnas_project_bwd_supported(oup, hid, dtype) || M <= 0 || stat_rows <= 0) return 0;
   static float dummy;
   Operand A{&dummy, ldg, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
   Epilogue ep{&dummy, ldgh, 0, nullptr, 0, &dummy, ldz, gh_ss, z_ss, nullptr, nullptr, ACT_RELU, nullptr, &dummy, STAT_Z, stat_rows};
@@ -3747,44 +3318,30 @@ extern "C" int atomnas_project_bwd_dp_supported(long M, int oup, int hid, int ld
 }
 
 // Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) in ONE pass over the raw depthwise output:
-//   dP = c1*g + c2*p + c3   (BatchNorm backward of the block-output BN; g, p: [M, oup])
+//   g = dP, the differentiated block-output BatchNorm (atomnas_bnbwd_apply's output; the prologue form that computed it per tile from
+//   two streams was removed in round 6)
 //   gh[M, hid] = act'(z*zscale + zshift) * (dP * Wp)            -- gradient wrt the raw depthwise-BN output, masked
 //   stats rows [sum gh, sum gh*z]                               -- for the depthwise BN's backward
 //   dwp[o*si + n*sj] += sum_m dP[m][o] * act(z*zscale + zshift)[m][n]
 // wpt: Wp^T packed by atomnas_pack_weights ([hid padded to 64][ldw >= oup rounded up to 32]).
-extern "C" int atomnas_project_bwd(const void* g, int ldg, const void* p, int ldp, const float* c1, const float* c2, const float* c3,
-                                   const void* wpt, int ldw, const void* z, int ldz, long z_ss, const float* zscale, const float* zshift,
-                                   int act, void* gh, int ldgh, long gh_ss, float* stats, int stat_rows, float* dwp, long si, long sj,
-                                   float* ws, long ws_floats, long M, int oup, int hid, int dtype, void* stream) {
+extern "C" int atomnas_project_bwd(const void* g, int ldg, const void* wpt, int ldw, const void* z, int ldz, long z_ss, const float* zscale,
+                                   const float* zshift, int act, void* gh, int ldgh, long gh_ss, float* stats, int stat_rows, float* dwp, long si,
+                                   long sj, float* ws, long ws_floats, long M, int oup, int hid, int dtype, void* stream) {
   ATOMNAS_REQUIRE(atomnas_project_bwd_supported(oup, hid, dtype), "project_bwd: unsupported shape oup=%d hid=%d dtype=%d", oup, hid, dtype);
-  const bool have_dp = !p && !c1 && !c2 && !c3;   // g is already dP = c1*g + c2*p + c3 (atomnas_bnbwd_apply): the streaming kernel
-  ATOMNAS_REQUIRE(g && (have_dp || (p && c1 && c2 && c3)) && wpt && z && zscale && zshift && gh && stats && dwp && ws && M > 0, "project_bwd: bad arguments");
+  ATOMNAS_REQUIRE(g && wpt && z && zscale && zshift && gh && stats && dwp && ws && M > 0, "project_bwd: bad arguments");
   ATOMNAS_REQUIRE(act >= ACT_RELU && act <= ACT_SWISH && stat_rows > 0, "project_bwd: bad activation / stat_rows");
-  ATOMNAS_REQUIRE(ldg >= oup && ldg % 8 == 0 && (have_dp || (ldp >= oup && ldp % 8 == 0)), "project_bwd: bad pitch");
+  ATOMNAS_REQUIRE(ldg >= oup && ldg % 8 == 0, "project_bwd: bad pitch");
   ATOMNAS_REQUIRE((z_ss >= M * 16 || (z_ss == 0 && ldz >= hid && ldz % 8 == 0)) && (gh_ss >= M * 16 || (gh_ss == 0 && ldgh >= hid && ldgh % 8 == 0)),
                   "project_bwd: bad hidden layout");
   ATOMNAS_REQUIRE(ldw >= (oup + 31) / 32 * 32 && ldw % 8 == 0, "project_bwd: packed weight pitch %d too small for oup=%d", ldw, oup);
-  Operand A{g, ldg, p, ldp, 0, 0, c1, c2, c3, 0};
+  Operand A{g, ldg, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
   Epilogue ep{gh, ldgh, 0, nullptr, 0, z, ldz, gh_ss, z_ss, zscale, zshift, act, nullptr, stats, STAT_Z, stat_rows};
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* W = (const bf16_t*)wpt;
   const int ut = (oup + 15) / 16;
-  if (have_dp) {
-    ATOMNAS_REQUIRE(oup % 8 == 0 && oup <= 64, "project_bwd: the dP form needs oup %% 8 == 0 and oup <= 64 (got %d)", oup);
-    ATOMNAS_REQUIRE(nt_st_kind(PRO_NONE, A, ep, M, hid, oup) == ST_MASK, "project_bwd: the dP form needs slab-major hidden tensors (or plain ones with hid %% 8 == 0) below 2 GB per 64-channel chunk");
-    if (ut == 1) return launch_project_bwd_st<1, 1>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-    if (ut == 2) return launch_project_bwd_st<1, 2>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-    if (ut == 3) return launch_project_bwd_st<2, 3>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-    return launch_project_bwd_st<2, 4>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-  }
-  if (oup <= 32) {
-    if (ut == 1) return launch_project_bwd_cfg<1, 1>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-    return launch_project_bwd_cfg<1, 2>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-  }
-  if (oup <= 48) return launch_project_bwd_cfg<2, 3>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-  // round 3: the 14x14 stages (oup 80 / 96): three k-steps of the input gradient, 5 / 6 accumulator tiles of the weight gradient
-  if (oup <= 64) return launch_project_bwd_cfg<2, 4>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-  if (oup <= 80) return launch_project_bwd_cfg<3, 5>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
-  return launch_project_bwd_cfg<3, 6>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  ATOMNAS_REQUIRE(nt_st_kind(PRO_NONE, A, ep, M, hid, oup) == ST_MASK, "project_bwd: needs slab-major hidden tensors (or plain ones with hid %% 8 == 0) below 2 GB per 64-channel chunk (ask atomnas_project_bwd_dp_supported)");
+  if (ut == 1) return launch_project_bwd_st<1, 1>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  if (ut == 2) return launch_project_bwd_st<1, 2>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  if (ut == 3) return launch_project_bwd_st<2, 3>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
+  return launch_project_bwd_st<2, 4>(A, W, ldw, ep, dwp, si, sj, ws, ws_floats, M, hid, oup, st);
 }
-

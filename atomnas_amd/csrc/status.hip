@@ -81,7 +81,7 @@ int resident_per_cu_raw(const void* kern, int threads, size_t lds) {
 
 extern "C" const char* atomnas_last_error() { return atomnas::g_err; }
 
-extern "C" int atomnas_abi_version() { return 8; }   // ATOMNAS_ABI_VERSION in include/atomnas_hip.h
+extern "C" int atomnas_abi_version() { return 9; }   // ATOMNAS_ABI_VERSION in include/atomnas_hip.h
 
 extern "C" int atomnas_runtime_version() {
   int v = 0;

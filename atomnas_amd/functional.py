@@ -265,18 +265,23 @@ def block_backward(pl, sv, G):
     # The fused block's projection weight is one contiguous [oup, total] tensor: one launch per branch segment.
     wp_jobs = ([(sg, h, pl.Wp_grad[stt:], pl.total) for sg, stt, h in zip(pl.seg, pl.start, pl.hid)] if pl.fused
                else [(0, HT, pl.Wp_grad, HT)])
-    # early stages (oup <= 48, no SE): the weight gradient rides in the input-gradient kernel below (one pass over D)
-    fused_pb = (_FUSED_PROJECT_BWD and se is None and not pl.fused and pl.expand and pl.oup <= _FUSED_PROJECT_BWD_MAXOUP
-                and ops.project_bwd_supported(pl.oup, HT, T))
+    # early stages (oup <= 48, no SE): the weight gradient rides in the input-gradient kernel below (one pass over D), which takes the
+    # differentiated pw_bn output dP as a tensor
+    g = _hidden(pl, M2, HT, T, dev)
+    st2D = _stats(HT, dev, pl.bnd["mgr"])
+    fused_pb = (_FUSED_PROJECT_BWD and _DP_TENSOR and se is None and not pl.fused and pl.expand and pl.oup <= _FUSED_PROJECT_BWD_MAXOUP
+                and ops.project_bwd_supported(pl.oup, HT, T) and ops.project_bwd_dp_supported(M2, pl.oup, HT, G, D, g, st2D.rows))
     # late stages (oup >= 80: every row of dP feeds 23..54 GEMM tiles): the differentiated pw_bn output dP = p1*G + p2*P + p3 is
     # materialised once (a few MB) and the GEMMs below read it without a prologue -- the input-gradient GEMM then takes the streaming
     # kernel (k_gemm_nt_st), measured 84 / 102 / 74 us against 158 / 198 / 208 us with the prologue (14x14 80 / 96 wide, 7x7)
     dP = None
-    if _DP_TENSOR and not fused_pb and se is None and T == torch.bfloat16 and pl.oup % 8 == 0:
+    if _DP_TENSOR and not fused_pb and T == torch.bfloat16 and pl.oup % 8 == 0:
         dP = torch.empty(M2, pl.oup, dtype=T, device=dev)
         ops.bnbwd_apply(G, Pr, p1, p2, p3, dP, M2, pl.oup)
     for sg, nv, out, si in ([] if fused_pb else wp_jobs):
-        if se is not None:
+        if se is not None and dP is not None:
+            ops.gemm_tn(dP, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2)
+        elif se is not None:
             ops.gemm_tn(G, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3)
         elif dP is not None:
             ops.gemm_tn(dP, pl.oup, _seg(D, sg), nv, out, si, 1, M2, v_mode=PRO_BNRELU, vc1=bD.scale[sg:], vc2=bD.shift[sg:],
@@ -284,13 +289,14 @@ def block_backward(pl, sv, G):
         else:
             ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
                         vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
-    g = _hidden(pl, M2, HT, T, dev)
-    st2D = _stats(HT, dev, pl.bnd["mgr"])
     if se is not None:
         # gradient wrt the gated tensor, then back through the gate (models/mobilenet_base.py:109-112) and the activation
         HWo = Ho * Wo
         dS = _hidden(pl, M2, HT, T, dev)
-        ops.gemm_nt(G, pl.WpT_pack, dS, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3)
+        if dP is not None:   # no prologue: the wide-output GEMM takes the streaming kernel (k_gemm_nt_st)
+            ops.gemm_nt(dP, pl.WpT_pack, dS, M2, HT, pl.oup)
+        else:
+            ops.gemm_nt(G, pl.WpT_pack, dS, M2, HT, pl.oup, a_mode=PRO_BNBWD, a2=Pr, ac1=p1, ac2=p2, ac3=p3)
         nh = N * pl.se_hid
         dz2, dpooled = (_f32(N * HT, dev).view(N, HT) for _ in range(2))
         parts = ops.se_pool_parts(N, HWo, HT)
@@ -299,15 +305,11 @@ def block_backward(pl, sv, G):
         ops.se_bwd_gate(dS, D, bD.scale, bD.shift, int(act), se["gate"], se["pooled"], pl.cmap, pl.se_w1p, pl.se_w2t, se["hpre"], dgate, dz2,
                         dz1, dpooled, pl.se_dw1, pl.se_db1, pl.se_dw2, pl.se_db2, N, HWo, HT, pl.total, pl.se_hid, se_act=pl.se_act)
         ops.se_bwd_apply(dS, D, bD.scale, bD.shift, int(act), se["gate"], dpooled, g, st2D.t, M2, HWo, HT, stat_rows=st2D.rows)
-    elif fused_pb and _DP_TENSOR and ops.project_bwd_dp_supported(M2, pl.oup, HT, G, D, g, st2D.rows):
-        # dP once (a narrow tensor), then the streaming form of the fused kernel: no prologue, nothing behind a branch
+    elif fused_pb:
+        # dP once (a narrow tensor), then the streaming fused kernel: no prologue, nothing behind a branch
         dPf = torch.empty(M2, pl.oup, dtype=T, device=dev)
         ops.bnbwd_apply(G, Pr, p1, p2, p3, dPf, M2, pl.oup)
-        ops.project_bwd(dPf, None, None, None, None, pl.WpT_pack, D, bD.scale, bD.shift, int(act), g, st2D.t, pl.Wp_grad, HT, 1, M2, pl.oup,
-                        HT, stat_rows=st2D.rows)
-    elif fused_pb:
-        ops.project_bwd(G, Pr, p1, p2, p3, pl.WpT_pack, D, bD.scale, bD.shift, int(act), g, st2D.t, pl.Wp_grad, HT, 1, M2, pl.oup, HT,
-                        stat_rows=st2D.rows)
+        ops.project_bwd(dPf, pl.WpT_pack, D, bD.scale, bD.shift, int(act), g, st2D.t, pl.Wp_grad, HT, 1, M2, pl.oup, HT, stat_rows=st2D.rows)
     else:
         # projection input gradient, masked by the depthwise activation, with the depthwise-BN backward statistics
         if dP is not None:
@@ -344,10 +346,6 @@ def block_backward(pl, sv, G):
     Gx = torch.empty(M, pl.inp, dtype=T, device=dev)
     if (T == torch.bfloat16 and not pl.fused and pl.inp <= min(_EXPAND_BWD_NOE, 64) and pl.inp % 8 == 0 and x2d.stride(0) % 8 == 0):   # atomnas_gram: inp <= 64, row pitch % 8
         return _expand_backward_noe(pl, x2d, h, e1, e2, e3, G if pl.res else None, Gx, M, HT, dev, T)
-    if pl.inp <= _FUSED_EXPAND_BWD and not pl.fused and ops.expand_bwd_supported(pl.inp, HT, T):
-        # early stages (16 -> 288, 24 -> 432): input and weight gradient of the expand convolution from ONE pass over h and E
-        ops.expand_bwd(h, E, e1, e2, e3, x2d, pl.WeT_pack, G if pl.res else None, Gx, pl.We_grad, M, pl.inp, HT)
-        return Gx
     # expand weight gradient dWe[n][k] = sum_m dE[m][n] * x[m][k]  (written transposed: out[i=k][j=n] -> dWe[n*inp + k]); the
     # fused block's expand weight is one contiguous [total, inp] tensor: one launch per branch segment
     we_jobs = ([(sg, hh, pl.We_grad[stt * pl.inp:]) for sg, stt, hh in zip(pl.seg, pl.start, pl.hid)] if pl.fused
@@ -386,7 +384,7 @@ def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
     ops.xb_coeffs(e2, e3, pl.We_pack, gram, sx, inp, HT, mp, vb, pl.We_grad)
     if inp <= _FUSED_EXPAND_BWD and ops.expand_bwd_supported(inp, HT, T):
         # one pass over h: both gradients, x M + v added inside the kernel
-        ops.expand_bwd(h, None, e1, None, None, x2d, pl.WeT_pack, res, Gx, pl.We_grad, M, inp, HT, mp=mp, vb=vb)
+        ops.expand_bwd(h, e1, x2d, pl.WeT_pack, res, Gx, pl.We_grad, M, inp, HT, mp=mp, vb=vb)
         return Gx
     if (inp <= _FUSED_EXPAND_BWD and not pl.fused and pl.nb > 1 and isinstance(h, ops.Slab)
             and all(ops.expand_bwd_supported(inp, pl.segpad(hh), T) for hh in pl.hid)):
@@ -395,7 +393,7 @@ def _expand_backward_noe(pl, x2d, h, e1, e2, e3, res, Gx, M, HT, dev, T):
         # Gx only), x M + v rides in the first launch
         for i in range(pl.nb):
             o, c = pl.seg[i], pl.segpad(pl.hid[i])
-            ops.expand_bwd(_seg(h, o), None, e1[o:], None, None, x2d, pl.WeT_pack[:, o:], res if i == 0 else Gx, Gx, pl.We_grad[o * inp:], M, inp,
+            ops.expand_bwd(_seg(h, o), e1[o:], x2d, pl.WeT_pack[:, o:], res if i == 0 else Gx, Gx, pl.We_grad[o * inp:], M, inp,
                            c, mp=mp if i == 0 else None, vb=vb if i == 0 else None)
         return Gx
     gx1 = torch.empty(M, inp, dtype=T, device=dev)

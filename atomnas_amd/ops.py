@@ -283,21 +283,20 @@ def expand_bwd_workspace(inp, hid, dev):
     return torch.empty(min(1024 * inp * hid, 16 << 20), dtype=torch.float32, device=dev)
 
 
-def expand_bwd(h, e, c1, c2, c3, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None, mp=None, vb=None):
-    """Fused backward of the expand convolution (include/atomnas_hip.h): gx = dE * We (+ add), dwe += dE^T x, dE = c1*h + c2*e + c3.
-    e = None: dE = c1*h, and with mp / vb (atomnas_xb_coeffs) gx += x M + v."""
-    _chk_cuda(h, x, gx, dwe, wt_pack)   # e = None: dE = c1*h (the E-elimination form)
+def expand_bwd(h, c1, x, wt_pack, add, gx, dwe, M, inp, hid, ws=None, mp=None, vb=None):
+    """Fused backward of the expand convolution without its raw output E (include/atomnas_hip.h): gx = (c1*h) * We (+ add), dwe += (c1*h)^T x,
+    and with mp / vb (atomnas_xb_coeffs) gx += x M + v."""
+    _chk_cuda(h, x, gx, dwe, wt_pack)
     wt, ldw = wt_pack, wt_pack.stride(0)
     if ws is None:
         ws = expand_bwd_workspace(inp, hid, x.device)
     _keep(ws)
     if _lib.PROFILE is not None:
         _lib.profile_tag("M%d N%d K%d fusedbwd" % (M, inp, hid))
-    _rec("expand_bwd", M=int(M), inp=int(inp), hid=int(hid), h=_lay(h), e=_lay(e), x=_lay(x), ldw=int(ldw), add=_lay(add), gx=_lay(gx), ws_floats=int(ws.numel()),
+    _rec("expand_bwd", M=int(M), inp=int(inp), hid=int(hid), h=_lay(h), x=_lay(x), ldw=int(ldw), add=_lay(add), gx=_lay(gx), ws_floats=int(ws.numel()),
          mp=mp is not None, ldm=int(mp.stride(0)) if mp is not None else 0, vb=vb is not None, dt=dt_code(x.dtype))
-    call("atomnas_expand_bwd", _p(h), _ld(h), _ss(h), _p(e), _ld(e) if e is not None else 0, _ss(e), _p(c1), _p(c2), _p(c3), _p(x), _ld(x), _p(wt), ldw,
-         _p(add), _ld(add) if add is not None else 0, _p(gx), _ld(gx), _p(dwe), _p(ws), ws.numel(), _p(mp), mp.stride(0) if mp is not None else 0,
-         _p(vb), M, inp, hid, dt_code(x.dtype), _stream())
+    call("atomnas_expand_bwd", _p(h), _ld(h), _ss(h), _p(c1), _p(x), _ld(x), _p(wt), ldw, _p(add), _ld(add) if add is not None else 0, _p(gx), _ld(gx),
+         _p(dwe), _p(ws), ws.numel(), _p(mp), mp.stride(0) if mp is not None else 0, _p(vb), M, inp, hid, dt_code(x.dtype), _stream())
 
 
 def project_bwd_supported(oup, hid, dtype):
@@ -305,26 +304,24 @@ def project_bwd_supported(oup, hid, dtype):
 
 
 def project_bwd_dp_supported(M, oup, hid, g, z, gh, stat_rows):
-    """whether atomnas_project_bwd takes its dP form (g = the differentiated BatchNorm output) for these tensors"""
+    """whether atomnas_project_bwd serves these tensors (layouts, sizes)"""
     return bool(_lib.load().atomnas_project_bwd_dp_supported(int(M), int(oup), int(hid), _ld(g), _ld(z), _ss(z), _ld(gh), _ss(gh), int(stat_rows),
                                                              dt_code(g.dtype)))
 
 
-def project_bwd(g, p, c1, c2, c3, wpt_pack, z, zscale, zshift, act, gh, stats, dwp, si, sj, M, oup, hid, stat_rows=None, ws=None):
-    """Fused backward of the projection (include/atomnas_hip.h): masked input gradient gh with the BN-backward statistics, and
-    dwp[o*si + n*sj] += dP^T act(bn(z)), from one pass over z.  p = c1 = c2 = c3 = None: g is already dP (bnbwd_apply), the
-    streaming kernel (oup % 8 == 0, oup <= 64)."""
+def project_bwd(g, wpt_pack, z, zscale, zshift, act, gh, stats, dwp, si, sj, M, oup, hid, stat_rows=None, ws=None):
+    """Fused backward of the projection (include/atomnas_hip.h): g = dP (bnbwd_apply's output); masked input gradient gh with the
+    BN-backward statistics, and dwp[o*si + n*sj] += dP^T act(bn(z)), from one pass over z (oup % 8 == 0, oup <= 64)."""
     _chk_cuda(g, z, gh, dwp, wpt_pack)
     if ws is None:
         ws = torch.empty(min(512 * oup * hid, 16 << 20), dtype=torch.float32, device=g.device)
     _keep(ws)
     if _lib.PROFILE is not None:
-        _lib.profile_tag("M%d N%d K%d fusedbwd%s" % (M, hid, oup, "" if p is not None else "+dP"))
-    _rec("project_bwd", M=int(M), oup=int(oup), hid=int(hid), g=_lay(g), p=_lay(p), ldw=int(wpt_pack.stride(0)), z=_lay(z), act=int(act), gh=_lay(gh),
+        _lib.profile_tag("M%d N%d K%d fusedbwd+dP" % (M, hid, oup))
+    _rec("project_bwd", M=int(M), oup=int(oup), hid=int(hid), g=_lay(g), ldw=int(wpt_pack.stride(0)), z=_lay(z), act=int(act), gh=_lay(gh),
          stat_rows=_rows(stats, stat_rows), si=int(si), sj=int(sj), ws_floats=int(ws.numel()), dt=dt_code(g.dtype))
-    call("atomnas_project_bwd", _p(g), _ld(g), _p(p), _ld(p) if p is not None else 0, _p(c1), _p(c2), _p(c3), _p(wpt_pack), wpt_pack.stride(0), _p(z), _ld(z), _ss(z),
-         _p(zscale), _p(zshift), int(act), _p(gh), _ld(gh), _ss(gh), _p(stats), _rows(stats, stat_rows), _p(dwp), si, sj, _p(ws), ws.numel(),
-         M, oup, hid, dt_code(g.dtype), _stream())
+    call("atomnas_project_bwd", _p(g), _ld(g), _p(wpt_pack), wpt_pack.stride(0), _p(z), _ld(z), _ss(z), _p(zscale), _p(zshift), int(act), _p(gh),
+         _ld(gh), _ss(gh), _p(stats), _rows(stats, stat_rows), _p(dwp), si, sj, _p(ws), ws.numel(), M, oup, hid, dt_code(g.dtype), _stream())
 
 
 def bn_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, save_mean,

@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 8   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess; 8: + atomnas_gather_jobs */
+#define ATOMNAS_ABI_VERSION 9   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess; 8: + atomnas_gather_jobs; 9: atomnas_expand_bwd / atomnas_project_bwd lose their two-stream forms (arguments e, c2, c3 / p, c1, c2, c3) */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -115,54 +115,45 @@ int atomnas_pw_gemm_tn(int u_mode, const void* u, int ldu, long u_ss, const void
                        const void* v2, int ldv2, long v2_ss, const float* vc1, const float* vc2, const float* vc3, int v_relu, int NV, float* out, long si, long sj, long M,
                        float* ws, long ws_floats, int dtype, void* stream);
 
-/* Backward of the expand convolution ConvBNReLU(inp, hid, 1) (models/mobilenet_base.py:316-320) with both gradients from ONE pass
- *   over the two hidden streams (bf16 storage; shapes per atomnas_expand_bwd_supported: the early, activation-dominated stages):
- *     dE = c1*h + c2*e + c3   (BatchNorm backward; h = masked gradient of the activated hidden tensor, e = raw conv output)
- *     gx[M, inp] = dE * We (+ add: the residual branch);   dwe[n*inp + k] += sum_m dE[m][n] * x[m][k]
- *   wt = We^T packed by atomnas_pack_weights ([inp padded to 64][ldw >= hid rounded up to 32]); ws: ws_floats floats for the
- *   per-workgroup partials of the weight gradient (inp*hid floats each; summed in workgroup order).  Replaces one
- *   atomnas_pw_gemm_nt (BNBWD prologue) + one atomnas_pw_gemm_tn, which read h and e twice. */
-int atomnas_expand_bwd_supported(int inp, int hid, int dtype);
-int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const void* e, int lde, long e_ss, const float* c1, const float* c2,
-                       const float* c3, const void* x, int ldx, const void* wt, int ldw, const void* add, int ldadd, void* gx, int ldgx,
-                       float* dwe, float* ws, long ws_floats, const void* mp, int ldm, const float* vb, long M, int inp, int hid, int dtype,
-                       void* stream);
-
-/*   ABI 4: e == NULL (c2, c3 ignored): dE = c1*h -- the expand backward without E below.  Its c2 / c3 terms are inp x inp sized
- *   (atomnas_xb_coeffs): mp / vb (optional, with e == NULL only) add x M + v to gx inside the kernel; the dwe terms are added by
- *   atomnas_xb_coeffs itself. */
-
-/* ---- expand backward without the raw expand output (csrc/xbwd.hip; bf16, inp <= 64 and a multiple of 8).  With the BatchNorm
- *      backward dE = c1*h + c2*E + c3 and E = x We^T (x: the block input [M][ldx], plain layout):
- *          dX = (c1*h) We + x M + v,   dWe = diag(c1) h^T x + diag(c2) We G + c3 sx^T,     M = We^T diag(c2) We,  v = c3^T We,
- *          G = X^T X,  sx = sum_m x_m
- *      so the wide GEMMs read h alone (models/mobilenet_base.py:316-320 backward).
- * atomnas_gram: G [inp][inp] and sx [inp] from one pass over x; per-workgroup partials of inp*inp + inp floats in the caller's
- *   workspace ws (ws_floats floats, at least one partial), summed in workgroup order.
+/* Backward of the expand convolution ConvBNReLU(inp, hid, 1) (models/mobilenet_base.py:316-320) WITHOUT its raw output E, both gradients
+ *   from ONE pass over the masked hidden gradient h (bf16 storage; shapes per atomnas_expand_bwd_supported: the early, activation-dominated
+ *   stages).  With the BatchNorm backward dE = c1*h + c2*E + c3 and E = x We^T (x: the block input [M][ldx], plain layout):
+ *       dX = (c1*h) We + x M + v,   dWe = diag(c1) h^T x + diag(c2) We G + c3 sx^T,     M = We^T diag(c2) We,  v = c3^T We,
+ *       G = X^T X,  sx = sum_m x_m
+ *   the c2 / c3 terms are inp x inp sized, so the wide tensors are read once and E not at all (csrc/xbwd.hip):
+ * atomnas_gram: G [inp][inp] and sx [inp] from one pass over x (inp <= 64 and a multiple of 8); per-workgroup partials of inp*inp + inp
+ *   floats in the caller's workspace ws (ws_floats floats, at least one partial), summed in workgroup order.
  * atomnas_xb_coeffs: writes mp = bf16(M) in atomnas_pw_gemm_nt's weight layout ([inp rounded up to 64][ldm], padding zeroed by the
  *   caller), vb = v (its bias) and adds the last two terms of dWe to dwe[C*inp]; wexp: packed expand weight [C][ldwe]
- *   (atomnas_pack_weights mode 0); c2 / c3: coefficients of the C hidden channels.  The h terms are atomnas_expand_bwd (e = NULL) or
- *   atomnas_pw_gemm_nt / atomnas_pw_gemm_tn with c1 as their BNRELU scale. */
+ *   (atomnas_pack_weights mode 0); c2 / c3: coefficients of the C hidden channels.
+ * atomnas_expand_bwd (ABI 9: the two-stream form that also read E is gone; the arguments e, c2, c3 with it):
+ *     gx[M, inp] = (c1*h) * We (+ x mp^T + vb when mp != NULL) (+ add: the residual branch);   dwe[n*inp + k] += sum_m c1[n]*h[m][n] * x[m][k]
+ *   wt = We^T packed by atomnas_pack_weights ([inp padded to 64][ldw >= hid rounded up to 32]); ws: ws_floats floats for the
+ *   per-workgroup partials of the weight gradient (inp*hid floats each; summed in workgroup order).  Replaces one atomnas_pw_gemm_nt
+ *   (BNBWD prologue) + one atomnas_pw_gemm_tn, which read h and E twice.  Wider layers: the same h terms through atomnas_pw_gemm_nt /
+ *   atomnas_pw_gemm_tn with c1 as their BNRELU scale. */
+int atomnas_expand_bwd_supported(int inp, int hid, int dtype);
+int atomnas_expand_bwd(const void* h, int ldh, long h_ss, const float* c1, const void* x, int ldx, const void* wt, int ldw, const void* add,
+                       int ldadd, void* gx, int ldgx, float* dwe, float* ws, long ws_floats, const void* mp, int ldm, const float* vb, long M,
+                       int inp, int hid, int dtype, void* stream);
 int atomnas_gram(const void* x, int ldx, long M, int inp, float* ws, long ws_floats, float* gram, float* sx, int dtype, void* stream);
 int atomnas_xb_coeffs(const float* c2, const float* c3, const void* wexp, int ldwe, const float* gram, int ldg, const float* sx, int inp,
                       int C, void* mp, int ldm, float* vb, float* dwe, void* stream);
 
 /* Backward of the linear projection nn.Conv2d(hid, oup, 1) (models/mobilenet_base.py:338) in ONE pass over the raw depthwise
- *   output z (bf16 storage; shapes per atomnas_project_bwd_supported: oup <= 96; the Python layer uses it up to 48, the early stages):
- *     dP = c1*g + c2*p + c3                                      (BatchNorm backward of the block-output BN; g, p: [M, oup])
- *       or, ABI 3: p = c1 = c2 = c3 = NULL and g IS dP (atomnas_bnbwd_apply's output; oup a multiple of 8 and <= 64, hidden tensors
- *       slab-major or plain with hid % 8 == 0): the prologue-free streaming kernel
+ *   output z (bf16 storage; shapes per atomnas_project_bwd_supported: oup a multiple of 8 and <= 64; layouts per
+ *   atomnas_project_bwd_dp_supported: hidden tensors slab-major, or plain with hid % 8 == 0):
+ *     g = dP, the differentiated block-output BatchNorm as a tensor [M, oup] (atomnas_bnbwd_apply's output; ABI 9: the form that computed
+ *       c1*g + c2*p + c3 per tile from two streams is gone, the arguments p, c1, c2, c3 with it)
  *     gh[M, hid] = act'(z*zscale + zshift) * (dP * Wp),  statistics rows [sum gh, sum gh*z]
  *     dwp[o*si + n*sj] += sum_m dP[m][o] * act(z*zscale + zshift)[m][n]
  *   wpt = Wp^T packed by atomnas_pack_weights ([hid padded to 64][ldw >= oup rounded up to 32]); ws: per-row-range partials of the
- *   weight gradient (oup*hid floats each).  Replaces atomnas_pw_gemm_nt(BNBWD, mask, STAT_Z) + atomnas_pw_gemm_tn. */
+ *   weight gradient (oup*hid floats each).  Replaces atomnas_pw_gemm_nt(mask, STAT_Z) + atomnas_pw_gemm_tn on dP. */
 int atomnas_project_bwd_supported(int oup, int hid, int dtype);
-/* 1 when the dP form (p = c1 = c2 = c3 = NULL) is available for these pitches / slab strides; otherwise use the prologue form */
 int atomnas_project_bwd_dp_supported(long M, int oup, int hid, int ldg, int ldz, long z_ss, int ldgh, long gh_ss, int stat_rows, int dtype);
-int atomnas_project_bwd(const void* g, int ldg, const void* p, int ldp, const float* c1, const float* c2, const float* c3, const void* wpt,
-                        int ldw, const void* z, int ldz, long z_ss, const float* zscale, const float* zshift, int act, void* gh, int ldgh,
-                        long gh_ss, float* stats, int stat_rows, float* dwp, long si, long sj, float* ws, long ws_floats, long M, int oup,
-                        int hid, int dtype, void* stream);
+int atomnas_project_bwd(const void* g, int ldg, const void* wpt, int ldw, const void* z, int ldz, long z_ss, const float* zscale,
+                        const float* zshift, int act, void* gh, int ldgh, long gh_ss, float* stats, int stat_rows, float* dwp, long si,
+                        long sj, float* ws, long ws_floats, long M, int oup, int hid, int dtype, void* stream);
 
 /* ---- BatchNorm2d (training, eval and cumulative-calibration modes): models/mobilenet_base.py:142,342;
  *      kwargs from models/mobilenet_supernet.py:95-98; calibration mode utils/common.py:214-226.

@@ -398,9 +398,8 @@ def run_dwconv_bwd(ctx, r):
 
 
 def run_expand_bwd(ctx, r):
-    """the form without E (atomnas_expand_bwd with e == NULL): gx = (c1*h) We (+ x mp^T + vb) (+ add), dwe += (c1*h)^T x"""
+    """atomnas_expand_bwd (the expand backward without E): gx = (c1*h) We (+ x mp^T + vb) (+ add), dwe += (c1*h)^T x"""
     ops = ctx.ops
-    assert r["e"] is None, "the two-stream form is not in the bf16 step"
     M, inp, hid = r["M"], r["inp"], r["hid"]
     T = ctx.T(r["dt"])
     harg, hq = ctx.act_in(ctx.randn(M, hid), r["h"], T)
@@ -428,7 +427,7 @@ def run_expand_bwd(ctx, r):
         gx = ctx.act_out(M, inp, r["gx"], T)
         dwe = torch.full((hid * inp,), 0.25, dtype=torch.float32, device="cuda")
         ws = torch.full((r["ws_floats"],), float("nan"), dtype=torch.float32, device="cuda")
-        ops.expand_bwd(harg, None, ctx.cvec(c1), None, None, xarg, wt, addarg, gx, dwe, M, inp, hid, ws=ws, **kw)
+        ops.expand_bwd(harg, ctx.cvec(c1), xarg, wt, addarg, gx, dwe, M, inp, hid, ws=ws, **kw)
         outs.append((gx, dwe))
     torch.cuda.synchronize()
     del hold
@@ -439,9 +438,8 @@ def run_expand_bwd(ctx, r):
 
 
 def run_project_bwd(ctx, r):
-    """the dP form: gh = act'(z*zs+zh) * (dP Wp), statistics [sum gh, sum gh*z], dwp += dP^T act(z*zs+zh)"""
+    """atomnas_project_bwd on the materialised dP: gh = act'(z*zs+zh) * (dP Wp), statistics [sum gh, sum gh*z], dwp += dP^T act(z*zs+zh)"""
     ops = ctx.ops
-    assert r["p"] is None, "the prologue form is not in the bf16 step"
     M, oup, hid = r["M"], r["oup"], r["hid"]
     T = ctx.T(r["dt"])
     garg, gq = ctx.act_in(ctx.randn(M, oup), r["g"], T)
@@ -462,7 +460,7 @@ def run_project_bwd(ctx, r):
         st = ctx.stats(r["stat_rows"], hid)
         dwp = torch.full(((oup - 1) * si + (hid - 1) * sj + 1,), 0.25, dtype=torch.float32, device="cuda")
         ws = torch.full((r["ws_floats"],), float("nan"), dtype=torch.float32, device="cuda")
-        ops.project_bwd(garg, None, None, None, None, wpt, zarg, ctx.cvec(zs), ctx.cvec(zh), r["act"], gh, st, dwp, si, sj, M, oup, hid,
+        ops.project_bwd(garg, wpt, zarg, ctx.cvec(zs), ctx.cvec(zh), r["act"], gh, st, dwp, si, sj, M, oup, hid,
                         stat_rows=r["stat_rows"], ws=ws)
         outs.append((gh, st, dwp))
     torch.cuda.synchronize()

@@ -183,7 +183,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), "missing symbol " + sym
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
-    assert lib.atomnas_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.atomnas_abi_version() == _lib.ABI_VERSION == 9
     assert isinstance(lib.atomnas_last_error(), bytes)
 
 

@@ -1,5 +1,5 @@
 """Kernel-level parity (GPU) of the expand backward without E (csrc/xbwd.hip, include/atomnas_hip.h): the Gram matrix of the block
-input, the inp x inp corrections, and atomnas_expand_bwd with e = NULL -- against float64 torch restatements of
+input, the inp x inp corrections, and atomnas_expand_bwd -- against float64 torch restatements of
 models/mobilenet_base.py:316-320 (backward) on inputs rounded to bf16.
 """
 import pytest
@@ -70,7 +70,7 @@ def test_gram_and_coeffs(gpu_lib, M, inp, C):
                                        (100000, 16, 96),     # two chunks only, many row blocks per workgroup: k_expand_bwd (the streaming
                                        (90000, 24, 64)])     # kernel's tile double-buffering needs three stages per row block)
 def test_expand_bwd_without_e(gpu_lib, M, inp, hid):
-    """atomnas_expand_bwd with e = NULL: gx = (c1*h) We + add (+ x M + v), dwe += (c1*h)^T x (slab-major h: the streaming kernel
+    """atomnas_expand_bwd: gx = (c1*h) We + add (+ x M + v), dwe += (c1*h)^T x (slab-major h: the streaming kernel
     k_expand_bwd_s; the same cases through k_expand_bwd with ATOMNAS_XB_STREAM=0)"""
     ops = _ops()
     if not ops.expand_bwd_supported(inp, hid, BF):
@@ -95,7 +95,7 @@ def test_expand_bwd_without_e(gpu_lib, M, inp, hid):
     for with_m, with_add in ((False, True), (True, True), (True, False)):
         gx = torch.full((M, inp), 7.0, dtype=BF, device="cuda")
         dwe = torch.zeros(hid, inp, dtype=torch.float32, device="cuda")
-        ops.expand_bwd(hb, None, cvec(c1), None, None, xb, wt, add.to(BF).cuda().contiguous() if with_add else None, gx, dwe, M, inp, hid,
+        ops.expand_bwd(hb, cvec(c1), xb, wt, add.to(BF).cuda().contiguous() if with_add else None, gx, dwe, M, inp, hid,
                        mp=mp if with_m else None, vb=cvec(vb) if with_m else None)
         torch.cuda.synchronize()
         gref = dE @ we.to(BF).double() + (add.to(BF).double() if with_add else 0.0)
@@ -103,3 +103,36 @@ def test_expand_bwd_without_e(gpu_lib, M, inp, hid):
             gref = gref + x.to(BF).double() @ mm.to(BF).double() + vb.double().view(1, -1)
         assert_close("gx", gx, gref, rtol=1.2e-2, atol=2e-2 * float(gref.abs().max()))
         assert_close("dwe", dwe, dref, rtol=2e-3, atol=2e-3 * float(dref.abs().max()))
+
+
+@pytest.mark.parametrize("slab", [True, False])
+@pytest.mark.parametrize("M,inp,hid,res", [(5000, 24, 432, True), (777, 16, 288, False), (4100, 40, 304, True), (130, 8, 48, False),
+                                           (9000, 16, 768, True), (2500, 32, 3 * 112, False)])
+def test_expand_bwd_fused_matches_the_two_gemm_form(gpu_lib, M, inp, hid, res, slab):
+    """atomnas_expand_bwd = atomnas_pw_gemm_nt + atomnas_pw_gemm_tn with c1 as their BNRELU scale (what functional._expand_backward_noe
+    issues for the layers too wide for the fused kernel), with h read once: same products, the weight gradient grouped by workgroup
+    (rounding-level difference).  Slab-major h takes the streaming kernel (k_expand_bwd_s), plain h the register-prefetch kernel."""
+    ops = _ops()
+    assert ops.expand_bwd_supported(inp, hid, BF) and not ops.expand_bwd_supported(40, 720, BF)   # see pwconv.hip
+    g = torch.Generator().manual_seed(M + inp + hid)
+    r = lambda *s: torch.randn(*s, generator=g)
+    H = r(M, hid).to(BF).cuda()
+    Hs = ops.Slab.from_plain(H, hid) if slab else H
+    X, Gres = r(M, inp).to(BF).cuda(), r(M, inp).to(BF).cuda()
+    We = r(hid, inp) / inp ** 0.5
+    c1 = cvec(torch.rand(hid, generator=g) + 0.5)
+    zeros = torch.zeros_like(c1)
+    wt = torch.zeros(pad(inp, 64), pad(hid, 32), dtype=BF, device="cuda")
+    wt[:inp, :hid] = We.t().to(BF).cuda()
+    gx1 = torch.full((M, inp), 7.0, dtype=BF, device="cuda")
+    gx2 = gx1.clone()
+    dw1 = torch.full((hid, inp), 0.25, dtype=torch.float32, device="cuda")   # gradients ACCUMULATE into the arena
+    dw2 = dw1.clone()
+    ops.expand_bwd(Hs, c1, X, wt, Gres if res else None, gx1, dw1.view(-1), M, inp, hid)
+    ops.gemm_tn(X, inp, Hs, hid, dw2.view(-1), 1, inp, M, v_mode=ops.PRO_BNRELU, vc1=c1, vc2=zeros, v_relu=0)
+    ops.gemm_nt(Hs, wt, gx2, M, inp, hid, a_mode=ops.PRO_BNRELU, ac1=c1, ac2=zeros, a_relu=0, add=Gres if res else None)
+    torch.cuda.synchronize()
+    # the fused kernel folds c1 into the bf16 weights (input gradient) / applies it to the fp32 accumulators (weight gradient), the GEMMs
+    # round c1*h to bf16: agreement to the operand roundings
+    assert torch.allclose(gx1.float(), gx2.float(), rtol=2e-2, atol=2e-2 * float(gx2.float().abs().max()))
+    assert torch.allclose(dw1, dw2, rtol=5e-3, atol=5e-3 * float(dw2.abs().max())), float((dw1 - dw2).abs().max())

@@ -7,12 +7,12 @@ bench.py's `roofline` object reports (one C-ABI entry point), so the average dur
 """
 import csv, re, sys, collections
 
-FAMILIES = ["k_dwb_mm", "k_dwf_mm2", "k_dwf_mm", "k_gemm_nt_swg", "k_image_preprocess", "k_gather_jobs", "k_dwb_cw2", "k_dwb_cw", "k_dwf_cw", "k_gemm_nt_st", "k_gemm_nt_sw", "k_bnbwd_apply", "k_expand_bwd_s", "k_expand_bwd", "k_project_bwd_cs", "k_gemm_nt_small", "k_zero", "k_add_i64", "k_scale_by", "k_dwconv_bwd", "k_dwconv_fwd", "k_gemm_nt_cs", "k_gemm_nt_ws", "k_gemm_nt", "k_gemm_tn3", "k_gemm_tn2", "k_gemm_tn", "k_reduce_batch", "k_gram_part", "k_gram_reduce", "k_xb_coeffs", "k_se_mlp", "k_se_pool", "k_se_wgrad", "k_se_bwd_apply", "k_se_scale", "k_act_bwd_stats",
+FAMILIES = ["k_dwb_mm", "k_dwf_mm2", "k_dwf_mm", "k_gemm_nt_swg", "k_image_preprocess", "k_gather_jobs", "k_dwb_cw2", "k_dwb_cw", "k_dwf_cw", "k_gemm_nt_st", "k_gemm_nt_sw", "k_bnbwd_apply", "k_expand_bwd_s", "k_expand_bwd", "k_gemm_nt_small", "k_zero", "k_add_i64", "k_scale_by", "k_dwconv_bwd", "k_dwconv_fwd", "k_gemm_nt_ws", "k_gemm_nt", "k_gemm_tn3", "k_gemm_tn2", "k_gemm_tn", "k_reduce_batch", "k_gram_part", "k_gram_reduce", "k_xb_coeffs", "k_se_mlp", "k_se_pool", "k_se_wgrad", "k_se_bwd_apply", "k_se_scale", "k_act_bwd_stats",
             "k_bn_finalize_bwd", "k_bn_finalize_fwd", "k_bn_apply", "k_bn_act_pool", "k_pool_act_bwd", "k_bn_eval_coeffs",
             "k_reg_value", "k_reg_grad", "k_pack", "k_im2col_stem", "k_rmsprop_ema", "k_ema", "k_ce_smooth", "k_colsum",
             "k_gamma_mask", "k_mask_index", "k_gather_dim", "k_reduce_parts", "k_sum_partials", "k_se_squeeze", "k_se_mlp_fwd",
             "k_se_scale", "k_se_dgate", "k_se_mlp_bwd_img", "k_se_wgrad", "k_se_bwd_apply"]
-ENTRY = {"k_dwb_mm": "atomnas_dwconv_bwd", "k_dwf_mm2": "atomnas_dwconv_fwd", "k_dwf_mm": "atomnas_dwconv_fwd", "k_gemm_nt_swg": "atomnas_pw_gemm_nt", "k_expand_bwd_s": "atomnas_expand_bwd", "k_gemm_nt_sw": "atomnas_pw_gemm_nt", "k_dwb_cw2": "atomnas_dwconv_bwd", "k_dwb_cw": "atomnas_dwconv_bwd", "k_dwf_cw": "atomnas_dwconv_fwd", "k_gemm_nt_st": "atomnas_pw_gemm_nt", "k_expand_bwd": "atomnas_expand_bwd", "k_project_bwd_cs": "atomnas_project_bwd", "k_gemm_nt_small": "atomnas_pw_gemm_nt", "k_gemm_nt_cs": "atomnas_pw_gemm_nt", "k_gemm_nt_ws": "atomnas_pw_gemm_nt", "k_gemm_nt": "atomnas_pw_gemm_nt", "k_gemm_tn3": "atomnas_pw_gemm_tn", "k_gemm_tn2": "atomnas_pw_gemm_tn",
+ENTRY = {"k_dwb_mm": "atomnas_dwconv_bwd", "k_dwf_mm2": "atomnas_dwconv_fwd", "k_dwf_mm": "atomnas_dwconv_fwd", "k_gemm_nt_swg": "atomnas_pw_gemm_nt", "k_expand_bwd_s": "atomnas_expand_bwd", "k_gemm_nt_sw": "atomnas_pw_gemm_nt", "k_dwb_cw2": "atomnas_dwconv_bwd", "k_dwb_cw": "atomnas_dwconv_bwd", "k_dwf_cw": "atomnas_dwconv_fwd", "k_gemm_nt_st": "atomnas_pw_gemm_nt", "k_expand_bwd": "atomnas_expand_bwd", "k_gemm_nt_small": "atomnas_pw_gemm_nt", "k_gemm_nt_ws": "atomnas_pw_gemm_nt", "k_gemm_nt": "atomnas_pw_gemm_nt", "k_gemm_tn3": "atomnas_pw_gemm_tn", "k_gemm_tn2": "atomnas_pw_gemm_tn",
          "k_gemm_tn": "atomnas_pw_gemm_tn", "k_dwconv_bwd": "atomnas_dwconv_bwd", "k_dwconv_fwd": "atomnas_dwconv_fwd"}
 
 

@@ -50,7 +50,7 @@ for (N, H, inp, hid) in [(256, 112, 16, 288), (256, 56, 24, 432)]:
     def run():
         h, x, add, gx = sets[cnt[0] % 3]
         cnt[0] += 1
-        ops.expand_bwd(h, None, c1, None, None, x, wt, add, gx, dwe, M, inp, hid, ws=ws, mp=mp, vb=vb)
+        ops.expand_bwd(h, c1, x, wt, add, gx, dwe, M, inp, hid, ws=ws, mp=mp, vb=vb)
 
     t = bench(run)
     print("M%-8d inp%-3d hid%-4d: %.3f ms  (h at %4.0f GB/s)" % (M, inp, hid, t, M * hid * 2 / t / 1e6), flush=True)
