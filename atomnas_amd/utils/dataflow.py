@@ -10,6 +10,7 @@ Same iterator protocol as the reference's DataPrefetcher (__iter__ / __next__ / 
 decoder, no lmdb): loaders hand over decoded uint8 arrays, e.g. SyntheticDecodedImages below (bench.py --input-pipeline uint8).
 """
 import ctypes
+import importlib
 import random
 
 import numpy as np
@@ -44,74 +45,142 @@ def check_box(H, W, box, size):
 class DevicePrefetcher(object):
     """DataPrefetcher (utils/dataflow.py:13-58) for decoded uint8 samples.  `loader` yields batches (images, boxes, flips, targets):
     images = list of uint8 HWC tensors (pinned memory makes the copies asynchronous), boxes = list of (top, left, height, width),
-    flips = list of bool, targets = int64 tensor.  Yields (input fp32 [N, 3, S, S] on the GPU, target on the GPU)."""
+    flips = list of bool, targets = int64 tensor.  Yields (input fp32 [N, 3, S, S] on the GPU, target on the GPU).
 
-    def __init__(self, loader, image_size=224, mean=T.IMAGENET_MEAN, std=T.IMAGENET_STD, max_image_bytes=3 * 640 * 640):
+    The host side of a batch -- drawing it from the loader (the crop / flip decisions of 256 samples), the descriptor table, 256 copy
+    submissions: ~7 ms of Python -- runs in a worker thread (threaded=True, default), one batch ahead of the hand-over; the training
+    thread only waits for an event.  Two slots (pixel pool, descriptors, output) alternate; a slot is refilled only after the consumer
+    of its previous batch has been ordered behind an event on the consumer's stream."""
+
+    def __init__(self, loader, image_size=224, mean=T.IMAGENET_MEAN, std=T.IMAGENET_STD, max_image_bytes=3 * 640 * 640, threaded=True):
         if not torch.cuda.is_available():
             raise _lib.AtomnasHipError("DevicePrefetcher needs the GPU (the preprocessing kernel has no CPU fallback)")
         self.loader_len = len(loader) if hasattr(loader, "__len__") else None
         self.loader = iter(loader)
         self.size, self.mean, self.std = int(image_size), tuple(mean), tuple(std)
         self.stream = torch.cuda.Stream()
+        self.device = torch.cuda.current_device()
         self.max_image_bytes = int(max_image_bytes)
         self.slots = [None, None]   # per slot: (device pool, device descriptors, pinned descriptors, output) sized on first use
         # per slot: event behind the last host-to-device copy that READ the slot's pinned descriptors.  The host rewrites them for the
         # batch after next; nothing else orders the host against that copy (the reference's prefetcher never reuses host staging
         # memory), and a caller that does not synchronise per step (graph replay) runs several steps ahead of the device.
         self.desc_read = [None, None]
-        self.k = 0
-        self.stop = False
-        self.preload()
+        self.consumed = [None, None]   # per slot: event on the consumer's stream behind the use of the slot's previous batch
+        self.k = 0                     # batches submitted
+        self.handed = 0                # batches handed out
+        self.threaded = bool(threaded)
+        if self.threaded:
+            import queue
+            import threading
+            self._q = queue.Queue(maxsize=1)
+            self._free = [threading.Semaphore(1), threading.Semaphore(1)]
+            self._closed = False
+            self._thread = threading.Thread(target=self._work, name="atomnas-prefetch", daemon=True)
+            self._thread.start()
+        else:
+            self._pending = self._submit()
 
-    def _slot(self, n, nbytes):
-        s = self.slots[self.k & 1]
+    def _slot(self, q, n, nbytes):
+        s = self.slots[q]
         if s is None or s[0].numel() < nbytes or s[3].shape[0] != n:
             cap = max(nbytes, n * self.max_image_bytes // 4)
             s = (torch.empty(cap, dtype=torch.uint8, device="cuda"), torch.empty(n * DESC_DTYPE.itemsize, dtype=torch.uint8, device="cuda"),
                  torch.empty(n * DESC_DTYPE.itemsize, dtype=torch.uint8).pin_memory(),
                  torch.empty(n, 3, self.size, self.size, dtype=torch.float32, device="cuda"))
-            self.slots[self.k & 1] = s
+            self.slots[q] = s
         return s
 
-    def preload(self):
+    def _submit(self):
+        """draws the next batch and queues its copies and the preprocessing launch on the side stream -> (input, target, ready event)
+        or None at the end of the loader"""
         try:
             images, boxes, flips, target = next(self.loader)
         except StopIteration:
-            self.stop = True
-            self.next_input = self.next_target = None
-            return
+            return None
+        q = self.k & 1
         n = len(images)
         sizes = [int(im.numel()) for im in images]
         offs = np.concatenate([[0], np.cumsum([(b + 15) // 16 * 16 for b in sizes])])
-        # the slot's previous batch was handed out two iterations ago; its consumer ran on the current stream before this call
-        self.stream.wait_stream(torch.cuda.current_stream())
-        pool, desc_dev, desc_pin, out = self._slot(n, int(offs[-1]))
-        ev = self.desc_read[self.k & 1]
+        pool, desc_dev, desc_pin, out = self._slot(q, n, int(offs[-1]))
+        ev = self.desc_read[q]
         if ev is not None:
             ev.synchronize()   # the copy queued two batches ago has read desc_pin (normally long done: no wait in steady state)
         d = np.frombuffer(desc_pin.numpy(), dtype=DESC_DTYPE)
-        for q, (im, box, fl) in enumerate(zip(images, boxes, flips)):
+        for i, (im, box, fl) in enumerate(zip(images, boxes, flips)):
             H, W = int(im.shape[0]), int(im.shape[1])
             check_box(H, W, box, self.size)
-            d[q] = (int(offs[q]), H, W, box[0], box[1], box[2], box[3], 1 if fl else 0, 0)
+            d[i] = (int(offs[i]), H, W, box[0], box[1], box[2], box[3], 1 if fl else 0, 0)
         with torch.cuda.stream(self.stream):
-            for q, im in enumerate(images):
-                pool[int(offs[q]):int(offs[q]) + sizes[q]].copy_(im.reshape(-1), non_blocking=True)
+            if self.consumed[q] is not None:
+                self.stream.wait_event(self.consumed[q])   # the slot's previous batch has been consumed (handed out two batches ago)
+            for i, im in enumerate(images):
+                pool[int(offs[i]):int(offs[i]) + sizes[i]].copy_(im.reshape(-1), non_blocking=True)
             desc_dev.copy_(desc_pin, non_blocking=True)
-            ev = self.desc_read[self.k & 1] = self.desc_read[self.k & 1] or torch.cuda.Event()
+            ev = self.desc_read[q] = self.desc_read[q] or torch.cuda.Event()
             ev.record(self.stream)
             preprocess(pool, desc_dev, n, self.size, self.mean, self.std, out, 0, self.stream)
-            self.next_target = target.cuda(non_blocking=True)
-        self.next_input = out
+            tgt = target.cuda(non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
         self.k += 1
+        return out, tgt, ready
+
+    def _work(self):
+        torch.cuda.set_device(self.device)
+        try:
+            while not self._closed:
+                self._free[self.k & 1].acquire()
+                if self._closed:
+                    break
+                item = self._submit()
+                self._q.put(item)
+                if item is None:
+                    break
+        except BaseException as e:   # handed to the consumer, which re-raises it
+            self._q.put(e)
 
     def __next__(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
-        if self.stop:
+        cur = torch.cuda.current_stream()
+        if self.handed > 0:
+            # everything the caller has queued on its stream so far -- the use of the batch handed out last time included -- is in front
+            # of this event: the slot of that batch may be refilled behind it
+            q = (self.handed - 1) & 1
+            ev = self.consumed[q] = self.consumed[q] or torch.cuda.Event()
+            ev.record(cur)
+            if self.threaded:
+                self._free[q].release()
+        if self.threaded:
+            item = self._q.get()
+            if isinstance(item, BaseException):
+                raise item
+        else:
+            item, self._pending = self._pending, None
+        if item is None:
             raise StopIteration
-        inp, tgt = self.next_input, self.next_target
-        self.preload()
-        return inp, tgt
+        out, tgt, ready = item
+        cur.wait_event(ready)
+        self.handed += 1
+        if not self.threaded:
+            self._pending = self._submit_after_consume()
+        return out, tgt
+
+    def _submit_after_consume(self):
+        # synchronous mode: the next batch is submitted right away (it fills the OTHER slot; its own slot's consumer event, recorded
+        # one hand-over ago, is waited for on the side stream)
+        return self._submit()
+
+    def close(self):
+        if self.threaded:
+            self._closed = True
+            for s in self._free:
+                s.release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __iter__(self):
         return self
@@ -158,3 +227,178 @@ class SyntheticDecodedImages(object):
                 random.setstate(self.rng_state)
         finally:
             random.setstate(saved)
+
+
+# ---------------------------------------------------------------------------------------------- the reference's factories
+# data_transforms / dataset / data_loader (utils/dataflow.py:92-267): same names, signatures and FLAGS keys, so that
+# `train.py app:<yml>` reaches the GPU input pipeline from the yaml.  What differs is WHERE the pixel work happens: a transform here
+# only decides (crop box, flip) per sample, the dataset hands out decoded uint8 images with those decisions, and DevicePrefetcher
+# runs crop / resize / flip / ToTensor / Normalize in one kernel per batch.  JPEG decoding and LMDB reading are not available in
+# this image (no decoder, no lmdb): 'imagenet1k' and 'imagenet1k_lmdb' raise and say so.
+class DeviceTransform(object):
+    """What data_transforms returns per split: the deciders of a transform chain whose pixel work is atomnas_image_preprocess.
+    transform(img) -> ((top, left, height, width), flip) for a decoded image (HWC array / tensor, PIL image or (width, height))."""
+
+    def __init__(self, crop, flip, size, mean, std):
+        self.crop, self.flip, self.size, self.mean, self.std = crop, flip, int(size), tuple(mean), tuple(std)
+
+    def __call__(self, img):
+        box = self.crop(img)   # random draws in the reference's order: the crop's, then the flip's
+        return box, (bool(self.flip()) if self.flip is not None else False)
+
+    def __repr__(self):
+        return "DeviceTransform({}, {}, size={})".format(self.crop, self.flip, self.size)
+
+
+def data_transforms(FLAGS):
+    """Get transform of dataset (utils/dataflow.py:92-170) -> (train_transforms, val_transforms, test_transforms)."""
+    name = FLAGS.data_transforms
+    if name == 'imagenet1k_mnas_bilinear':
+        size = int(FLAGS.get('image_size', 224)) if hasattr(FLAGS, 'get') else 224
+        (crop, flip), (vcrop, _) = T.mnas_bilinear_transforms(size)
+        train = DeviceTransform(crop, flip, size, T.IMAGENET_MEAN, T.IMAGENET_STD)
+        val = DeviceTransform(vcrop, None, size, T.IMAGENET_MEAN, T.IMAGENET_STD)
+        return train, val, val
+    if name == 'imagenet1k_mnas_bicubic':
+        raise NotImplementedError("data_transforms 'imagenet1k_mnas_bicubic': atomnas_image_preprocess implements PIL's BILINEAR resampler only "
+                                  "(use 'imagenet1k_mnas_bilinear'; bicubic is the same machinery with support 2, not built)")
+    if name in ('imagenet1k_basic', 'imagenet1k_inception', 'imagenet1k_mobile'):
+        raise NotImplementedError("data_transforms '{}': ColorJitter / Lighting have no device kernel here".format(name))
+    try:
+        transforms_lib = importlib.import_module(name)
+        return transforms_lib.data_transforms()
+    except ImportError:
+        raise NotImplementedError('Data transform {} is not yet implemented.'.format(name))
+
+
+class FakeData(object):
+    """utils/dataflow.py:61-89: `size` samples of one all-zero image with label 0 (the reference's smoke data source)."""
+
+    def __init__(self, size=1000, image_size=(3, 224, 224), num_classes=10):
+        self.size, self.image_size, self.num_classes = size, image_size, num_classes
+        self.img = torch.zeros(image_size)
+        self.target = 0
+
+    def __getitem__(self, index):
+        if index >= len(self):
+            raise IndexError("{} index out of range".format(self.__class__.__name__))
+        return self.img, self.target
+
+    def __len__(self):
+        return self.size
+
+
+class DecodedFakeData(object):
+    """`size` decoded samples for the GPU input pipeline: a pool of uint8 HWC images of ImageNet-like sizes in pinned memory (sample i
+    is image i mod pool) with seeded labels; __getitem__ applies the split's DeviceTransform and returns (image, box, flip, target).
+    Stand-in for ImageFolder / ImageFolderLMDB + a JPEG decoder, which this image cannot provide."""
+
+    def __init__(self, size, transform, num_classes=1000, pool_size=64, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        pin = torch.cuda.is_available()
+        self.images = []
+        for q in range(pool_size):
+            H, W = SyntheticDecodedImages.SIZES[q % len(SyntheticDecodedImages.SIZES)]
+            im = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, generator=g)
+            self.images.append(im.pin_memory() if pin else im)
+        self.labels = torch.randint(0, num_classes, (pool_size * 16,), generator=g).tolist()
+        self.size, self.transform, self.num_classes = int(size), transform, num_classes
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, index):
+        if index >= self.size:
+            raise IndexError("{} index out of range".format(self.__class__.__name__))
+        im = self.images[index % len(self.images)]
+        box, flip = self.transform(im)
+        return im, box, flip, self.labels[index % len(self.labels)]
+
+
+def dataset(train_transforms, val_transforms, test_transforms, FLAGS):
+    """Get dataset for classification (utils/dataflow.py:173-211) -> (train_set, val_set, test_set)."""
+    name = FLAGS.dataset
+    if name == 'imagenet1k_fake':
+        shape = (3, FLAGS.image_size, FLAGS.image_size)
+        return FakeData(size=1281167, image_size=shape, num_classes=1000), FakeData(size=50000, image_size=shape, num_classes=1000), None
+    if name == 'imagenet1k_decoded_fake':
+        ntrain, nval = int(FLAGS.get('fake_train_size', 1281167)), int(FLAGS.get('fake_val_size', 50000))
+        seed = int(FLAGS.get('random_seed', 0))
+        train_set = DecodedFakeData(ntrain, train_transforms, seed=seed) if (not FLAGS.get('test_only', False) or FLAGS.get('bn_calibration', False)) else None
+        return train_set, DecodedFakeData(nval, val_transforms, seed=seed + 1), None
+    if name in ('imagenet1k', 'imagenet1k_lmdb'):
+        raise NotImplementedError("dataset '{}': needs a JPEG decoder{} (not in this image); decoded sources: 'imagenet1k_decoded_fake' or a "
+                                  "module with dataset(train_transforms, val_transforms, test_transforms)".format(name, " and lmdb" if name.endswith('lmdb') else ""))
+    try:
+        dataset_lib = importlib.import_module(name)
+        return dataset_lib.dataset(train_transforms, val_transforms, test_transforms)
+    except ImportError:
+        raise NotImplementedError('Dataset {} is not yet implemented.'.format(name))
+
+
+class DecodedLoader(object):
+    """torch.utils.data.DataLoader's role for decoded samples (utils/dataflow.py:217-225 `_build_loader`): batches of `batch_size`
+    samples (image, box, flip, target) -> (images, boxes, flips, targets int64 pinned), the form DevicePrefetcher takes.  shuffle:
+    a fresh seeded permutation per pass; rank / world: the DistributedSampler split (every rank the same number of samples, the
+    index list padded by wrapping around); drop_last as torch's.  Samples are drawn in the iterating thread -- with DevicePrefetcher
+    that is its worker thread, off the training thread."""
+
+    def __init__(self, dset, batch_size, shuffle, rank=0, world=1, drop_last=False, seed=0):
+        self.dset, self.batch_size, self.shuffle = dset, int(batch_size), bool(shuffle)
+        self.rank, self.world, self.drop_last, self.seed = int(rank), int(world), bool(drop_last), int(seed)
+        self.epoch = 0
+        n = len(dset)
+        self.per_rank = (n + self.world - 1) // self.world
+
+    def __len__(self):
+        return self.per_rank // self.batch_size if self.drop_last else (self.per_rank + self.batch_size - 1) // self.batch_size
+
+    def _indices(self):
+        n = len(self.dset)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(n, generator=g).tolist()
+        else:
+            idx = list(range(n))
+        total = self.per_rank * self.world
+        idx += idx[:total - n]
+        return idx[self.rank:total:self.world]
+
+    def __iter__(self):
+        idx = self._indices()
+        self.epoch += 1
+        pin = torch.cuda.is_available()
+        for b in range(len(self)):
+            chunk = idx[b * self.batch_size:(b + 1) * self.batch_size]
+            samples = [self.dset[i] for i in chunk]
+            target = torch.tensor([s[3] for s in samples], dtype=torch.int64)
+            yield [s[0] for s in samples], [s[1] for s in samples], [s[2] for s in samples], (target.pin_memory() if pin else target)
+
+
+def data_loader(train_set, val_set, test_set, FLAGS):
+    """Get data loader (utils/dataflow.py:214-267) -> (train_loader, calib_loader, val_loader, test_loader).  `data_loader_workers`
+    is accepted and unused: there is no per-sample pixel work left on the host to spread over worker processes."""
+    if FLAGS.data_loader != 'imagenet1k_basic':
+        try:
+            data_loader_lib = importlib.import_module(FLAGS.data_loader)
+            return data_loader_lib.data_loader(train_set, val_set, test_set)
+        except ImportError:
+            raise NotImplementedError('Data loader {} is not yet implemented.'.format(FLAGS.data_loader))
+    rank = world = None
+    if FLAGS.use_distributed:
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+    training = not FLAGS.get('test_only', False)
+    calibrating = bool(FLAGS.get('bn_calibration', False))
+    seed = int(FLAGS.get('random_seed', 0))
+
+    def _build_loader(dset, batch_size, shuffle):
+        # distributed: the sampler shuffles (DistributedSampler's default) and the loader does not; single process: the loader does
+        return DecodedLoader(dset, batch_size, shuffle if world is None else True, rank=rank or 0, world=world or 1,
+                             drop_last=FLAGS.get('drop_last', False), seed=seed)
+
+    train_loader = _build_loader(train_set, FLAGS._loader_batch_size, True) if training else None
+    calib_loader = _build_loader(train_set, FLAGS.get('_loader_batch_size_calib', FLAGS._loader_batch_size), True) if calibrating else None
+    val_loader = _build_loader(val_set, FLAGS._loader_batch_size, False) if world is None else \
+        DecodedLoader(val_set, FLAGS._loader_batch_size, True, rank=rank, world=world, drop_last=FLAGS.get('drop_last', False), seed=seed)
+    return train_loader, calib_loader, val_loader, val_loader

@@ -127,3 +127,71 @@ def test_pil_resize_restatement_matches_the_committed_fixture():
         assert np.array_equal(got, c["resized"].numpy()), (c["box"], c["size"], c["flip"])
         t = pr.to_tensor_normalize(got, g["mean"], g["std"])
         assert t.dtype == np.float32 and t.shape == (3, c["size"], c["size"])
+
+
+# ---- the reference's factories (utils/dataflow.py:92-267) over decoded sources: host logic, no GPU
+class _Flags(dict):
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _flags(**kw):
+    f = _Flags(data_transforms="imagenet1k_mnas_bilinear", dataset="imagenet1k_decoded_fake", data_loader="imagenet1k_basic", image_size=224,
+               use_distributed=False, test_only=False, bn_calibration=True, fake_train_size=50, fake_val_size=11, random_seed=3,
+               _loader_batch_size=8, _loader_batch_size_calib=4, data_loader_workers=62)
+    f.update(kw)
+    return f
+
+
+def test_data_factories_have_the_reference_protocol():
+    from atomnas_amd.utils import dataflow as DF
+    F = _flags()
+    tr, va, te = DF.data_transforms(F)
+    assert va is te and tr.size == 224 and tr.mean == T.IMAGENET_MEAN and va.flip is None
+    train_set, val_set, test_set = DF.dataset(tr, va, te, F)
+    assert (len(train_set), len(val_set), test_set) == (50, 11, None)
+    train_loader, calib_loader, val_loader, test_loader = DF.data_loader(train_set, val_set, test_set, F)
+    assert (len(train_loader), len(calib_loader), len(val_loader)) == (7, 13, 2) and test_loader is val_loader
+    random.seed(5)
+    batches = list(train_loader)
+    assert [len(b[0]) for b in batches] == [8] * 6 + [2]
+    images, boxes, flips, target = batches[0]
+    assert images[0].dtype == torch.uint8 and images[0].dim() == 3 and target.dtype == torch.int64 and len(boxes) == len(flips) == 8
+    for im, (i, j, h, w) in zip(images, boxes):
+        assert 0 <= i and 0 <= j and i + h <= im.shape[0] and j + w <= im.shape[1]
+    # validation: centre crops, no flips, dataset order
+    vb = list(val_loader)
+    assert not any(vb[0][2]) and [len(b[0]) for b in vb] == [8, 3]
+    assert vb[0][1][0] == T.CenterCropPadding(224, 32).get_box(vb[0][0][0])
+    # drop_last, and the DistributedSampler split: every rank the same number of samples, together they cover the set
+    F2 = _flags(drop_last=True)
+    assert len(DF.data_loader(train_set, val_set, None, F2)[0]) == 6
+    seen = []
+    for r in range(3):
+        ld = DF.DecodedLoader(val_set, 2, False, rank=r, world=3)
+        got = [t for b in ld for t in b[3].tolist()]
+        assert len(got) == 4
+        seen.append(got)
+    labels = [val_set[i][3] for i in range(11)]
+    assert sorted(sum(seen, [])) == sorted(labels + labels[:1])
+
+
+def test_data_factories_refuse_what_this_image_cannot_do():
+    from atomnas_amd.utils import dataflow as DF
+    with pytest.raises(NotImplementedError, match="BILINEAR"):
+        DF.data_transforms(_flags(data_transforms="imagenet1k_mnas_bicubic"))
+    with pytest.raises(NotImplementedError):
+        DF.data_transforms(_flags(data_transforms="imagenet1k_basic"))
+    with pytest.raises(NotImplementedError, match="not yet implemented"):
+        DF.data_transforms(_flags(data_transforms="no_such_module_xyz"))
+    with pytest.raises(NotImplementedError, match="JPEG"):
+        DF.dataset(None, None, None, _flags(dataset="imagenet1k_lmdb"))
+    with pytest.raises(NotImplementedError, match="not yet implemented"):
+        DF.data_loader(None, None, None, _flags(data_loader="no_such_loader_xyz"))
+    with pytest.raises(NotImplementedError, match="BILINEAR"):
+        T.RandomResizedCropPadding(224, interpolation=3)   # PIL.Image.BICUBIC
+    T.RandomResizedCropPadding(224, interpolation=2)       # BILINEAR is what the kernel implements
+    fake = DF.dataset(None, None, None, _flags(dataset="imagenet1k_fake"))   # the reference's zero-image smoke source keeps its form
+    assert len(fake[0]) == 1281167 and fake[0][0][0].shape == (3, 224, 224) and fake[0][0][1] == 0

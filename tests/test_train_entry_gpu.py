@@ -27,3 +27,17 @@ def test_train_entry_runs_two_epochs(gpu_lib, tmp_path):
     out2 = r2.stdout + r2.stderr
     assert r2.returncode == 0, out2[-4000:]
     assert "Epoch 2/3" in out2 and "Epoch 0/3" not in out2, out2[-3000:]
+
+
+def test_train_entry_on_the_gpu_input_pipeline(gpu_lib, tmp_path):
+    """the same entry fed by `dataset: imagenet1k_decoded_fake`: data_transforms('imagenet1k_mnas_bilinear') / dataset / data_loader
+    (the reference's factories, utils/dataflow.py:92-267) -> DevicePrefetcher -> TrainStep.set_batch; calibration and validation
+    batches through the same pipeline"""
+    env = dict(os.environ, ATOMNAS_E2E_DIR=str(tmp_path), ARNOLD_OUTPUT=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "app:" + os.path.join(ROOT, "tests", "data", "tiny_search_decoded.yml")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert out.count(" val: ") >= 2 and "Prune threshold" in out, out[-4000:]
+    assert out.count(" step ") >= 6, out[-4000:]   # 2 epochs x 3 steps were trained on pipeline batches
+    assert os.path.exists(os.path.join(str(tmp_path), "latest_checkpoint.pt"))

@@ -4,7 +4,10 @@
 Same entry, yaml semantics and loop order as the reference's train.py (run_one_epoch :130-250, per-epoch validate / mask /
 shrink :364-411, checkpoint :395-411), with the iteration executed by atomnas_amd.engine.TrainStep (one replayed hipGraph
 per iteration, RCCL all-reduce of the gradient arena).  Under a launcher (torch.distributed.run) one process drives one GPU.
-Input pipeline: `dataset: imagenet1k_fake` (synthetic, device resident) -- the JPEG/LMDB pipeline is outside this path.
+Input: `dataset: imagenet1k_fake` (synthetic, device resident: the benchmark protocol) or any decoded source through the reference's
+factories utils.dataflow.data_transforms / dataset / data_loader (`dataset: imagenet1k_decoded_fake`, or a module of your own) ->
+utils.dataflow.DevicePrefetcher (crop / PIL-exact bilinear resize / flip / normalize on the GPU) -> TrainStep.set_batch.  JPEG decoding
+and LMDB reading are not available in this image.
 """
 import logging
 import os
@@ -21,6 +24,22 @@ from atomnas_amd.utils import optim, prune
 from atomnas_amd.utils.common import bn_calibration, get_params_by_name, set_random_seed
 
 NUM_IMAGENET_TRAIN = 1281167
+
+
+LOADERS = None   # (train_loader, calib_loader, val_loader, test_loader) when the yaml names a decoded data source; None: synthetic batches
+
+
+def device_batches(loader, steps):
+    """at most `steps` batches of `loader` through the GPU input pipeline (train.py:215-218 of the reference: DataPrefetcher)"""
+    from atomnas_amd.utils import dataflow
+    pre = dataflow.DevicePrefetcher(loader, image_size=cfg.FLAGS.image_size)
+    try:
+        for i, (x, y) in enumerate(pre):
+            if i >= steps:
+                break
+            yield x, y
+    finally:
+        pre.close()
 
 
 def fake_batches(batch, image_size, num_classes, steps, seed):
@@ -83,14 +102,18 @@ def validate(epoch, model_wrapper, ema, criterion, meters, steps):
         model.eval()
         model.apply(bn_calibration)
         with torch.no_grad():
-            for x, y in fake_batches(FLAGS.bn_calibration_per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'],
-                                     FLAGS.bn_calibration_steps, 7 + epoch):
+            calib = (device_batches(LOADERS[1], FLAGS.bn_calibration_steps) if LOADERS is not None and LOADERS[1] is not None else
+                     fake_batches(FLAGS.bn_calibration_per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'],
+                                  FLAGS.bn_calibration_steps, 7 + epoch))
+            for x, y in calib:
                 model(x)
         if FLAGS.use_distributed:
             udist.allreduce_bn(model)
     model.eval()
     with torch.no_grad():
-        for x, y in fake_batches(FLAGS.per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'], steps, 11):
+        val = (device_batches(LOADERS[2], steps) if LOADERS is not None and LOADERS[2] is not None else
+               fake_batches(FLAGS.per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'], steps, 11))
+        for x, y in val:
             mc.forward_loss(model, criterion, x, y, meters)
     return meters.flush(), eval_wrapper
 
@@ -173,8 +196,12 @@ def train_val_test():
     for epoch in range(last_epoch + 1, FLAGS.num_epochs):
         model.train()
         t0, seen = time.time(), 0
-        for x, y in fake_batches(FLAGS.per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'], steps_per_epoch,
-                                 FLAGS.get('random_seed', 0) + rank + 1000 * epoch):
+        batches = (device_batches(LOADERS[0], steps_per_epoch) if LOADERS is not None else
+                   fake_batches(FLAGS.per_gpu_batch_size, FLAGS.image_size, FLAGS.model_kwparams['num_classes'], steps_per_epoch,
+                                FLAGS.get('random_seed', 0) + rank + 1000 * epoch))
+        for x, y in batches:
+            if x.shape[0] != FLAGS.per_gpu_batch_size:
+                continue   # a short last batch: the captured step has a static batch (drop_last: True avoids drawing it)
             step.set_batch(x, y)
             step.global_step = FLAGS._global_step
             step.step(lr=optimizer.param_groups[0]['lr'], rho=rho_scheduler(FLAGS._global_step))
@@ -222,9 +249,20 @@ def main():
     import common as mc
     FLAGS = cfg.load_app(sys.argv[1:])
     logging.basicConfig(stream=sys.stdout, level=logging.INFO, format='%(asctime)s %(message)s')
+    global LOADERS
+    num_train = NUM_IMAGENET_TRAIN
+    sets = None
     if FLAGS.get('dataset', 'imagenet1k_fake') != 'imagenet1k_fake':
-        raise NotImplementedError('only the synthetic `imagenet1k_fake` source is implemented (input pipeline is out of scope)')
-    mc.setup_distributed(NUM_IMAGENET_TRAIN)
+        # the reference's three factories (train.py:330-339 / utils/dataflow.py:92-267) over a decoded source
+        from atomnas_amd.utils import dataflow
+        if FLAGS.get('bn_calibration', False):
+            FLAGS._loader_batch_size_calib = FLAGS.bn_calibration_per_gpu_batch_size
+        sets = dataflow.dataset(*dataflow.data_transforms(FLAGS), FLAGS)
+        if sets[0] is not None:
+            num_train = len(sets[0])
+    mc.setup_distributed(num_train)
+    if sets is not None:
+        LOADERS = dataflow.data_loader(*sets, FLAGS)
     if udist.is_master():
         logging.info(FLAGS)
     set_random_seed(FLAGS.get('random_seed', 0))
