@@ -57,6 +57,7 @@ SIGNATURES = {
     "atomnas_gram": [vp, i32, i64, i32, vp, i64, vp, vp, i32, vp],
     "atomnas_image_preprocess": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
     "atomnas_xb_coeffs": [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp],
+    "atomnas_fold_jobs": [vp, i32, i32, i64, i64, vp],
 }
 NO_STATUS = {"atomnas_last_error": (ctypes.c_char_p, []), "atomnas_abi_version": (i32, []),
              "atomnas_runtime_version": (i32, []), "atomnas_expand_bwd_supported": (i32, [i32, i32, i32]),

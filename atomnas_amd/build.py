@@ -100,7 +100,7 @@ def _compile(src):
 
 # sources whose inline-asm loads / counted LDS-DMA waits tools/check_asm_waits.py verifies on the ISA: their device assembly is kept
 # next to the objects (csrc/build/*.s, stamped with the same digest) so that the check in the CPU test suite costs a parse, not a compile
-ISA_CHECKED = ("dwconv_cw.hip", "dwconv.hip", "dwconv_mm.hip", "dwconv_mm2.hip", "pwconv.hip", "xbwd.hip")
+ISA_CHECKED = ("dwconv_cw.hip", "dwconv.hip", "dwconv_mm.hip", "dwconv_mm2.hip", "pwconv.hip", "pwconv_tn.hip", "xbwd.hip")
 
 
 def assemble(src):

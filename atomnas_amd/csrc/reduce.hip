@@ -163,3 +163,47 @@ extern "C" int atomnas_reduce_flush(void* stream) {
   if (g_rj.empty()) return 0;
   return flush_jobs_locked((hipStream_t)stream);
 }
+
+
+// ---- fold jobs (ABI 9): dst[r][c] += src[r][c]; src[r][c] = 0 over a table of 2-D blocks, one launch for the whole table (or a slice).
+// The fused block of AtomNAS+ keeps its expand / projection weights as ONE contiguous tensor over all kernel-size groups, as the
+// reference's state_dict has them (models/mobilenet_base.py:236-254), while the kernels run on branch segments padded to whole 16-channel
+// slabs: the weight gradient of a layer is computed by ONE weight-gradient GEMM into a padded scratch matrix and folded into the
+// contiguous gradient arena here, segment by segment (round 5 launched one GEMM per segment: 128 launches per AtomNAS-C+ step).  The
+// source is cleared on the way, so the scratch is ready for the next accumulation without a fill.
+namespace atomnas {
+struct FoldJob {
+  float* src;
+  float* dst;
+  long src_ld, dst_ld;
+  int rows, cols;
+  unsigned blk0;   // first workgroup of the job, ascending over the table
+  int pad_;
+};
+static_assert(sizeof(FoldJob) == 48, "atomnas_fold_job layout");
+
+__global__ __launch_bounds__(256) void k_fold_jobs(const FoldJob* __restrict__ jobs, int njobs, unsigned blk_base) {
+  const unsigned b = blockIdx.x + blk_base;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {   // the last job whose first block is <= b (uniform)
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const FoldJob jb = jobs[lo];
+  const long e = (long)(b - jb.blk0) * 256 + threadIdx.x;
+  if (e >= (long)jb.rows * jb.cols) return;
+  const int r = (int)(e / jb.cols), c = (int)(e % jb.cols);
+  float* s = jb.src + r * jb.src_ld + c;
+  jb.dst[r * jb.dst_ld + c] += *s;
+  *s = 0.f;
+}
+}  // namespace atomnas
+
+// jobs_dev: device array of atomnas_fold_job (include/atomnas_hip.h), blk0 ascending, one workgroup per 256 elements of a job; the launch
+// covers jobs first .. first + njobs - 1: blk_base = blk0 of job `first`, nblocks = the workgroups of that slice.  Blocks must not overlap.
+extern "C" int atomnas_fold_jobs(const void* jobs_dev, int first, int njobs, long blk_base, long nblocks, void* stream) {
+  ATOMNAS_REQUIRE(jobs_dev && first >= 0 && njobs > 0 && blk_base >= 0 && nblocks > 0 && blk_base + nblocks < (1L << 31), "fold_jobs: bad arguments");
+  hipLaunchKernelGGL(atomnas::k_fold_jobs, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                     (const atomnas::FoldJob*)jobs_dev + first, njobs, (unsigned)blk_base);
+  return atomnas::check_launch("fold_jobs");
+}

@@ -145,6 +145,8 @@ _FUSED_EXPAND_BWD = int(os.environ.get("ATOMNAS_FUSED_EXPAND_BWD", "48"))   # ex
 # the per-segment launches of 40 -> 720; the 31.41 of profiles/r04_expand_bwd_noe_ab.txt for 48 predates that kernel).
 _EXPAND_BWD_NOE = int(os.environ.get("ATOMNAS_EXPAND_BWD_NOE", "48"))
 _PLAIN_HIDDEN = bool(int(os.environ.get("ATOMNAS_PLAIN_HIDDEN", "0")))
+# fused block (AtomNAS+): one weight-gradient GEMM per layer into a padded scratch + fold jobs (0: one GEMM per kernel-size segment)
+_FUSED_WG_BATCH = bool(int(os.environ.get("ATOMNAS_FUSED_WG_BATCH", "1")))
 _DP_TENSOR = bool(int(os.environ.get("ATOMNAS_DP_TENSOR", "1")))   # experiment switch: 0 = the BatchNorm-backward prologue in every GEMM tile
 TAIL_TAP = None   # set to a list by tests to receive the dropout keep mask of every tail forward
 # set to a list by tests to receive, for every activation the forward applies, (kind, plan, raw tensor, scale, shift): the pre-activation
@@ -278,6 +280,10 @@ def block_backward(pl, sv, G):
     if _DP_TENSOR and not fused_pb and T == torch.bfloat16 and pl.oup % 8 == 0:
         dP = torch.empty(M2, pl.oup, dtype=T, device=dev)
         ops.bnbwd_apply(G, Pr, p1, p2, p3, dP, M2, pl.oup)
+    if pl.fused and _FUSED_WG_BATCH:
+        # ONE launch over the padded width into the layer's scratch matrix, folded into the contiguous [oup, total] gradient per segment
+        mgr = pl.mgr
+        wp_jobs = [(0, HT, mgr.FW[pl.Wp_scratch_off:pl.Wp_scratch_off + pl.oup * HT], HT)]
     for sg, nv, out, si in ([] if fused_pb else wp_jobs):
         if se is not None and dP is not None:
             ops.gemm_tn(dP, pl.oup, _seg(se["S"], sg), nv, out, si, 1, M2)
@@ -289,6 +295,8 @@ def block_backward(pl, sv, G):
         else:
             ops.gemm_tn(G, pl.oup, _seg(D, sg), nv, out, si, 1, M2, u_mode=PRO_BNBWD, u2=Pr, uc1=p1, uc2=p2, uc3=p3, v_mode=PRO_BNRELU,
                         vc1=bD.scale[sg:], vc2=bD.shift[sg:], v_relu=int(act))
+    if pl.fused and _FUSED_WG_BATCH:
+        ops.fold_jobs(pl.mgr, pl.fold_first, pl.fold_np)
     if se is not None:
         # gradient wrt the gated tensor, then back through the gate (models/mobilenet_base.py:109-112) and the activation
         HWo = Ho * Wo
@@ -350,9 +358,13 @@ def block_backward(pl, sv, G):
     # fused block's expand weight is one contiguous [total, inp] tensor: one launch per branch segment
     we_jobs = ([(sg, hh, pl.We_grad[stt * pl.inp:]) for sg, stt, hh in zip(pl.seg, pl.start, pl.hid)] if pl.fused
                else [(0, HT, pl.We_grad)])
+    if pl.fused and _FUSED_WG_BATCH:
+        we_jobs = [(0, HT, pl.mgr.FW[pl.We_scratch_off:pl.We_scratch_off + HT * pl.inp])]
     for sg, nv, out in we_jobs:
         ops.gemm_tn(x2d, pl.inp, _seg(h, sg), nv, out, 1, pl.inp, M, v_mode=PRO_BNBWD, v2=_seg(E, sg), vc1=e1[sg:], vc2=e2[sg:],
                     vc3=e3[sg:])
+    if pl.fused and _FUSED_WG_BATCH:
+        ops.fold_jobs(pl.mgr, pl.fold_first + pl.fold_np, pl.fold_ne)
     # expand input gradient (+ residual branch)
     ops.gemm_nt(h, pl.WeT_pack, Gx, M, pl.inp, HT, a_mode=PRO_BNBWD, a2=E, ac1=e1, ac2=e2, ac3=e3, add=G if pl.res else None)
     return Gx

@@ -70,8 +70,42 @@ _DEFER_BYTES = [0]
 _DEFER_LIMIT = 512 << 20   # partial workspaces kept alive before an early flush: bounds the extra peak memory of the deferral
 
 
+# ---- fold jobs of the fused block (csrc/reduce.hip k_fold_jobs): a layer's weight gradient is accumulated in a padded scratch matrix by ONE
+# weight-gradient GEMM and folded into the contiguous gradient tensor afterwards.  Inside a deferred-reduction window the folds of all
+# blocks since the last flush run as ONE launch behind the flush (the GEMM's partials reach the scratch only there); otherwise at once.
+_FOLD_PENDING = []   # (manager, first job, number of jobs)
+
+
+def fold_jobs(mgr, first, n):
+    """dst += src; src = 0 for jobs first .. first + n - 1 of mgr.fold_table (runtime.ArenaManager)"""
+    if n <= 0:
+        return
+    if _DEFER[0]:
+        if _FOLD_PENDING and _FOLD_PENDING[-1][0] is mgr and _FOLD_PENDING[-1][1] == first + n:   # backward walks the table downwards
+            _FOLD_PENDING[-1] = (mgr, first, _FOLD_PENDING[-1][2] + n)
+        elif _FOLD_PENDING and _FOLD_PENDING[-1][0] is mgr and _FOLD_PENDING[-1][1] + _FOLD_PENDING[-1][2] == first:
+            _FOLD_PENDING[-1] = (mgr, _FOLD_PENDING[-1][1], _FOLD_PENDING[-1][2] + n)
+        else:
+            _FOLD_PENDING.append((mgr, first, n))
+        return
+    _fold_launch(mgr, first, n)
+
+
+def _fold_launch(mgr, first, n):
+    blk = mgr.fold_blk0
+    call("atomnas_fold_jobs", _p(mgr.fold_table), int(first), int(n), int(blk[first]), int(blk[first + n] - blk[first]), _stream())
+
+
+def _fold_flush():
+    for mgr, first, n in _FOLD_PENDING:
+        _fold_launch(mgr, first, n)
+    del _FOLD_PENDING[:]
+
+
 def reduce_defer(on):
     call("atomnas_reduce_defer", int(bool(on)), _stream())
+    if not on:
+        _fold_flush()   # atomnas_reduce_defer(0) has flushed the recorded reductions on this stream
     _DEFER[0] = bool(on)
     if not on:
         del _DEFER_KEEP[:]
@@ -80,6 +114,7 @@ def reduce_defer(on):
 
 def reduce_flush():
     call("atomnas_reduce_flush", _stream())
+    _fold_flush()
     del _DEFER_KEEP[:]
     _DEFER_BYTES[0] = 0
 

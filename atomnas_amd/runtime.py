@@ -470,11 +470,14 @@ class ArenaManager:
 
         # ---- finish the plans (views)
         self.plans = {}
+        self._fold_build = []   # fold jobs of the fused blocks: (scratch offset, gradient-arena offset, src_ld, dst_ld, rows, cols)
+        self._fold_size = 0
         for m, pl, info in plans:
             pl.mgr = self
             self._finish_plan(m, pl, info)
             object.__setattr__(m, "_plan", pl)
             self.plans[pl.name] = pl
+        self._build_fold_table(dev)
 
         # regulariser job tables (L2 'mnas' over conv/fc weights + classifier bias; L1 filled by the prune module)
         self._build_reg_tables()
@@ -639,6 +642,20 @@ class ArenaManager:
         pl.Wd_grad = [G[o:o + pl.segpad(h) * k * k] for o, h, k in zip(so["Wd"], pl.hid, pl.ks)]
         pl.bnd = bnv(so["bnd"], HT, [list(d.children())[1] for d in dws], False)
         pl.Wp_grad = G[so["Wp"]:so["Wp"] + pl.oup * total]
+        # one weight-gradient GEMM per layer into a padded scratch matrix, folded into the contiguous tensors per segment
+        pl.fold_first = len(self._fold_build)
+        o_p = self._fold_take(pl.oup * HT)
+        pl.Wp_scratch_off = o_p
+        for sg, st, h in segs:
+            self._fold_build.append((o_p + sg, so["Wp"] + st, HT, total, pl.oup, h))
+        pl.fold_np = len(self._fold_build) - pl.fold_first
+        pl.fold_ne = 0
+        if pl.expand:
+            o_e = self._fold_take(HT * pl.inp)
+            pl.We_scratch_off = o_e
+            for sg, st, h in segs:
+                self._fold_build.append((o_e + sg * pl.inp, so["We"] + st * pl.inp, h * pl.inp, h * pl.inp, 1, h * pl.inp))
+            pl.fold_ne = len(self._fold_build) - pl.fold_first - pl.fold_np
         pl.bnp = bnv(so["bnp"], pl.oup, [list(m.project_conv.children())[1]], False)
         pl.Wp_pack, pl.WpT_pack = self._packview(pk["Wp"]), self._packview(pk["WpT"])
         pl.taps = [self.packF[o:o + kk * c].view(kk, c) for (o, kk, c) in pk["taps"]]
@@ -656,6 +673,32 @@ class ArenaManager:
             o1, o2, o3 = pk["se"]
             nh = pl.se_hid * HT
             pl.se_w1p, pl.se_w2t, pl.se_b2p = self.packF[o1:o1 + nh], self.packF[o2:o2 + nh], self.packF[o3:o3 + HT]
+
+    # ---- fused blocks: padded scratch matrices of the expand / projection weight gradients and the table that folds them into the
+    # contiguous gradient tensors (ops.fold_jobs, csrc/reduce.hip k_fold_jobs)
+    def _fold_take(self, n):
+        off = self._fold_size
+        self._fold_size = _align(off + n)
+        return off
+
+    def _build_fold_table(self, dev):
+        jobs = self._fold_build
+        self.FW = torch.zeros(max(self._fold_size, ALIGN), dtype=torch.float32, device=dev)   # zero once: every fold clears what it read
+        self.fold_table, self.fold_blk0 = None, [0]
+        if not jobs:
+            return
+
+        class J(ctypes.Structure):
+            _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("src_ld", ctypes.c_long), ("dst_ld", ctypes.c_long),
+                        ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("blk0", ctypes.c_uint), ("pad_", ctypes.c_int)]
+
+        arr = (J * len(jobs))()
+        blk = 0
+        for q, (so, do, sld, dld, rows, cols) in enumerate(jobs):
+            arr[q] = J(self.FW.data_ptr() + 4 * so, self.G.data_ptr() + 4 * do, sld, dld, rows, cols, blk, 0)
+            blk += (rows * cols + 255) // 256
+            self.fold_blk0.append(blk)
+        self.fold_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(dev)
 
     def _packview(self, t):
         off, rows, ld = t

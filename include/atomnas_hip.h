@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 9   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess; 8: + atomnas_gather_jobs; 9: atomnas_expand_bwd / atomnas_project_bwd lose their two-stream forms (arguments e, c2, c3 / p, c1, c2, c3) */
+#define ATOMNAS_ABI_VERSION 9   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess; 8: + atomnas_gather_jobs; 9: atomnas_expand_bwd / atomnas_project_bwd lose their two-stream forms (arguments e, c2, c3 / p, c1, c2, c3), + atomnas_fold_jobs */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -295,6 +295,22 @@ int atomnas_image_preprocess(const void* pool, const void* desc, int N, int S, c
  *   optimizer).  atomnas_reduce_defer(0) flushes what is recorded and returns to immediate reductions. */
 int atomnas_reduce_defer(int on, void* stream);
 int atomnas_reduce_flush(void* stream);
+
+/* Fold jobs (ABI 9): dst[r][c] += src[r][c]; src[r][c] = 0 over a table of 2-D fp32 blocks, one launch per table slice.  The fused
+ *   block of AtomNAS+ (models/mobilenet_base.py:236-254) keeps ONE contiguous expand / projection weight over all kernel-size groups,
+ *   the kernels run on branch segments padded to whole 16-channel slabs: a layer's weight gradient is ONE atomnas_pw_gemm_tn into a
+ *   padded scratch matrix, folded into the contiguous gradient tensor segment by segment here (the scratch is left zeroed).
+ *   blk0 = first workgroup of the job, ascending, one workgroup per 256 elements; a launch covers jobs first .. first + njobs - 1 with
+ *   blk_base = blk0 of job `first` and nblocks = the workgroups of the slice.  Blocks must not overlap. */
+typedef struct atomnas_fold_job {
+  float* src;
+  float* dst;
+  long src_ld, dst_ld;
+  int rows, cols;
+  unsigned blk0;
+  int pad_;
+} atomnas_fold_job;
+int atomnas_fold_jobs(const void* jobs_dev, int first, int njobs, long blk_base, long nblocks, void* stream);
 
 /* ---- dynamic shrink
  * alive masks |gamma| > thr (train.py:46-63, utils/prune.py:190-195): mode 0 current, 1 current|EMA, 2 EMA only.
