@@ -150,3 +150,77 @@ def test_cfg5_atomnas_c_plus_full_size(gpu_lib):
         ts.step(lr=0.004)
         l.append(ts.loss[0].item())
     assert all(v == v for v in l) and l[-1] < l[0], l
+
+
+def test_fold_jobs_kernel(gpu_lib):
+    """atomnas_fold_jobs (csrc/reduce.hip): dst += src, src = 0 over a table of 2-D blocks; whole table and slices of it"""
+    import ctypes
+    from atomnas_amd import _lib, ops
+
+    class J(ctypes.Structure):
+        _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("src_ld", ctypes.c_long), ("dst_ld", ctypes.c_long),
+                    ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("blk0", ctypes.c_uint), ("pad_", ctypes.c_int)]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    src = torch.randn(40, 100, device="cuda", generator=g)
+    dst = torch.randn(40, 77, device="cuda", generator=g)
+    src0, dst0 = src.clone(), dst.clone()
+    blocks = [(0, 3, 0, 5, 7, 13), (8, 20, 9, 30, 31, 40), (39, 99, 39, 76, 1, 1), (10, 70, 20, 0, 3, 300 // 3 // 10)]   # (sr, sc, dr, dc, rows, cols)
+    arr, blk, blk0 = (J * len(blocks))(), 0, [0]
+    for q, (sr, sc, dr, dc, rows, cols) in enumerate(blocks):
+        arr[q] = J(src.data_ptr() + 4 * (sr * 100 + sc), dst.data_ptr() + 4 * (dr * 77 + dc), 100, 77, rows, cols, blk, 0)
+        blk += (rows * cols + 255) // 256
+        blk0.append(blk)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def expect(jobs, s, d):
+        for sr, sc, dr, dc, rows, cols in jobs:
+            d[dr:dr + rows, dc:dc + cols] += s[sr:sr + rows, sc:sc + cols]
+            s[sr:sr + rows, sc:sc + cols] = 0
+    _lib.call("atomnas_fold_jobs", ctypes.c_void_p(table.data_ptr()), 1, 2, blk0[1], blk0[3] - blk0[1], st)   # jobs 1 and 2 only
+    torch.cuda.synchronize()
+    expect(blocks[1:3], src0, dst0)
+    assert torch.equal(src, src0) and torch.equal(dst, dst0)
+    _lib.call("atomnas_fold_jobs", ctypes.c_void_p(table.data_ptr()), 0, 4, 0, blk0[4], st)                    # the whole table
+    torch.cuda.synchronize()
+    expect(blocks, src0, dst0)
+    assert torch.equal(src, src0) and torch.equal(dst, dst0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_block_batched_weight_gradients_equal_the_per_segment_launches(gpu_lib, dtype):
+    """functional._FUSED_WG_BATCH: the expand / projection weight gradients of a fused block as ONE atomnas_pw_gemm_tn per layer into
+    a padded scratch matrix + atomnas_fold_jobs, against one launch per kernel-size segment -- the same products; the reduction over
+    the rows is cut into chunks by the GEMM's width, so the two weight gradients agree to summation-order rounding, everything else
+    bit for bit; a second backward accumulates (the scratch is left zeroed by the fold)."""
+    from atomnas_amd import functional as Fn
+    from atomnas_amd.models import mobilenet_base as mb
+
+    def run(batched):
+        torch.manual_seed(5)
+        blk = mb.InvertedResidualChannelsFused(24, 24, 1, [30, 50, 13], [3, 5, 7], True, active_fn=mb.get_active_fn("nn.Swish"),
+                                               batch_norm_kwargs={"momentum": 0.01, "eps": 1e-3}, se_ratio=0.5)
+        blk.compute_dtype = dtype
+        blk.cuda().train()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(6, 24, 14, 14, device="cuda", generator=g).requires_grad_(True)
+        go = torch.randn(6, 24, 14, 14, device="cuda", generator=g)
+        old, Fn._FUSED_WG_BATCH = Fn._FUSED_WG_BATCH, batched
+        try:
+            for _ in range(2):   # gradients accumulate over two backward passes
+                blk(x).backward(go)
+        finally:
+            Fn._FUSED_WG_BATCH = old
+        torch.cuda.synchronize()
+        scratch_clean = float(blk._plan.mgr.FW.abs().max()) == 0.0
+        return collections.OrderedDict((n, p.grad.detach().clone()) for n, p in blk.named_parameters()), x.grad.clone(), scratch_clean
+
+    a, ax, _ = run(False)
+    b, bx, clean = run(True)
+    assert clean, "the fold must leave the scratch matrices zeroed"
+    assert torch.equal(ax, bx)
+    for n in a:
+        if n.endswith("expand_conv.0.weight") or n.endswith("project_conv.0.weight"):
+            assert torch.allclose(a[n], b[n], rtol=1e-4, atol=1e-5 * float(a[n].abs().max())), (n, float((a[n] - b[n]).abs().max()))
+        else:
+            assert torch.equal(a[n], b[n]), n
