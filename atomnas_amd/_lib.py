@@ -55,7 +55,7 @@ SIGNATURES = {
     "atomnas_gather_dim": [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp],
     "atomnas_gather_jobs": [vp, i32, i64, vp],
     "atomnas_gram": [vp, i32, i64, i32, vp, i64, vp, vp, i32, vp],
-    "atomnas_image_preprocess": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
+    "atomnas_image_preprocess": [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
     "atomnas_xb_coeffs": [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp],
     "atomnas_fold_jobs": [vp, i32, i32, i64, i64, vp],
 }

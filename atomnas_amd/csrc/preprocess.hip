@@ -1,12 +1,14 @@
-// Input pipeline on the GPU: decoded uint8 HWC images -> crop -> bilinear resize -> horizontal flip -> ToTensor ->
+// Input pipeline on the GPU: decoded uint8 HWC images -> crop -> bilinear / bicubic resize -> horizontal flip -> ToTensor ->
 // Normalize, straight into the batch tensor the stem reads.  What the reference does per sample on CPU workers with PIL / torchvision
-// (utils/dataflow.py:92-170 `data_transforms` 'imagenet1k_mnas_bilinear': RandomResizedCropPadding / CenterCropPadding + Resize,
+// (utils/dataflow.py:92-170 `data_transforms` 'imagenet1k_mnas_bilinear' / 'imagenet1k_mnas_bicubic' -- the latter is the default of
+// apps/mobilenet/default_mnas_scheduler.yml --: RandomResizedCropPadding / CenterCropPadding + Resize,
 // RandomHorizontalFlip, ToTensor, Normalize; utils/transforms.py:79-177) -- the random crop PARAMETERS stay host logic
 // (atomnas_amd/utils/transforms.py restates them), the pixel work is this kernel.  JPEG decoding and LMDB are out of scope (no decoder
 // in the image).
 //
-// The resize is PIL's (Image.resize(size, Image.BILINEAR) on the cropped image, which is what torchvision's F.resized_crop / Resize
-// call): a separable triangle filter whose support grows with the down-scaling factor (antialiasing), coefficients normalised and
+// The resize is PIL's (Image.resize(size, Image.BILINEAR | Image.BICUBIC) on the cropped image, which is what torchvision's
+// F.resized_crop / Resize call): a separable triangle filter (support 1) or Keys cubic with a = -0.5 (support 2: negative lobes, hence the
+// clamps of both passes) whose support grows with the down-scaling factor (antialiasing), coefficients normalised and
 // quantised to 22 fractional bits, horizontal pass first, each pass rounded to uint8 (libImaging/Resample.c: precompute_coeffs,
 // normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc).  Restated here operation by operation in double / int32
 // arithmetic with FP contraction off, so the result is BIT-IDENTICAL to PIL's (tests/test_input_pipeline_gpu.py against fixtures
@@ -30,16 +32,26 @@ struct ImgDesc {
 };
 static_assert(sizeof(ImgDesc) == 40, "atomnas_img_desc layout");
 
-constexpr int PP_KMAX = 19;       // taps per dimension: down-scaling up to 9x
+constexpr int PP_KMAX = 38;       // taps per dimension: down-scaling up to 9x with the bicubic filter's support of 2 (bilinear: 19)
 constexpr int PP_BITS = 22;       // PRECISION_BITS of Resample.c for 8-bit channels
 
 // coefficients of output position xx (of `out`) over an input axis of `in` samples: first sample, count, k[] -- precompute_coeffs +
 // normalize_coeffs_8bpc; k points into LDS (the weights are evaluated twice instead of being kept in a private array)
-__device__ __forceinline__ void pp_coeffs(int in, int out, int xx, int& xmin, int& cnt, int* k) {
+__device__ __forceinline__ double pp_weight(double a, int cubic) {
+#pragma clang fp contract(off)
+  if (a < 0.0) a = -a;
+  if (!cubic) return a < 1.0 ? 1.0 - a : 0.0;           // bilinear_filter
+  const double A = -0.5;                                  // bicubic_filter (Keys, a = -0.5)
+  if (a < 1.0) return ((A + 2.0) * a - (A + 3.0)) * a * a + 1;
+  if (a < 2.0) return (((a - 5) * a + 8) * a - 4) * A;
+  return 0.0;
+}
+
+__device__ __forceinline__ void pp_coeffs(int in, int out, int xx, int cubic, int& xmin, int& cnt, int* k) {
 #pragma clang fp contract(off)
   const double scale = (double)in / (double)out;
   const double filterscale = scale < 1.0 ? 1.0 : scale;
-  const double support = 1.0 * filterscale;
+  const double support = (cubic ? 2.0 : 1.0) * filterscale;
   const double center = 0.0 + (xx + 0.5) * scale;
   const double ss = 1.0 / filterscale;
   int lo = (int)(center - support + 0.5);
@@ -49,15 +61,9 @@ __device__ __forceinline__ void pp_coeffs(int in, int out, int xx, int& xmin, in
   hi -= lo;
   if (hi > PP_KMAX) hi = PP_KMAX;   // (never: the host side rejects scales above 9)
   double ww = 0.0;
+  for (int x = 0; x < hi; ++x) ww += pp_weight((x + lo - center + 0.5) * ss, cubic);
   for (int x = 0; x < hi; ++x) {
-    double a = (x + lo - center + 0.5) * ss;
-    if (a < 0.0) a = -a;
-    ww += a < 1.0 ? 1.0 - a : 0.0;
-  }
-  for (int x = 0; x < hi; ++x) {
-    double a = (x + lo - center + 0.5) * ss;
-    if (a < 0.0) a = -a;
-    double v = a < 1.0 ? 1.0 - a : 0.0;
+    double v = pp_weight((x + lo - center + 0.5) * ss, cubic);
     if (ww != 0.0) v /= ww;
     k[x] = v < 0.0 ? (int)(-0.5 + v * (double)(1 << PP_BITS)) : (int)(0.5 + v * (double)(1 << PP_BITS));
   }
@@ -75,7 +81,7 @@ __device__ __forceinline__ int pp_clip8(int v) {
 template <int OUT>
 __global__ __launch_bounds__(256) void k_image_preprocess(const unsigned char* __restrict__ pool, const ImgDesc* __restrict__ desc, int S,
                                                          float m0, float m1, float m2, float s0, float s1, float s2,
-                                                         void* __restrict__ out) {
+                                                         void* __restrict__ out, int cubic) {
   __shared__ int s_kx[64][PP_KMAX + 2], s_ky[4][PP_KMAX + 2];   // [..][KMAX] = first sample, [..][KMAX + 1] = count
   const int n = blockIdx.z;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -85,9 +91,9 @@ __global__ __launch_bounds__(256) void k_image_preprocess(const unsigned char* _
   if (ty == 0 && ox < S) {
     // the flip mirrors the RESIZED image: output column ox shows resized column S - 1 - ox
     const int rx = d.flip ? S - 1 - ox : ox;
-    pp_coeffs(d.bw, S, rx, s_kx[tx][PP_KMAX], s_kx[tx][PP_KMAX + 1], s_kx[tx]);
+    pp_coeffs(d.bw, S, rx, cubic, s_kx[tx][PP_KMAX], s_kx[tx][PP_KMAX + 1], s_kx[tx]);
   }
-  if (tx == 0 && oy < S) pp_coeffs(d.bh, S, oy, s_ky[ty][PP_KMAX], s_ky[ty][PP_KMAX + 1], s_ky[ty]);
+  if (tx == 0 && oy < S) pp_coeffs(d.bh, S, oy, cubic, s_ky[ty][PP_KMAX], s_ky[ty][PP_KMAX + 1], s_ky[ty]);
   __syncthreads();
   if (ox >= S || oy >= S) return;
   const int xmin = s_kx[tx][PP_KMAX], xn = s_kx[tx][PP_KMAX + 1], ymin = s_ky[ty][PP_KMAX], yn = s_ky[ty][PP_KMAX + 1];
@@ -137,19 +143,21 @@ __global__ __launch_bounds__(256) void k_image_preprocess(const unsigned char* _
 using namespace atomnas;
 
 // include/atomnas_hip.h: pool = the packed uint8 HWC images, desc = device array of N atomnas_img_desc (ImgDesc above + 4 bytes of padding),
-// out_mode 0: fp32 NCHW, 1: bf16 NHWC (channel pitch 8), 2: uint8 [N][S][S][3] before ToTensor (parity against PIL).
+// out_mode 0: fp32 NCHW, 1: bf16 NHWC (channel pitch 8), 2: uint8 [N][S][S][3] before ToTensor (parity against PIL); filter 0: PIL's BILINEAR,
+// 1: PIL's BICUBIC resampler.
 extern "C" int atomnas_image_preprocess(const void* pool, const void* desc, int N, int S, const float* mean3, const float* std3, void* out,
-                                        int out_mode, void* stream) {
+                                        int out_mode, int filter, void* stream) {
   ATOMNAS_REQUIRE(pool && desc && out && N > 0 && S > 0 && S <= 1024, "image_preprocess: bad arguments");
   ATOMNAS_REQUIRE(out_mode == 2 || (mean3 && std3), "image_preprocess: mean / std (host arrays of 3 floats) are required");
   ATOMNAS_REQUIRE(out_mode >= 0 && out_mode <= 2, "image_preprocess: out_mode %d", out_mode);
+  ATOMNAS_REQUIRE(filter == 0 || filter == 1, "image_preprocess: filter %d (0 = PIL BILINEAR, 1 = PIL BICUBIC)", filter);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((S + 63) / 64, (S + 3) / 4, N), block(256);
   const ImgDesc* d = reinterpret_cast<const ImgDesc*>(desc);
   const float m0 = mean3 ? mean3[0] : 0.f, m1 = mean3 ? mean3[1] : 0.f, m2 = mean3 ? mean3[2] : 0.f;
   const float s0 = std3 ? std3[0] : 1.f, s1 = std3 ? std3[1] : 1.f, s2 = std3 ? std3[2] : 1.f;
-  if (out_mode == 2) hipLaunchKernelGGL(k_image_preprocess<2>, grid, block, 0, st, (const unsigned char*)pool, d, S, m0, m1, m2, s0, s1, s2, out);
-  else if (out_mode == 1) hipLaunchKernelGGL(k_image_preprocess<1>, grid, block, 0, st, (const unsigned char*)pool, d, S, m0, m1, m2, s0, s1, s2, out);
-  else hipLaunchKernelGGL(k_image_preprocess<0>, grid, block, 0, st, (const unsigned char*)pool, d, S, m0, m1, m2, s0, s1, s2, out);
+  if (out_mode == 2) hipLaunchKernelGGL(k_image_preprocess<2>, grid, block, 0, st, (const unsigned char*)pool, d, S, m0, m1, m2, s0, s1, s2, out, filter);
+  else if (out_mode == 1) hipLaunchKernelGGL(k_image_preprocess<1>, grid, block, 0, st, (const unsigned char*)pool, d, S, m0, m1, m2, s0, s1, s2, out, filter);
+  else hipLaunchKernelGGL(k_image_preprocess<0>, grid, block, 0, st, (const unsigned char*)pool, d, S, m0, m1, m2, s0, s1, s2, out, filter);
   return check_launch("image_preprocess");
 }

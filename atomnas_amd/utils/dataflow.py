@@ -24,14 +24,17 @@ DESC_DTYPE = np.dtype([("off", "<i8"), ("H", "<i4"), ("W", "<i4"), ("bi", "<i4")
 MAX_SCALE = 9.0   # the kernel's tap budget: a crop side may be at most 9x the output side
 
 
-def preprocess(pool_dev, desc_dev, n, size, mean, std, out, out_mode=0, stream=None):
+FILTERS = {"bilinear": 0, "bicubic": 1}   # the `filter` argument of atomnas_image_preprocess: PIL's BILINEAR / BICUBIC resamplers
+
+
+def preprocess(pool_dev, desc_dev, n, size, mean, std, out, out_mode=0, stream=None, filter="bilinear"):
     """launches atomnas_image_preprocess: pool_dev uint8 device tensor, desc_dev uint8 device tensor holding n DESC_DTYPE records"""
     st = ctypes.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
     m = (ctypes.c_float * 3)(*mean)
     s = (ctypes.c_float * 3)(*std)
     _lib.call("atomnas_image_preprocess", ctypes.c_void_p(pool_dev.data_ptr()), ctypes.c_void_p(desc_dev.data_ptr()), int(n), int(size),
               ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
-              ctypes.c_void_p(out.data_ptr()), int(out_mode), st)
+              ctypes.c_void_p(out.data_ptr()), int(out_mode), FILTERS[filter], st)
 
 
 def check_box(H, W, box, size):
@@ -52,12 +55,16 @@ class DevicePrefetcher(object):
     thread only waits for an event.  Two slots (pixel pool, descriptors, output) alternate; a slot is refilled only after the consumer
     of its previous batch has been ordered behind an event on the consumer's stream."""
 
-    def __init__(self, loader, image_size=224, mean=T.IMAGENET_MEAN, std=T.IMAGENET_STD, max_image_bytes=3 * 640 * 640, threaded=True):
+    def __init__(self, loader, image_size=224, mean=T.IMAGENET_MEAN, std=T.IMAGENET_STD, max_image_bytes=3 * 640 * 640, threaded=True,
+                 filter="bilinear"):
         if not torch.cuda.is_available():
             raise _lib.AtomnasHipError("DevicePrefetcher needs the GPU (the preprocessing kernel has no CPU fallback)")
         self.loader_len = len(loader) if hasattr(loader, "__len__") else None
         self.loader = iter(loader)
         self.size, self.mean, self.std = int(image_size), tuple(mean), tuple(std)
+        if filter not in FILTERS:
+            raise NotImplementedError("resampling filter %r (atomnas_image_preprocess: %s)" % (filter, ", ".join(FILTERS)))
+        self.filter = filter
         self.stream = torch.cuda.Stream()
         self.device = torch.cuda.current_device()
         self.max_image_bytes = int(max_image_bytes)
@@ -119,7 +126,7 @@ class DevicePrefetcher(object):
             desc_dev.copy_(desc_pin, non_blocking=True)
             ev = self.desc_read[q] = self.desc_read[q] or torch.cuda.Event()
             ev.record(self.stream)
-            preprocess(pool, desc_dev, n, self.size, self.mean, self.std, out, 0, self.stream)
+            preprocess(pool, desc_dev, n, self.size, self.mean, self.std, out, 0, self.stream, self.filter)
             tgt = target.cuda(non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.stream)
@@ -239,8 +246,8 @@ class DeviceTransform(object):
     """What data_transforms returns per split: the deciders of a transform chain whose pixel work is atomnas_image_preprocess.
     transform(img) -> ((top, left, height, width), flip) for a decoded image (HWC array / tensor, PIL image or (width, height))."""
 
-    def __init__(self, crop, flip, size, mean, std):
-        self.crop, self.flip, self.size, self.mean, self.std = crop, flip, int(size), tuple(mean), tuple(std)
+    def __init__(self, crop, flip, size, mean, std, filter="bilinear"):
+        self.crop, self.flip, self.size, self.mean, self.std, self.filter = crop, flip, int(size), tuple(mean), tuple(std), filter
 
     def __call__(self, img):
         box = self.crop(img)   # random draws in the reference's order: the crop's, then the flip's
@@ -253,15 +260,13 @@ class DeviceTransform(object):
 def data_transforms(FLAGS):
     """Get transform of dataset (utils/dataflow.py:92-170) -> (train_transforms, val_transforms, test_transforms)."""
     name = FLAGS.data_transforms
-    if name == 'imagenet1k_mnas_bilinear':
+    if name in ('imagenet1k_mnas_bilinear', 'imagenet1k_mnas_bicubic'):
         size = int(FLAGS.get('image_size', 224)) if hasattr(FLAGS, 'get') else 224
-        (crop, flip), (vcrop, _) = T.mnas_bilinear_transforms(size)
-        train = DeviceTransform(crop, flip, size, T.IMAGENET_MEAN, T.IMAGENET_STD)
-        val = DeviceTransform(vcrop, None, size, T.IMAGENET_MEAN, T.IMAGENET_STD)
+        filt = name.rsplit('_', 1)[1]   # Image.BILINEAR / Image.BICUBIC of the reference: the `filter` of atomnas_image_preprocess
+        (crop, flip), (vcrop, _) = T.mnas_transforms(size, filt)
+        train = DeviceTransform(crop, flip, size, T.IMAGENET_MEAN, T.IMAGENET_STD, filt)
+        val = DeviceTransform(vcrop, None, size, T.IMAGENET_MEAN, T.IMAGENET_STD, filt)
         return train, val, val
-    if name == 'imagenet1k_mnas_bicubic':
-        raise NotImplementedError("data_transforms 'imagenet1k_mnas_bicubic': atomnas_image_preprocess implements PIL's BILINEAR resampler only "
-                                  "(use 'imagenet1k_mnas_bilinear'; bicubic is the same machinery with support 2, not built)")
     if name in ('imagenet1k_basic', 'imagenet1k_inception', 'imagenet1k_mobile'):
         raise NotImplementedError("data_transforms '{}': ColorJitter / Lighting have no device kernel here".format(name))
     try:

@@ -69,12 +69,12 @@ class RandomResizedCropPadding(object):
                  max_attempts=10, crop_padding=0):
         self.size = size if isinstance(size, tuple) else (size, size)
         assert (scale[0] < scale[1]) and (ratio[0] < ratio[1])
-        # the kernel implements PIL's BILINEAR resampler only (the 'imagenet1k_mnas_bilinear' transform); the reference's default
-        # yaml uses 'imagenet1k_mnas_bicubic' (apps/mobilenet/default_mnas_scheduler.yml), which this pipeline does not reproduce:
-        # asking for another filter is an error, not a silent substitution
-        if interpolation is not None and _interp_name(interpolation) != "bilinear":
-            raise NotImplementedError("atomnas_image_preprocess resizes with PIL's BILINEAR filter only (got %r)" % (interpolation,))
+        # the kernel implements PIL's BILINEAR and BICUBIC resamplers ('imagenet1k_mnas_bilinear' / 'imagenet1k_mnas_bicubic', the latter
+        # the default of apps/mobilenet/default_mnas_scheduler.yml); asking for another filter is an error, not a silent substitution
+        if interpolation is not None and _interp_name(interpolation) not in ("bilinear", "bicubic"):
+            raise NotImplementedError("atomnas_image_preprocess resizes with PIL's BILINEAR or BICUBIC filter only (got %r)" % (interpolation,))
         self.interpolation = interpolation
+        self.filter = _interp_name(interpolation) if interpolation is not None else "bilinear"
         self.max_attempts = max_attempts
         self.scale = scale
         self.min_object_covered = min_object_covered or scale[0]
@@ -158,9 +158,14 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)   # u
 MNAS_CROP_PADDING = 32                                                         # utils/dataflow.py:133
 
 
-def mnas_bilinear_transforms(image_size=224):
-    """the box / flip deciders of data_transforms('imagenet1k_mnas_bilinear') (utils/dataflow.py:125-160): (train, val)"""
+def mnas_transforms(image_size=224, filter="bilinear"):
+    """the box / flip deciders of data_transforms('imagenet1k_mnas_bilinear' | 'imagenet1k_mnas_bicubic') (utils/dataflow.py:125-160):
+    (train, val); the filter only travels with them (the pixel work is the kernel's)"""
     train = (RandomResizedCropPadding(image_size, scale=(0.08, 1.0), min_object_covered=0.1, ratio=(3. / 4., 4. / 3.), log_ratio=False,
-                                      crop_padding=MNAS_CROP_PADDING), RandomHorizontalFlip())
+                                      interpolation=filter, crop_padding=MNAS_CROP_PADDING), RandomHorizontalFlip())
     val = (CenterCropPadding(image_size, MNAS_CROP_PADDING), None)
     return train, val
+
+
+def mnas_bilinear_transforms(image_size=224):
+    return mnas_transforms(image_size, "bilinear")

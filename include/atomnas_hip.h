@@ -60,7 +60,7 @@ extern "C" {
 #define ATOMNAS_HYP_GRAD_SCALE 3
 
 const char* atomnas_last_error(void);
-#define ATOMNAS_ABI_VERSION 9   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess; 8: + atomnas_gather_jobs; 9: atomnas_expand_bwd / atomnas_project_bwd lose their two-stream forms (arguments e, c2, c3 / p, c1, c2, c3), + atomnas_fold_jobs */
+#define ATOMNAS_ABI_VERSION 9   /* 2: (ptr, ld, ss) activations, partial-row statistics, workspaces, SE / fused-backward entry points; 3: + atomnas_bnbwd_apply; 4: + atomnas_gram, atomnas_xb_coeffs, atomnas_expand_bwd with e = NULL; 5: the SE dense layers take their weights packed over the padded channel layout; 6: + atomnas_dwconv_mm_supported; 7: + atomnas_image_preprocess; 8: + atomnas_gather_jobs; 9: atomnas_expand_bwd / atomnas_project_bwd lose their two-stream forms (arguments e, c2, c3 / p, c1, c2, c3), + atomnas_fold_jobs, atomnas_image_preprocess takes the resampling filter */
 int atomnas_abi_version(void);
 int atomnas_runtime_version(void);
 
@@ -269,8 +269,9 @@ int atomnas_reg_value(const float* p, const void* jobs_dev, int njobs, int use_a
 int atomnas_pack_weights(const float* arena, void* packbuf, const void* jobs_dev, int njobs, int dtype, void* stream);
 
 /* ---- input pipeline (utils/dataflow.py:92-170 'imagenet1k_mnas_bilinear', utils/transforms.py:54-177): decoded uint8
- *      HWC images -> crop -> PIL-exact bilinear resize (antialiased triangle filter, 22-bit coefficients, horizontal pass rounded to
- *      uint8, then vertical: libImaging/Resample.c) -> horizontal flip -> ToTensor -> Normalize, one launch per batch.
+ *      HWC images -> crop -> PIL-exact resize (filter 0: BILINEAR, antialiased triangle filter; filter 1: BICUBIC, Keys cubic a = -0.5
+ *      -- 'imagenet1k_mnas_bicubic', the reference's default; 22-bit coefficients, horizontal pass rounded to uint8, then vertical:
+ *      libImaging/Resample.c) -> horizontal flip -> ToTensor -> Normalize, one launch per batch.
  * pool: the images, packed (3 channels, row pitch 3 W);  desc: device array of N atomnas_img_desc;  S: output side;
  * mean3 / std3: HOST arrays of three floats (read at the call);  out_mode 0: fp32 NCHW [N][3][S][S] (what atomnas_im2col_stem reads),
  * 1: bf16 NHWC with a channel pitch of 8 (padding zero), 2: uint8 [N][S][S][3], the resized and flipped image before ToTensor
@@ -283,7 +284,7 @@ typedef struct atomnas_img_desc {
   int pad_;
 } atomnas_img_desc;
 int atomnas_image_preprocess(const void* pool, const void* desc, int N, int S, const float* mean3, const float* std3, void* out,
-                             int out_mode, void* stream);
+                             int out_mode, int filter, void* stream);
 
 /* ---- deferred fixed-order reductions (ABI 5).  The weight-gradient entry points (atomnas_pw_gemm_tn, atomnas_dwconv_bwd,
  *   atomnas_expand_bwd, atomnas_project_bwd) write per-workgroup partials to their workspace and sum them in a fixed order with one

@@ -1,4 +1,4 @@
-"""ORACLE -- test infrastructure only.  numpy restatement of PIL's 8-bit bilinear resize (libImaging/Resample.c of Pillow:
+"""ORACLE -- test infrastructure only.  numpy restatement of PIL's 8-bit bilinear / bicubic resize (libImaging/Resample.c of Pillow:
 precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc, ImagingResampleVertical_8bpc) -- the resampling behind
 torchvision's F.resized_crop / Resize, which the reference's input pipeline calls (utils/transforms.py:165-172, utils/dataflow.py:140-160).
 
@@ -9,11 +9,33 @@ import numpy as np
 PRECISION_BITS = 32 - 8 - 2
 
 
-def coeffs(in_size, out_size):
+BILINEAR, BICUBIC = "bilinear", "bicubic"
+
+
+def _filter(filt):
+    """(support, weight function) of Resample.c: bilinear_filter (triangle, support 1), bicubic_filter (Keys cubic with a = -0.5,
+    support 2) -- torchvision's InterpolationMode.BILINEAR / BICUBIC on PIL images"""
+    if filt == BILINEAR:
+        return 1.0, lambda x: 1.0 - x if x < 1.0 else 0.0
+    if filt == BICUBIC:
+        a = -0.5
+
+        def w(x):
+            if x < 1.0:
+                return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+            if x < 2.0:
+                return (((x - 5) * x + 8) * x - 4) * a
+            return 0.0
+        return 2.0, w
+    raise ValueError(filt)
+
+
+def coeffs(in_size, out_size, filt=BILINEAR):
     """per output position: (first input sample, integer coefficients)"""
+    fsupport, fw = _filter(filt)
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
-    support = 1.0 * filterscale
+    support = fsupport * filterscale
     ss = 1.0 / filterscale
     out = []
     for xx in range(out_size):
@@ -24,8 +46,7 @@ def coeffs(in_size, out_size):
         xmax = min(xmax, in_size) - xmin
         w = []
         for x in range(xmax):
-            a = abs((x + xmin - center + 0.5) * ss)
-            w.append(1.0 - a if a < 1.0 else 0.0)
+            w.append(fw(abs((x + xmin - center + 0.5) * ss)))
         ww = 0.0
         for v in w:
             ww += v
@@ -42,25 +63,29 @@ def _clip8(v):
     return np.clip(v >> PRECISION_BITS, 0, 255)
 
 
-def resize_bilinear_u8(img, out_h, out_w):
+def resize_u8(img, out_h, out_w, filt=BILINEAR):
     """img: uint8 [H, W, C] -> uint8 [out_h, out_w, C]; horizontal pass, rounding to uint8, vertical pass (PIL's order)"""
     H, W, C = img.shape
     src = img.astype(np.int64)
     tmp = np.empty((H, out_w, C), dtype=np.int64)
-    for xx, (xmin, k) in enumerate(coeffs(W, out_w)):
+    for xx, (xmin, k) in enumerate(coeffs(W, out_w, filt)):
         acc = (1 << (PRECISION_BITS - 1)) + (src[:, xmin:xmin + len(k), :] * k[None, :, None]).sum(1)
         tmp[:, xx, :] = _clip8(acc)
     out = np.empty((out_h, out_w, C), dtype=np.int64)
-    for yy, (ymin, k) in enumerate(coeffs(H, out_h)):
+    for yy, (ymin, k) in enumerate(coeffs(H, out_h, filt)):
         acc = (1 << (PRECISION_BITS - 1)) + (tmp[ymin:ymin + len(k), :, :] * k[:, None, None]).sum(0)
         out[yy] = _clip8(acc)
     return out.astype(np.uint8)
 
 
-def crop_resize_flip(img, box, size, flip):
-    """F.resized_crop(img, i, j, h, w, size, BILINEAR) followed by an optional horizontal flip, on a uint8 HWC array"""
+def resize_bilinear_u8(img, out_h, out_w):
+    return resize_u8(img, out_h, out_w, BILINEAR)
+
+
+def crop_resize_flip(img, box, size, flip, filt=BILINEAR):
+    """F.resized_crop(img, i, j, h, w, size, interpolation) followed by an optional horizontal flip, on a uint8 HWC array"""
     i, j, h, w = box
-    r = resize_bilinear_u8(img[i:i + h, j:j + w, :], size, size)
+    r = resize_u8(img[i:i + h, j:j + w, :], size, size, filt)
     return r[:, ::-1, :].copy() if flip else r
 
 

@@ -113,8 +113,9 @@ def test_pil_resize_restatement_is_bit_identical_to_pil():
         S = int(rng.choice([17, 32, 64, 224]))
         if h > 9 * S or w > 9 * S:
             continue
-        ref = np.asarray(Image.fromarray(img).crop((j, i, j + w, i + h)).resize((S, S), Image.BILINEAR))
-        assert np.array_equal(pr.resize_bilinear_u8(img[i:i + h, j:j + w], S, S), ref), (t, H, W, (i, j, h, w), S)
+        for filt, pf in ((pr.BILINEAR, Image.BILINEAR), (pr.BICUBIC, Image.BICUBIC)):
+            ref = np.asarray(Image.fromarray(img).crop((j, i, j + w, i + h)).resize((S, S), pf))
+            assert np.array_equal(pr.resize_u8(img[i:i + h, j:j + w], S, S, filt), ref), (t, filt, H, W, (i, j, h, w), S)
         n += 1
     assert n >= 25
 
@@ -125,6 +126,8 @@ def test_pil_resize_restatement_matches_the_committed_fixture():
     for c in g["cases"]:
         got = pr.crop_resize_flip(c["image"].numpy(), c["box"], c["size"], c["flip"])
         assert np.array_equal(got, c["resized"].numpy()), (c["box"], c["size"], c["flip"])
+        gotc = pr.crop_resize_flip(c["image"].numpy(), c["box"], c["size"], c["flip"], pr.BICUBIC)
+        assert np.array_equal(gotc, c["resized_bicubic"].numpy()), ("bicubic", c["box"], c["size"], c["flip"])
         t = pr.to_tensor_normalize(got, g["mean"], g["std"])
         assert t.dtype == np.float32 and t.shape == (3, c["size"], c["size"])
 
@@ -180,8 +183,8 @@ def test_data_factories_have_the_reference_protocol():
 
 def test_data_factories_refuse_what_this_image_cannot_do():
     from atomnas_amd.utils import dataflow as DF
-    with pytest.raises(NotImplementedError, match="BILINEAR"):
-        DF.data_transforms(_flags(data_transforms="imagenet1k_mnas_bicubic"))
+    tb = DF.data_transforms(_flags(data_transforms="imagenet1k_mnas_bicubic"))   # the reference's default transform (default_mnas_scheduler.yml)
+    assert tb[0].filter == "bicubic" and tb[1].filter == "bicubic" and DF.data_transforms(_flags())[0].filter == "bilinear"
     with pytest.raises(NotImplementedError):
         DF.data_transforms(_flags(data_transforms="imagenet1k_basic"))
     with pytest.raises(NotImplementedError, match="not yet implemented"):
@@ -191,7 +194,7 @@ def test_data_factories_refuse_what_this_image_cannot_do():
     with pytest.raises(NotImplementedError, match="not yet implemented"):
         DF.data_loader(None, None, None, _flags(data_loader="no_such_loader_xyz"))
     with pytest.raises(NotImplementedError, match="BILINEAR"):
-        T.RandomResizedCropPadding(224, interpolation=3)   # PIL.Image.BICUBIC
-    T.RandomResizedCropPadding(224, interpolation=2)       # BILINEAR is what the kernel implements
+        T.RandomResizedCropPadding(224, interpolation=1)   # PIL.Image.LANCZOS: no kernel
+    assert T.RandomResizedCropPadding(224, interpolation=3).filter == "bicubic" and T.RandomResizedCropPadding(224, interpolation=2).filter == "bilinear"
     fake = DF.dataset(None, None, None, _flags(dataset="imagenet1k_fake"))   # the reference's zero-image smoke source keeps its form
     assert len(fake[0]) == 1281167 and fake[0][0][0].shape == (3, 224, 224) and fake[0][0][1] == 0

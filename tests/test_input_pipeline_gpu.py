@@ -17,7 +17,7 @@ import pil_resize as pr  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _run(images, boxes, flips, size, mean, std, out_mode):
+def _run(images, boxes, flips, size, mean, std, out_mode, filter="bilinear"):
     from atomnas_amd.utils import dataflow as DF
     n = len(images)
     sizes = [int(im.numel()) for im in images]
@@ -35,7 +35,7 @@ def _run(images, boxes, flips, size, mean, std, out_mode):
         out = torch.full((n, size, size, 8), 7.0, dtype=torch.bfloat16, device="cuda")
     else:
         out = torch.full((n, 3, size, size), float("nan"), dtype=torch.float32, device="cuda")
-    DF.preprocess(pool, desc, n, size, mean, std, out, out_mode)
+    DF.preprocess(pool, desc, n, size, mean, std, out, out_mode, filter=filter)
     torch.cuda.synchronize()
     return out
 
@@ -47,14 +47,15 @@ def test_preprocess_kernel_matches_pil_fixture_exactly(gpu_lib):
         by_size.setdefault(c["size"], []).append(c)
     for S, cases in by_size.items():
         imgs, boxes, flips = [c["image"] for c in cases], [c["box"] for c in cases], [c["flip"] for c in cases]
-        u8 = _run(imgs, boxes, flips, S, g["mean"], g["std"], 2).cpu()
-        f32 = _run(imgs, boxes, flips, S, g["mean"], g["std"], 0).cpu()
-        b16 = _run(imgs, boxes, flips, S, g["mean"], g["std"], 1).cpu()
-        for q, c in enumerate(cases):
-            assert torch.equal(u8[q], c["resized"]), (S, q, int((u8[q] != c["resized"]).sum()))          # PIL's bytes
-            want = torch.from_numpy(pr.to_tensor_normalize(c["resized"].numpy(), g["mean"], g["std"]))
-            assert torch.equal(f32[q], want), (S, q, float((f32[q] - want).abs().max()))                   # ToTensor + Normalize, fp32
-            assert torch.equal(b16[q, :, :, :3].permute(2, 0, 1), want.bfloat16()) and float(b16[q, :, :, 3:].abs().max()) == 0.0
+        for filt, key in (("bilinear", "resized"), ("bicubic", "resized_bicubic")):
+            u8 = _run(imgs, boxes, flips, S, g["mean"], g["std"], 2, filt).cpu()
+            f32 = _run(imgs, boxes, flips, S, g["mean"], g["std"], 0, filt).cpu()
+            b16 = _run(imgs, boxes, flips, S, g["mean"], g["std"], 1, filt).cpu()
+            for q, c in enumerate(cases):
+                assert torch.equal(u8[q], c[key]), (filt, S, q, int((u8[q] != c[key]).sum()))          # PIL's bytes
+                want = torch.from_numpy(pr.to_tensor_normalize(c[key].numpy(), g["mean"], g["std"]))
+                assert torch.equal(f32[q], want), (filt, S, q, float((f32[q] - want).abs().max()))         # ToTensor + Normalize, fp32
+                assert torch.equal(b16[q, :, :, :3].permute(2, 0, 1), want.bfloat16()) and float(b16[q, :, :, 3:].abs().max()) == 0.0
 
 
 def test_preprocess_kernel_random_boxes_against_the_pil_restatement(gpu_lib):
@@ -70,10 +71,11 @@ def test_preprocess_kernel_random_boxes_against_the_pil_restatement(gpu_lib):
         imgs.append(im)
         boxes.append(crop(im))
         flips.append(flip())
-    u8 = _run(imgs, boxes, flips, 224, T.IMAGENET_MEAN, T.IMAGENET_STD, 2).cpu().numpy()
-    for q in range(len(imgs)):
-        want = pr.crop_resize_flip(imgs[q].numpy(), boxes[q], 224, flips[q])
-        assert np.array_equal(u8[q], want), (q, boxes[q], flips[q], int((u8[q] != want).sum()))
+    for filt in ("bilinear", "bicubic"):
+        u8 = _run(imgs, boxes, flips, 224, T.IMAGENET_MEAN, T.IMAGENET_STD, 2, filt).cpu().numpy()
+        for q in range(len(imgs)):
+            want = pr.crop_resize_flip(imgs[q].numpy(), boxes[q], 224, flips[q], filt)
+            assert np.array_equal(u8[q], want), (filt, q, boxes[q], flips[q], int((u8[q] != want).sum()))
 
 
 def test_device_prefetcher_yields_the_batches_of_its_loader(gpu_lib):

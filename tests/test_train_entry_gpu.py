@@ -30,7 +30,7 @@ def test_train_entry_runs_two_epochs(gpu_lib, tmp_path):
 
 
 def test_train_entry_on_the_gpu_input_pipeline(gpu_lib, tmp_path):
-    """the same entry fed by `dataset: imagenet1k_decoded_fake`: data_transforms('imagenet1k_mnas_bilinear') / dataset / data_loader
+    """the same entry fed by `dataset: imagenet1k_decoded_fake`: data_transforms('imagenet1k_mnas_bicubic') / dataset / data_loader
     (the reference's factories, utils/dataflow.py:92-267) -> DevicePrefetcher -> TrainStep.set_batch; calibration and validation
     batches through the same pipeline"""
     env = dict(os.environ, ATOMNAS_E2E_DIR=str(tmp_path), ARNOLD_OUTPUT=str(tmp_path))

@@ -36,10 +36,13 @@ def main():
     for q, (H, W, box, S, flip) in enumerate(spec):
         img = image(rng, H, W, q % 3)
         i, j, h, w = box
-        r = Image.fromarray(img).crop((j, i, j + w, i + h)).resize((S, S), Image.BILINEAR)
-        if flip:
-            r = r.transpose(Image.FLIP_LEFT_RIGHT)
-        cases.append(dict(image=torch.from_numpy(img), box=box, size=S, flip=flip, resized=torch.from_numpy(np.asarray(r).copy())))
+        res = {}
+        for name, filt in (("bilinear", Image.BILINEAR), ("bicubic", Image.BICUBIC)):   # data_transforms 'imagenet1k_mnas_bilinear' / '_bicubic'
+            r = Image.fromarray(img).crop((j, i, j + w, i + h)).resize((S, S), filt)
+            if flip:
+                r = r.transpose(Image.FLIP_LEFT_RIGHT)
+            res[name] = torch.from_numpy(np.asarray(r).copy())
+        cases.append(dict(image=torch.from_numpy(img), box=box, size=S, flip=flip, resized=res["bilinear"], resized_bicubic=res["bicubic"]))
     import PIL
     torch.save(dict(cases=cases, pil_version=PIL.__version__, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)), OUT)
     print("wrote", OUT, os.path.getsize(OUT), "bytes, PIL", PIL.__version__)

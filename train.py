@@ -32,7 +32,9 @@ LOADERS = None   # (train_loader, calib_loader, val_loader, test_loader) when th
 def device_batches(loader, steps):
     """at most `steps` batches of `loader` through the GPU input pipeline (train.py:215-218 of the reference: DataPrefetcher)"""
     from atomnas_amd.utils import dataflow
-    pre = dataflow.DevicePrefetcher(loader, image_size=cfg.FLAGS.image_size)
+    tf = getattr(getattr(loader, 'dset', None), 'transform', None)   # the split's DeviceTransform: resampling filter, mean, std
+    kw = dict(filter=tf.filter, mean=tf.mean, std=tf.std) if isinstance(tf, dataflow.DeviceTransform) else {}
+    pre = dataflow.DevicePrefetcher(loader, image_size=cfg.FLAGS.image_size, **kw)
     try:
         for i, (x, y) in enumerate(pre):
             if i >= steps:
