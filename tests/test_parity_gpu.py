@@ -82,6 +82,33 @@ def test_full_size_c_supernet_bf16_bs16_blockwise(gpu_lib):
         assert gp_e < 5e-3 and gp_cos > 0.9999, (name, gp_e, gp_cos)
 
 
+def test_full_size_c_supernet_bf16_blockwise_against_the_plain_storage_model(gpu_lib):
+    """The same comparison against the UNMODIFIED storage model (orc.Bf16Storage: bf16 tensors, fp32 arithmetic, no operand roundings of
+    the matrix-core depthwise kernels).  The test above takes its rounding points from the library's own atomnas_dwconv_mm_supported
+    predicate, so a dispatch / predicate bug would move both sides together; this one is independent of it.  Its bounds are 2x what a
+    correct implementation with other operand roundings measures at batch 4 (output 3.2e-3, input gradient 1.8e-2, parameter gradients
+    1.8e-2, cosine 0.99984; with the restated roundings 5.6e-4 / 3.4e-3 / 2.4e-3): a relative operand difference of 2.6e-4 in front of a
+    bf16 rounding sends ~7 % of the elements to the other neighbour (3.9e-3 each), and the block carries that through two BatchNorms."""
+    import atomnas_oracle as orc
+    import parity_diag as pd
+    from atomnas_amd import configs
+    from atomnas_amd.models import mobilenet_base as mb
+    from atomnas_amd.models import mobilenet_supernet as ms
+    torch.manual_seed(3)
+    model = ms.Model(**dict(configs.model_kwparams("atomnas_c_supernet"), input_size=224))
+    model.set_compute_dtype(torch.bfloat16)
+    model.apply(mb.init_weights_mnas)
+    g = torch.Generator().manual_seed(8)
+    N = 4
+    x, y = torch.randn(N, 3, 224, 224, generator=g), torch.randint(0, 1000, (N,), generator=g)
+    rows, _ = pd.teacher_forced(model, x, y, 1000, 0.0, storage=orc.Bf16Storage())
+    assert len(rows) == 22
+    for name, out_e, gin_e, gp_e, gp_cos in rows:
+        assert out_e < 6.5e-3, (name, out_e)
+        assert gin_e < 3.6e-2, (name, gin_e)
+        assert gp_e < 3.6e-2 and gp_cos > 0.9995, (name, gp_e, gp_cos)
+
+
 def _blockwise(model, n_blocks_min):
     import parity_diag as pd
     model.set_compute_dtype(torch.bfloat16)

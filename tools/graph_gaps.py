@@ -3,6 +3,8 @@ replayed steps: wall time from the first kernel's start to the last kernel's end
 consecutive kernels (one queue), and the gaps grouped by the kernel that FOLLOWS them.
 
     python tools/graph_gaps.py gpurun_out/prof_dir [nsteps]
+Trace a run WITHOUT the eager passes of the roofline / cpu legs (bench.py --no-roofline --no-cpu-baseline): every step of such a run
+after the warm-up is a graph replay.
 """
 import collections
 import csv

@@ -60,17 +60,19 @@ def run_pair(model, x, y, dtype, num_classes, p_drop):
                 grads=grads, feats=[(a.double().cpu(), b.detach()) for a, b in zip(outs, feats)], keep=keep, oracle_s=dt)
 
 
-def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32):
+def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32, storage=None):
     """Per-layer parity of a deep bf16 network without the chaos of the whole chain: the oracle (Bf16Storage) runs the full
     training forward / backward once; then every block of the HIP model is run ALONE on the oracle's input of that block and on the
-    oracle's gradient of its output.  Returns rows (name, out rel-L2, input-grad rel-L2, param-grad rel-L2, param-grad cosine)."""
+    oracle's gradient of its output.  Returns rows (name, out rel-L2, input-grad rel-L2, param-grad rel-L2, param-grad cosine).
+    storage: the oracle's storage model (default: Bf16Storage with the matrix-core operand roundings where the LIBRARY says it runs those
+    kernels; pass orc.Bf16Storage() for the predicate-independent model: bf16 tensors, fp32 arithmetic, no operand roundings)."""
     from atomnas_amd import runtime
     sd0 = collections.OrderedDict((k, v.detach().cpu().clone().to(oracle_dtype) if v.is_floating_point() else v.detach().cpu().clone())
                                   for k, v in model.state_dict().items())
     spec = orc.spec_from_model(model)
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
     t0 = time.perf_counter()
-    ref_logits, feats = orc.model_forward(x.bfloat16().to(oracle_dtype), work, spec, True, {}, dropout_mask=None, return_features=True, q=bf16_storage())
+    ref_logits, feats = orc.model_forward(x.bfloat16().to(oracle_dtype), work, spec, True, {}, dropout_mask=None, return_features=True, q=storage if storage is not None else bf16_storage())
     for f in feats:
         f.retain_grad()
     orc.ce_label_smooth(ref_logits, y, 0.1).mean().backward()

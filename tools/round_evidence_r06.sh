@@ -13,7 +13,9 @@ bash tools/profile_round.sh $T > gpurun_out/evidence_$T.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_$T/MFMA -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_${T}_MFMA.log 2>&1)
 python tools/rocprof_summary.py gpurun_out/prof_$T/k_kernel_trace.csv > gpurun_out/${T}_bench_bs256_kernel_summary.txt 2>&1
 cp $(find gpurun_out/prof_$T -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_bench_bs256_kernel_stats.csv 2>/dev/null
-python tools/graph_gaps.py $(dirname $(find gpurun_out/prof_$T -name "*kernel_trace.csv" | head -1)) 3 > gpurun_out/${T}_graph_gaps.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gaps_$T -o k -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1)
+python tools/graph_gaps.py $(dirname $(find gpurun_out/gaps_$T -name "*kernel_trace.csv" | head -1)) 3 > gpurun_out/${T}_graph_gaps.txt 2>&1
+rm -rf gpurun_out/gaps_$T
 python tools/pmc_traffic.py gpurun_out/pmc_$T > profiles/${T}_pmc_traffic.json 2> gpurun_out/${T}_pmc_traffic.log
 python tools/pmc_mfma.py gpurun_out/pmc_$T/MFMA > profiles/${T}_pmc_mfma.json 2> gpurun_out/${T}_pmc_mfma.log
 cp profiles/${T}_pmc_traffic.json profiles/${T}_pmc_mfma.json gpurun_out/ 2>/dev/null
