@@ -6,8 +6,9 @@ moved into a HIP kernel.
                 uint8 pixels on a side stream (a quarter of the fp32 bytes), atomnas_image_preprocess on that stream -> fp32 NCHW batch
 
 Same iterator protocol as the reference's DataPrefetcher (__iter__ / __next__ / __len__, batch k + 1 in flight while batch k trains,
-`torch.cuda.current_stream().wait_stream(side)` at hand-over).  JPEG decoding and LMDB reading are out of scope in this image (no
-decoder, no lmdb): loaders hand over decoded uint8 arrays, e.g. SyntheticDecodedImages below (bench.py --input-pipeline uint8).
+`torch.cuda.current_stream().wait_stream(side)` at hand-over).  Decoding stays on the host, as in the reference: `dataset: imagenet1k`
+(image folders) decodes JPEG / PNG with PIL on loader threads (ImageFolderDecoded); LMDB records cannot be read here (no lmdb module).
+Loaders hand over decoded uint8 arrays, e.g. SyntheticDecodedImages below (bench.py --input-pipeline uint8).
 """
 import ctypes
 import importlib
@@ -240,8 +241,8 @@ class SyntheticDecodedImages(object):
 # data_transforms / dataset / data_loader (utils/dataflow.py:92-267): same names, signatures and FLAGS keys, so that
 # `train.py app:<yml>` reaches the GPU input pipeline from the yaml.  What differs is WHERE the pixel work happens: a transform here
 # only decides (crop box, flip) per sample, the dataset hands out decoded uint8 images with those decisions, and DevicePrefetcher
-# runs crop / resize / flip / ToTensor / Normalize in one kernel per batch.  JPEG decoding and LMDB reading are not available in
-# this image (no decoder, no lmdb): 'imagenet1k' and 'imagenet1k_lmdb' raise and say so.
+# runs crop / resize / flip / ToTensor / Normalize in one kernel per batch.  'imagenet1k' decodes image folders with PIL on loader
+# threads; 'imagenet1k_lmdb' raises (no lmdb module in this image).
 class DeviceTransform(object):
     """What data_transforms returns per split: the deciders of a transform chain whose pixel work is atomnas_image_preprocess.
     transform(img) -> ((top, left, height, width), flip) for a decoded image (HWC array / tensor, PIL image or (width, height))."""
@@ -312,12 +313,60 @@ class DecodedFakeData(object):
     def __len__(self):
         return self.size
 
-    def __getitem__(self, index):
+    def load(self, index):
         if index >= self.size:
             raise IndexError("{} index out of range".format(self.__class__.__name__))
-        im = self.images[index % len(self.images)]
+        return self.images[index % len(self.images)], self.labels[index % len(self.labels)]
+
+    def __getitem__(self, index):
+        im, target = self.load(index)
         box, flip = self.transform(im)
-        return im, box, flip, self.labels[index % len(self.labels)]
+        return im, box, flip, target
+
+
+IMG_EXTENSIONS = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm', '.tif', '.tiff', '.webp')   # torchvision.datasets.folder
+
+
+class ImageFolderDecoded(object):
+    """torchvision.datasets.ImageFolder's role (utils/dataflow.py:176-184, `dataset: imagenet1k`) for the GPU input pipeline: samples are
+    `root/<class>/<file>` with the classes sorted by name (class index = position) and the files of a class sorted by path; `load(i)`
+    decodes with PIL (`Image.open(path).convert('RGB')`, what torchvision's default loader does) into a uint8 HWC tensor (pinned when a
+    GPU is present) -- the decode releases the GIL, so DecodedLoader runs it on `data_loader_workers` threads --, `__getitem__` adds the
+    split's DeviceTransform decisions: (image, box, flip, target).  The pixel work of the transform stays on the GPU."""
+
+    def __init__(self, root, transform):
+        import os
+        self.root, self.transform = root, transform
+        classes = sorted(e.name for e in os.scandir(root) if e.is_dir())
+        if not classes:
+            raise FileNotFoundError("Couldn't find any class folder in {}.".format(root))
+        self.classes = classes
+        self.class_to_idx = {c: i for i, c in enumerate(classes)}
+        self.samples = []
+        for c in classes:
+            for base, _, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+                for f in sorted(files):
+                    if f.lower().endswith(IMG_EXTENSIONS):
+                        self.samples.append((os.path.join(base, f), self.class_to_idx[c]))
+        if not self.samples:
+            raise FileNotFoundError("Found no valid file for the classes in {}.".format(root))
+        self.pin = torch.cuda.is_available()
+
+    def __len__(self):
+        return len(self.samples)
+
+    def load(self, index):
+        from PIL import Image
+        path, target = self.samples[index]
+        with open(path, 'rb') as f:
+            arr = np.asarray(Image.open(f).convert('RGB'))
+        im = torch.from_numpy(np.ascontiguousarray(arr))
+        return (im.pin_memory() if self.pin else im), target
+
+    def __getitem__(self, index):
+        im, target = self.load(index)
+        box, flip = self.transform(im)
+        return im, box, flip, target
 
 
 def dataset(train_transforms, val_transforms, test_transforms, FLAGS):
@@ -331,9 +380,14 @@ def dataset(train_transforms, val_transforms, test_transforms, FLAGS):
         seed = int(FLAGS.get('random_seed', 0))
         train_set = DecodedFakeData(ntrain, train_transforms, seed=seed) if (not FLAGS.get('test_only', False) or FLAGS.get('bn_calibration', False)) else None
         return train_set, DecodedFakeData(nval, val_transforms, seed=seed + 1), None
-    if name in ('imagenet1k', 'imagenet1k_lmdb'):
-        raise NotImplementedError("dataset '{}': needs a JPEG decoder{} (not in this image); decoded sources: 'imagenet1k_decoded_fake' or a "
-                                  "module with dataset(train_transforms, val_transforms, test_transforms)".format(name, " and lmdb" if name.endswith('lmdb') else ""))
+    if name == 'imagenet1k':
+        import os
+        train_set = (ImageFolderDecoded(os.path.join(FLAGS.dataset_dir, 'train'), train_transforms)
+                     if (not FLAGS.get('test_only', False) or FLAGS.get('bn_calibration', False)) else None)
+        return train_set, ImageFolderDecoded(os.path.join(FLAGS.dataset_dir, 'val'), val_transforms), None
+    if name == 'imagenet1k_lmdb':
+        raise NotImplementedError("dataset 'imagenet1k_lmdb': the lmdb module is not in this image (utils/lmdb_dataset.py:24-71); the same "
+                                  "records decode through ImageFolderDecoded's PIL path once they can be read -- use 'imagenet1k' (image folders)")
     try:
         dataset_lib = importlib.import_module(name)
         return dataset_lib.dataset(train_transforms, val_transforms, test_transforms)
@@ -345,11 +399,15 @@ class DecodedLoader(object):
     """torch.utils.data.DataLoader's role for decoded samples (utils/dataflow.py:217-225 `_build_loader`): batches of `batch_size`
     samples (image, box, flip, target) -> (images, boxes, flips, targets int64 pinned), the form DevicePrefetcher takes.  shuffle:
     a fresh seeded permutation per pass; rank / world: the DistributedSampler split (every rank the same number of samples, the
-    index list padded by wrapping around); drop_last as torch's.  Samples are drawn in the iterating thread -- with DevicePrefetcher
-    that is its worker thread, off the training thread."""
+    index list padded by wrapping around); drop_last as torch's.  workers > 0: the samples of a batch are LOADED (decoded) on that many
+    threads (PIL's decoder releases the GIL); the transform's random decisions are then drawn in sample order by the iterating thread
+    (one stream of Python's `random`, whatever the thread timing) -- with DevicePrefetcher that is its worker thread, off the training
+    thread."""
 
-    def __init__(self, dset, batch_size, shuffle, rank=0, world=1, drop_last=False, seed=0):
+    def __init__(self, dset, batch_size, shuffle, rank=0, world=1, drop_last=False, seed=0, workers=0):
         self.dset, self.batch_size, self.shuffle = dset, int(batch_size), bool(shuffle)
+        self.workers = max(0, int(workers))
+        self._pool = None
         self.rank, self.world, self.drop_last, self.seed = int(rank), int(world), bool(drop_last), int(seed)
         self.epoch = 0
         n = len(dset)
@@ -375,14 +433,24 @@ class DecodedLoader(object):
         pin = torch.cuda.is_available()
         for b in range(len(self)):
             chunk = idx[b * self.batch_size:(b + 1) * self.batch_size]
-            samples = [self.dset[i] for i in chunk]
+            if self.workers > 0 and hasattr(self.dset, "load") and hasattr(self.dset, "transform"):
+                if self._pool is None:
+                    import concurrent.futures
+                    self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="atomnas-decode")
+                loaded = list(self._pool.map(self.dset.load, chunk))
+                samples = []
+                for im, tgt in loaded:
+                    box, flip = self.dset.transform(im)
+                    samples.append((im, box, flip, tgt))
+            else:
+                samples = [self.dset[i] for i in chunk]
             target = torch.tensor([s[3] for s in samples], dtype=torch.int64)
             yield [s[0] for s in samples], [s[1] for s in samples], [s[2] for s in samples], (target.pin_memory() if pin else target)
 
 
 def data_loader(train_set, val_set, test_set, FLAGS):
-    """Get data loader (utils/dataflow.py:214-267) -> (train_loader, calib_loader, val_loader, test_loader).  `data_loader_workers`
-    is accepted and unused: there is no per-sample pixel work left on the host to spread over worker processes."""
+    """Get data loader (utils/dataflow.py:214-267) -> (train_loader, calib_loader, val_loader, test_loader).  `data_loader_workers`:
+    decode threads of a loader (at most 16; the reference's worker processes also crop / resize / normalize, which is GPU work here)."""
     if FLAGS.data_loader != 'imagenet1k_basic':
         try:
             data_loader_lib = importlib.import_module(FLAGS.data_loader)
@@ -396,14 +464,15 @@ def data_loader(train_set, val_set, test_set, FLAGS):
     training = not FLAGS.get('test_only', False)
     calibrating = bool(FLAGS.get('bn_calibration', False))
     seed = int(FLAGS.get('random_seed', 0))
+    workers = min(16, int(FLAGS.get('data_loader_workers', 0) or 0))
 
     def _build_loader(dset, batch_size, shuffle):
         # distributed: the sampler shuffles (DistributedSampler's default) and the loader does not; single process: the loader does
         return DecodedLoader(dset, batch_size, shuffle if world is None else True, rank=rank or 0, world=world or 1,
-                             drop_last=FLAGS.get('drop_last', False), seed=seed)
+                             drop_last=FLAGS.get('drop_last', False), seed=seed, workers=workers)
 
     train_loader = _build_loader(train_set, FLAGS._loader_batch_size, True) if training else None
     calib_loader = _build_loader(train_set, FLAGS.get('_loader_batch_size_calib', FLAGS._loader_batch_size), True) if calibrating else None
     val_loader = _build_loader(val_set, FLAGS._loader_batch_size, False) if world is None else \
-        DecodedLoader(val_set, FLAGS._loader_batch_size, True, rank=rank, world=world, drop_last=FLAGS.get('drop_last', False), seed=seed)
+        DecodedLoader(val_set, FLAGS._loader_batch_size, True, rank=rank, world=world, drop_last=FLAGS.get('drop_last', False), seed=seed, workers=workers)
     return train_loader, calib_loader, val_loader, val_loader

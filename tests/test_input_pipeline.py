@@ -189,7 +189,7 @@ def test_data_factories_refuse_what_this_image_cannot_do():
         DF.data_transforms(_flags(data_transforms="imagenet1k_basic"))
     with pytest.raises(NotImplementedError, match="not yet implemented"):
         DF.data_transforms(_flags(data_transforms="no_such_module_xyz"))
-    with pytest.raises(NotImplementedError, match="JPEG"):
+    with pytest.raises(NotImplementedError, match="lmdb"):
         DF.dataset(None, None, None, _flags(dataset="imagenet1k_lmdb"))
     with pytest.raises(NotImplementedError, match="not yet implemented"):
         DF.data_loader(None, None, None, _flags(data_loader="no_such_loader_xyz"))
@@ -198,3 +198,51 @@ def test_data_factories_refuse_what_this_image_cannot_do():
     assert T.RandomResizedCropPadding(224, interpolation=3).filter == "bicubic" and T.RandomResizedCropPadding(224, interpolation=2).filter == "bilinear"
     fake = DF.dataset(None, None, None, _flags(dataset="imagenet1k_fake"))   # the reference's zero-image smoke source keeps its form
     assert len(fake[0]) == 1281167 and fake[0][0][0].shape == (3, 224, 224) and fake[0][0][1] == 0
+
+
+def _make_image_folder(root, classes, per_class, seed=0):
+    """root/{train,val}/<class>/<k>.jpg|png written with PIL: what torchvision's ImageFolder reads"""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    for split in ("train", "val"):
+        for c in classes:
+            d = os.path.join(root, split, c)
+            os.makedirs(d)
+            for k in range(per_class):
+                H, W = int(rng.randint(40, 90)), int(rng.randint(40, 90))
+                img = Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8))
+                img.save(os.path.join(d, "%02d.%s" % (k, "png" if k % 3 == 0 else "jpg")), quality=90)
+        with open(os.path.join(root, split, "notes.txt"), "w") as f:   # stray files at the class level are ignored
+            f.write("x")
+
+
+def test_image_folder_dataset_decodes_like_the_reference_loader(tmp_path):
+    """`dataset: imagenet1k` (utils/dataflow.py:176-184: torchvision ImageFolder over dataset_dir/train and /val): classes sorted by name,
+    files sorted inside a class, decoded with PIL to RGB; samples carry the split's crop / flip decisions; decode on loader threads
+    gives the same batches as the sequential form (the random decisions are drawn in sample order by one thread)."""
+    from PIL import Image
+    from atomnas_amd.utils import dataflow as DF
+    root = str(tmp_path)
+    _make_image_folder(root, ["n02", "n01", "n10"], 4)
+    F = _flags(dataset="imagenet1k", dataset_dir=root, _loader_batch_size=5, bn_calibration=False, data_loader_workers=3)
+    tr, va, te = DF.data_transforms(F)
+    train_set, val_set, _ = DF.dataset(tr, va, te, F)
+    assert train_set.classes == ["n01", "n02", "n10"] and len(train_set) == 12 and len(val_set) == 12
+    assert [t for _, t in train_set.samples] == [0] * 4 + [1] * 4 + [2] * 4
+    assert [os.path.basename(p_) for p_, _ in train_set.samples[:4]] == ["00.png", "01.jpg", "02.jpg", "03.png"]
+    im, box, flip, target = val_set[5]
+    want = np.asarray(Image.open(val_set.samples[5][0]).convert("RGB"))
+    assert im.dtype == torch.uint8 and np.array_equal(im.numpy(), want) and target == 1
+    assert box == T.CenterCropPadding(224, 32).get_box(im) and flip is False
+    loaders = DF.data_loader(train_set, val_set, None, F)
+    assert loaders[0].workers == 3 and len(loaders[0]) == 3
+    random.seed(9)
+    threaded = list(loaders[0])
+    seq_loader = DF.DecodedLoader(train_set, 5, True, seed=F.random_seed, workers=0)
+    random.seed(9)
+    sequential = list(seq_loader)
+    assert [len(b[0]) for b in threaded] == [5, 5, 2]
+    for a, b in zip(threaded, sequential):
+        assert all(torch.equal(x, y) for x, y in zip(a[0], b[0])) and a[1] == b[1] and a[2] == b[2] and torch.equal(a[3], b[3])
+    with pytest.raises(FileNotFoundError):
+        DF.ImageFolderDecoded(os.path.join(root, "train", "n01"), tr)   # no class folders below
