@@ -60,15 +60,18 @@ def run_pair(model, x, y, dtype, num_classes, p_drop):
                 grads=grads, feats=[(a.double().cpu(), b.detach()) for a, b in zip(outs, feats)], keep=keep, oracle_s=dt)
 
 
-def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32, storage=None):
+def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32, storage=None, oracle_device="cpu"):
     """Per-layer parity of a deep bf16 network without the chaos of the whole chain: the oracle (Bf16Storage) runs the full
     training forward / backward once; then every block of the HIP model is run ALONE on the oracle's input of that block and on the
     oracle's gradient of its output.  Returns rows (name, out rel-L2, input-grad rel-L2, param-grad rel-L2, param-grad cosine).
     storage: the oracle's storage model (default: Bf16Storage with the matrix-core operand roundings where the LIBRARY says it runs those
-    kernels; pass orc.Bf16Storage() for the predicate-independent model: bf16 tensors, fp32 arithmetic, no operand roundings)."""
+    kernels; pass orc.Bf16Storage() for the predicate-independent model: bf16 tensors, fp32 arithmetic, no operand roundings).
+    oracle_device: "cuda" runs the oracle's torch ops on the GPU (ATen / MIOpen: still not this library) -- what makes batch 256 feasible."""
     from atomnas_amd import runtime
-    sd0 = collections.OrderedDict((k, v.detach().cpu().clone().to(oracle_dtype) if v.is_floating_point() else v.detach().cpu().clone())
+    od = torch.device(oracle_device)
+    sd0 = collections.OrderedDict((k, v.detach().to(od).clone().to(oracle_dtype) if v.is_floating_point() else v.detach().to(od).clone())
                                   for k, v in model.state_dict().items())
+    x, y = x.to(od), y.to(od)
     spec = orc.spec_from_model(model)
     work = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd0.items()}
     t0 = time.perf_counter()
@@ -97,9 +100,9 @@ def teacher_forced(model, x, y, num_classes, p_drop, oracle_dtype=torch.float32,
             mgr.leave()
         torch.cuda.synchronize()
         pg = torch.cat([p.grad.double().cpu().flatten() for _, p in blk.named_parameters()])
-        pr = torch.cat([work["features.%s.%s" % (name, n)].grad.double().flatten() for n, _ in blk.named_parameters()])
-        rows.append(("features." + name, rel_l2(out.double().cpu(), feats[i + 1].detach().double()),
-                     rel_l2(xin.grad.double().cpu(), feats[i].grad.double()), rel_l2(pg, pr),
+        pr = torch.cat([work["features.%s.%s" % (name, n)].grad.double().cpu().flatten() for n, _ in blk.named_parameters()])
+        rows.append(("features." + name, rel_l2(out.double().cpu(), feats[i + 1].detach().double().cpu()),
+                     rel_l2(xin.grad.double().cpu(), feats[i].grad.double().cpu()), rel_l2(pg, pr),
                      float(torch.dot(pg, pr) / (pg.norm() * pr.norm()))))
     return rows, oracle_s
 
