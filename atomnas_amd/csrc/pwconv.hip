@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* 
 //   ST_MASK : C = mask_z(A * W^T), optional sum c / sum c*z statistics        (the input gradient of the projection through the
 //             activation of the depthwise BatchNorm; A is the already differentiated BatchNorm output, see atomnas_bnbwd_apply)
 //   ST_PBWD : ST_MASK plus the projection's weight gradient of the wave's 64 channels (atomnas_project_bwd without a prologue)
-// A is plain bf16 without a prologue, K a multiple of 8; weights as for k_gemm_nt_cs (rows >= N and columns >= K of Wp are zero).
+// A is plain bf16 without a prologue, K a multiple of 8; rows >= N and columns >= K of the packed weights Wp are zero.
 constexpr int PB_RP = 16 + 4;   // rows of a tile + pad (elements): 40-byte rows, 8-byte aligned fragment reads
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 enum { ST_FWD = 1, ST_MASK = 2, ST_PBWD = 3 };
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   f32x2 s1[8], s2[8];   // per-lane statistics of channels nb + 2 i, nb + 2 i + 1 (pairs: v_pk_add_f32 / v_pk_fma_f32)
 #pragma unroll
   for (int i = 0; i < 8; ++i) s1[i] = s2[i] = f32x2{0.f, 0.f};
-  // ST_PBWD: the weight gradient dWp[o][n] += sum_m A[m][o] * act(bn(z))[m][n] of the wave's 64 channels, as in k_project_bwd_cs
+  // ST_PBWD: the weight gradient dWp[o][n] += sum_m A[m][o] * act(bn(z))[m][n] of the wave's 64 channels
   // (both operands transposed through a wave-private LDS region, 16x16x16 MFMAs over the tile's 16 rows)
   constexpr int UTA = UT > 0 ? UT : 1;
   f32x4 racc[UTA][4];
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(256, EB_MINWG) void k_expand_bwd(Operand A, const b
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-// The streaming instances take the cases they are written for (see k_gemm_nt_st); everything else stays with k_gemm_nt_cs.
+// The streaming instances take the cases they are written for (see k_gemm_nt_st); everything else goes on to the LDS-weights / generic kernels.
 static int nt_st_kind(int mode, const Operand& A, const Epilogue& ep, long M, int N, int K) {
   static const int on = getenv("ATOMNAS_NT_ST") ? atoi(getenv("ATOMNAS_NT_ST")) : 1;
   if (!on || mode != PRO_NONE || (K & 7) || ep.bias || ep.add || ep.out_f32) return 0;
@@ -1253,7 +1253,7 @@ static void launch_nt_st(int kind, const Operand& A, const void* Wp, int ldw, co
     long tiles_per_item = (mtiles * wchunks + waves - 1) / waves;                                                       \
     if (tiles_per_item < 8) tiles_per_item = 8;                                                                         \
     if (tiles_per_item < min_tpi) tiles_per_item = min_tpi;                                                             \
-    const long max_ranges = waves / wchunks > 0 ? waves / wchunks : 1;   /* one round of workgroups, as for k_gemm_nt_cs */ \
+    const long max_ranges = waves / wchunks > 0 ? waves / wchunks : 1;   /* one round of workgroups */ \
     if ((mtiles + tiles_per_item - 1) / tiles_per_item > max_ranges) tiles_per_item = (mtiles + max_ranges - 1) / max_ranges; \
     if (tiles_per_item > 4096) tiles_per_item = 4096;   /* keeps t * tile bytes in 32 bits (nt_st_kind) */              \
     const long nrg = (mtiles + tiles_per_item - 1) / tiles_per_item;                                                    \
@@ -1626,8 +1626,32 @@ __global__ __launch_bounds__(NWV * 64, WGPC) void k_gemm_nt_swg(const bf16_t* __
         asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(cf[ks][2]) : "v"(cb) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:272" : "=v"(cf[ks][3]) : "v"(cb) : "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // Round 6, the instances with one wave per SIMD (UT >= 12: the 7x7 maps, where a stage was a dependent chain read -> wait ->
+      // arithmetic -> read -> wait -> MFMA, profiles/r06_late_stage_gemm_experiments.txt): the weight fragments of a k-step are in flight
+      // while the prologue of the activations runs, and those of the second k-step while the MFMAs of the first issue.  LDS reads of a wave
+      // return in order, so the waits are counted (lgkmcnt(LGK) = everything but the LGK fragment reads issued last; tools/check_asm_waits.py
+      // models it).  Same MFMA order per accumulator: bit-identical results.  In situ: N192 K3456 0.251 -> 0.231 ms per step (three launches),
+      // N320 0.111 -> 0.108; the 14x14 instances (two and more waves per SIMD overlap the chain by themselves) measured 1-2 % SLOWER with
+      // it and keep the plain sequence.
+      constexpr bool PREFETCH = UT >= 12;
+      constexpr int LGK = UT < 15 ? UT : 15;   // the counter has four bits: with more fragment reads behind it the wait covers a few of them too
+      bf16x8 wf[PREFETCH ? 2 : 1][UT];
+      auto read_w = [&](int ks, int buf) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          const int wr = 16 * t + j, p = 4 * ks + q;
+          const unsigned wa = base + (unsigned)AT * 1024u + (unsigned)wr * 128u + (unsigned)((p ^ (wr & 7)) << 4);
+          asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][t]) : "v"(wa) : "memory");
+        }
+      };
+      if constexpr (PREFETCH) {
+        read_w(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LGK) : "memory");   // activations and coefficients of both k-steps
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
+      bf16x8 af[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int k0 = 64 * c + 32 * ks + 8 * q;
@@ -1641,20 +1665,27 @@ __global__ __launch_bounds__(NWV * 64, WGPC) void k_gemm_nt_swg(const bf16_t* __
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (k0 + e >= K) v[e] = 0.f;   // (act(0) is 0 for the three activations; kept explicit)
-        bf16x8 af;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) af[e] = (bf16_t)v[e];
-        bf16x8 wf[UT];   // the k-step's weight fragments: all reads in flight, one wait
+        for (int e = 0; e < 8; ++e) af[ks][e] = (bf16_t)v[e];
+        if constexpr (!PREFETCH) {   // the k-step's weight fragments: all reads in flight, one wait, then its MFMAs
+          read_w(ks, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < UT; ++t) {
-          const int wr = 16 * t + j, p = 4 * ks + q;
-          const unsigned wa = base + (unsigned)AT * 1024u + (unsigned)wr * 128u + (unsigned)((p ^ (wr & 7)) << 4);
-          asm volatile("ds_read_b128 %0, %1" : "=v"(wf[t]) : "v"(wa) : "memory");
+          for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], af[ks], acc[t], 0, 0, 0);
         }
+      }
+      if constexpr (PREFETCH) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_w(1, 1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LGK) : "memory");   // the first k-step's fragments
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], af[0], acc[t], 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], af, acc[t], 0, 0, 0);
+        for (int t = 0; t < UT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], af[1], acc[t], 0, 0, 0);
       }
       slot = slot + 1 == DEPTH ? 0 : slot + 1;
     }

@@ -342,6 +342,33 @@ _Z4goodv:
     assert n == 1 and len(f) == 1 and "v_add_f32" in f[0], f
 
 
+def test_asm_wait_checker_counted_lgkm_waits(tmp_path):
+    """Counted `s_waitcnt lgkmcnt(N)` (k_gemm_nt_swg, round 6): LDS operations return in order, so the wait covers every asm load but the
+    N operations issued last; a use of one of the last N is a finding, a compiler-issued LDS operation in between counts as one of
+    them, and with a scalar-memory load in flight (out-of-order return) only lgkmcnt(0) covers anything."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_asm_waits as caw
+
+    def kern(body):
+        return "_Z4kernv:\n" + body + "\ts_endpgm\n.Lfunc_end0:\n"
+    rd = lambda r, a: "\t;;#ASMSTART\n\tds_read_b128 v[%d:%d], v%d\n\t;;#ASMEND\n" % (r, r + 3, a)
+    wait = lambda n: "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(%d)\n\t;;#ASMEND\n" % n
+    use = lambda r: "\tv_add_f32_e32 v1, v%d, v%d\n" % (r, r)
+    cases = {
+        "older_ok": (rd(10, 5) + rd(20, 6) + wait(1) + use(10), 0),
+        "newest_in_flight": (rd(10, 5) + rd(20, 6) + wait(1) + use(20), 1),
+        "compiler_lds_op_counts": (rd(10, 5) + "\tds_write_b32 v7, v8\n" + wait(1) + use(10), 0),
+        "count_past_the_block": (rd(10, 5) + wait(2) + use(10), 1),
+        "smem_in_flight": ("\t;;#ASMSTART\n\ts_load_dwordx2 s[4:5], s[0:1], 0x0\n\t;;#ASMEND\n" + rd(10, 5) + rd(20, 6) + wait(1) + use(10), 1),
+        "zero_covers_all": (rd(10, 5) + rd(20, 6) + wait(0) + use(20) + use(10), 0),
+    }
+    for name, (body, nfind) in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(kern(body))
+        findings, _ = caw.check(str(f))
+        assert len(findings) == nfind, (name, findings)
+
+
 def test_ring_checker_counts_copies_behind_the_awaited_stage(tmp_path):
     """tools/check_asm_waits.check_rings on synthetic assembly: a ring of three stages of two copies with `s_waitcnt vmcnt(2)` in its loop
     (two stages ahead: exact) passes; the same loop with vmcnt(4) -- more than what was issued behind the awaited stage -- is a finding,

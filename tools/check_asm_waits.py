@@ -8,7 +8,9 @@ scans the gfx950 assembly of a translation unit and reports every instruction th
     python tools/check_asm_waits.py atomnas_amd/csrc/dwconv_cw.hip      (compiles with the build's flags, -S)  -> exit 1 on a finding
 
 Per function a forward data-flow over the basic blocks: registers written by an asm load are pending until an `s_waitcnt` with
-lgkmcnt(0), and no instruction outside ASMSTART/ASMEND may name a pending register on any path.
+lgkmcnt(0) -- or, round 6, a COUNTED lgkmcnt(N) that provably covers them (LDS operations return in order: everything but the N
+operations issued last, when no scalar-memory load is in flight) --, and no instruction outside ASMSTART/ASMEND may name a pending
+register on any path.
 
 Round 5: the LDS-DMA rings (k_expand_bwd_s, k_gemm_nt_sw, k_gemm_tn3 of pwconv.hip, k_gram_part of xbwd.hip) wait for their copies with
 a COUNTED `s_waitcnt vmcnt(N)`.  That is right only if (check_rings)
@@ -117,28 +119,54 @@ def check(path):
             if op not in ("s_branch", "s_endpgm", "s_setpc_b64") and i + 1 < len(blocks):
                 succ[i].append(i + 1)
         entry = [set() for _ in blocks]
+        smem_entry = [False for _ in blocks]   # a scalar-memory load may be in flight at the block's entry
         work = list(range(len(blocks)))
         reported = set()
         while work:
             i = work.pop()
             pending = set(entry[i])
+            # Counted waits (round 6, k_gemm_nt_swg): LDS operations of a wave return in order, so `s_waitcnt lgkmcnt(N)` completes every
+            # LDS operation but the N issued last.  `events` = the lgkm-class operations of THIS block in issue order (asm loads with their
+            # destination registers, compiler-issued ds_* / scalar-memory operations with none); a counted wait retires the block's own
+            # events but the last N -- and everything pending from the predecessors, which is older -- when N does not reach past the
+            # block's own events and no scalar-memory load (they may return out of order) is among what is in flight.
+            events, smem_in_flight = [], bool(smem_entry[i])
             for ln, t, ia in blocks[i]:
                 op, _, rest = t.partition(" ")
                 if op == "s_waitcnt":
-                    if "lgkmcnt(0)" in rest:
-                        pending = set()
+                    m = re.search(r"lgkmcnt\((\d+)\)", rest)
+                    if m is not None:
+                        n = int(m.group(1))
+                        if n == 0:
+                            pending, events, smem_in_flight = set(), [], False
+                        elif not smem_in_flight and n <= len(events):
+                            done = events[:len(events) - n]
+                            events = events[len(events) - n:]
+                            still = set().union(*[e for e in events]) if events else set()
+                            pending = still   # the predecessors' loads and this block's older ones are complete
+                            del done
                     continue
+                is_lgkm = op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("s_scratch_load")
+                if is_lgkm and not op.startswith("ds_"):
+                    smem_in_flight = True
                 if ia:
                     if op in ASM_LOADS:
-                        pending |= regs(rest.split(",")[0])
+                        r = regs(rest.split(",")[0])
+                        pending |= r
+                        events.append(r)
+                    elif is_lgkm:
+                        events.append(set())
                     continue
+                if is_lgkm:
+                    events.append(set())
                 hit = regs(rest) & pending
                 if hit and ln not in reported:
                     reported.add(ln)
                     findings.append("%s:%d %s: `%s` touches %s while its asm load is in flight" % (os.path.basename(path), ln, func, t, sorted(hit)[:4]))
             for j in succ[i]:
-                if not pending <= entry[j]:
+                if not pending <= entry[j] or (smem_in_flight and not smem_entry[j]):
                     entry[j] |= pending
+                    smem_entry[j] = smem_entry[j] or smem_in_flight
                     work.append(j)
         nloads += sum(1 for _, t, ia in ins if ia and t.split(" ")[0] in ASM_LOADS)
     return findings, nloads

@@ -13,7 +13,7 @@ import csv, glob, json, re, sys, collections
 FAMILIES = {"k_dwb_mm": "atomnas_dwconv_bwd", "k_dwf_mm2": "atomnas_dwconv_fwd", "k_dwf_mm": "atomnas_dwconv_fwd", "k_gemm_nt_swg": "atomnas_pw_gemm_nt", "k_expand_bwd_s": "atomnas_expand_bwd", "k_gemm_nt_sw": "atomnas_pw_gemm_nt", "k_dwb_cw2": "atomnas_dwconv_bwd", "k_dwb_cw": "atomnas_dwconv_bwd", "k_dwf_cw": "atomnas_dwconv_fwd",
             "k_gemm_nt_st": "atomnas_pw_gemm_nt",   # (its ST_PBWD instances run behind atomnas_project_bwd: a few launches of 78)
             "k_expand_bwd": "atomnas_expand_bwd", "k_gemm_nt_small": "atomnas_pw_gemm_nt",
-            "k_dwconv_bwd": "atomnas_dwconv_bwd", "k_dwconv_fwd": "atomnas_dwconv_fwd", "k_gemm_nt_cs": "atomnas_pw_gemm_nt",
+            "k_dwconv_bwd": "atomnas_dwconv_bwd", "k_dwconv_fwd": "atomnas_dwconv_fwd", 
             "k_gemm_nt_ws": "atomnas_pw_gemm_nt", "k_gemm_nt": "atomnas_pw_gemm_nt", "k_gemm_tn3": "atomnas_pw_gemm_tn", "k_gemm_tn2": "atomnas_pw_gemm_tn",
             "k_gemm_tn": "atomnas_pw_gemm_tn"}
 
