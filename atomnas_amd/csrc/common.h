@@ -117,13 +117,15 @@ template <int V> struct VecIO<bf16_t, V> {
 // Activation modes carried by the integer `relu` / `mask` arguments of the C ABI: 0 none, 1 ReLU, 2 ReLU6, 3 Swish
 // (models/mobilenet_base.py:407-415 `get_active_fn`, :72-80 `Swish`).
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_SWISH = 3 };
-// Resolved once per kernel into the original ReLU flag plus one uniform upper bound (6 or +inf): the ReLU select keeps the
-// code generation the kernels were tuned with, ReLU6 costs one v_min / one compare with a scalar operand.  (Measured on the
-// depthwise backward: a three-way select on the mode per element +35 %, a (lo, hi) clamp +14 % through register pressure.)
+// Resolved once per kernel into two uniform bounds: none (-inf, +inf), ReLU (0, +inf), ReLU6 (0, 6).  The forward is ONE v_med3_f32 per
+// element for the three of them (round 6: the earlier `fminf(relu ? fmaxf(a, 0) : a, hi)` compiled to five instructions per element --
+// two canonicalising v_max, v_max with 0, a select on the flag, v_min -- 40 of the ~90 prologue instructions per k-step of the 1x1 GEMMs,
+// which are bound by instruction issue where they run at one wave per SIMD: profiles/r06_late_stage_gemm_experiments.txt); the backward is
+// two compares.  Same values for every non-NaN input; a NaN now propagates instead of becoming 0.
 // Swish (x * sigmoid(x)) sits behind a wave-uniform branch: the ReLU paths do not execute the exponential.
-struct Act { int relu; float hi; int swish; };
+struct Act { float lo; float hi; int swish; };
 __device__ __forceinline__ Act act_of(int mode) {
-  return Act{mode == ACT_RELU || mode == ACT_RELU6, mode == ACT_RELU6 ? 6.f : __builtin_inff(), mode == ACT_SWISH};
+  return Act{mode == ACT_RELU || mode == ACT_RELU6 ? 0.f : -__builtin_inff(), mode == ACT_RELU6 ? 6.f : __builtin_inff(), mode == ACT_SWISH};
 }
 __device__ __forceinline__ float swish_f(float a) { return a / (1.f + __expf(-a)); }
 // d/da [a * sigmoid(a)] = s * (1 + a * (1 - s))
@@ -133,7 +135,7 @@ __device__ __forceinline__ float swish_grad(float a) {
 }
 __device__ __forceinline__ float act_apply(float a, Act m) {
   if (__builtin_expect(m.swish, 0)) return swish_f(a);
-  return fminf(m.relu ? fmaxf(a, 0.f) : a, m.hi);
+  return __builtin_amdgcn_fmed3f(a, m.lo, m.hi);
 }
 // vector form: ONE wave-uniform branch per V values (per-element calls leave a branch per element in the unrolled hot loops)
 template <int V> __device__ __forceinline__ void act_apply_v(float (&a)[V], Act m) {
@@ -142,11 +144,11 @@ template <int V> __device__ __forceinline__ void act_apply_v(float (&a)[V], Act 
     for (int e = 0; e < V; ++e) a[e] = swish_f(a[e]);
   } else {
 #pragma unroll
-    for (int e = 0; e < V; ++e) a[e] = fminf(m.relu ? fmaxf(a[e], 0.f) : a[e], m.hi);
+    for (int e = 0; e < V; ++e) a[e] = __builtin_amdgcn_fmed3f(a[e], m.lo, m.hi);
   }
 }
 // act_pass = the derivative is non-zero at pre-activation a (ReLU / ReLU6 / none)
-__device__ __forceinline__ bool act_pass(float a, Act m) { return !(m.relu && !(a > 0.f)) && a < m.hi; }
+__device__ __forceinline__ bool act_pass(float a, Act m) { return a > m.lo && a < m.hi; }
 // gradient c of the activated value back through the activation at pre-activation a
 __device__ __forceinline__ float act_bwd(float c, float a, Act m) {
   if (__builtin_expect(m.swish, 0)) return c * swish_grad(a);

@@ -1659,12 +1659,17 @@ __global__ __launch_bounds__(NWV * 64, WGPC) void k_gemm_nt_swg(const bf16_t* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float sc = cf[ks][e >> 2][e & 3], sh = cf[ks][2 + (e >> 2)][e & 3];
-          v[e] = (k0 + e < K) ? (float)hb[ks][e] * sc + sh : 0.f;
+          v[e] = (float)hb[ks][e] * sc + sh;
         }
         act_apply_v<8>(v, am);
+        // channels past K exist in the last chunk only (wave-uniform test): their copies re-read valid slabs and coefficients, so v is
+        // finite there and is replaced by 0 after the activation (round 6: the per-element bound was 32 of the prologue's instructions
+        // per k-step in every chunk)
+        if (64 * c + 64 > K) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (k0 + e >= K) v[e] = 0.f;   // (act(0) is 0 for the three activations; kept explicit)
+          for (int e = 0; e < 8; ++e)
+            if (k0 + e >= K) v[e] = 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) af[ks][e] = (bf16_t)v[e];
         if constexpr (!PREFETCH) {   // the k-step's weight fragments: all reads in flight, one wait, then its MFMAs
