@@ -164,6 +164,15 @@ template <int V> __device__ __forceinline__ void act_bwd_v(float* c, const float
   }
 }
 
+// fp32 values of a PACKED pair of bf16 (bits of two stored outputs): one shift, one mask.  The epilogues that accumulate statistics of
+// the STORED values use it on the registers they store: written as `(float)(bf16_t)x` per element the compiler converts every value twice
+// (one v_cvt_pk_bf16_f32 per pair for the store, one per ELEMENT for the statistics -- 6 conversions per 4 outputs, 17 % of the expand
+// forward's loop; round 6, profiles/r06_late_stage_gemm_experiments.txt).  Callers pin the packed registers with an empty asm BEFORE the
+// store and the statistics read them, so that instruction selection cannot split the conversion again.
+__device__ __forceinline__ f32x2 bf16_pair_f32(unsigned bits) {
+  return f32x2{__builtin_bit_cast(float, bits << 16), __builtin_bit_cast(float, bits & 0xffff0000u)};
+}
+
 // Activation layouts (include/atomnas_hip.h).  plain: [M][ld], element (row, c) at row*ld + c.  slab-major (ss > 0): the channel
 // dimension is cut into slabs of 16 channels and every slab is a contiguous [M][16] matrix, slab stride ss elements:
 // (c/16)*ss + row*16 + c%16.  A workgroup that owns a channel range then streams CONTIGUOUS memory (32-byte pixels back to back)

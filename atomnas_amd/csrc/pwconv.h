@@ -192,6 +192,21 @@ __device__ __forceinline__ void nt_epilogue_core(const Epilogue& ep, const f32x4
 #pragma unroll
         for (int i = 0; i < 8; ++i) o8[i] = c[8 * h8 + i];
         VecIO<float, 8>::store(cp, o8);
+      } else if constexpr (sizeof(T) == 2) {
+        // one packed conversion per pair; the statistics see the stored values through the bits that are stored (common.h: bf16_pair_f32)
+        bf16x8 ob;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ob[i] = (bf16_t)c[8 * h8 + i];
+        typedef __attribute__((ext_vector_type(4))) unsigned bits4;
+        bits4 bits = __builtin_bit_cast(bits4, ob);
+        asm volatile("" : "+v"(bits));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 o = bf16_pair_f32(bits[i]);
+          c[8 * h8 + 2 * i] = o[0];
+          c[8 * h8 + 2 * i + 1] = o[1];
+        }
+        *reinterpret_cast<bits4*>(reinterpret_cast<T*>(ep.c) + lay_off(row, n8, ep.ldc, ep.css)) = bits;
       } else {
         float o8[8];
 #pragma unroll

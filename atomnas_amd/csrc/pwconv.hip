@@ -279,11 +279,12 @@ template <int KSTEPS, int EPK> struct StCfg {
   static constexpr int BT = EPK == ST_PBWD ? (KSTEPS == 1 ? ST_PB_BT1 : ST_PB_BT2)   // registers: + the weight-gradient accumulators
                                             : KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : ST_BT6;
   static constexpr int PD = BT > 0 ? (BT >= 2 ? 2 : 1) : 2;
-  static constexpr int WPE = EPK != ST_FWD ? 1 : KSTEPS == 1 ? ST_WPE1 : KSTEPS == 2 ? ST_WPE2 : KSTEPS == 3 ? ST_WPE3 : 1;
+  static constexpr int WPE = EPK == ST_PBWD ? 1 : 2;
   static constexpr bool SH = ST_SHARED && BT > 0 && BT % 4 == 0 && EPK != ST_PBWD;   // bursts shared by the workgroup's four waves
   static constexpr int BTP = KSTEPS <= 3 ? BT : 0;   // burst tiles of the private (per-wave) form
 };
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 constexpr unsigned ST_OOB = 0x80000000u;   // >= num_records of every resource below
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* p) {
@@ -466,29 +467,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       bf16x8 ob;
 #pragma unroll
       for (int i = 0; i < 8; ++i) ob[i] = (bf16_t)c[8 * h + i];
+      u32x4 obits = __builtin_bit_cast(u32x4, ob);
+      asm volatile("" : "+v"(obits));   // the packed conversion happens once (common.h: bf16_pair_f32)
       // The tile offset rides in soffset (one scalar for all unrolled tiles instead of a vector induction variable per access and
       // tile).  HAZARD: with an SGPR soffset LLVM does not keep the next VALU instructions off the store's data registers (its rule
       // exempts that form), but on gfx950 data overwritten in the two instructions after the store IS what gets written (r03: 0.17 %
       // wrong elements in test_gemm_nt[20000-1440-80]).  The asm below uses `ob` after the statistics: its registers stay intact.
 #if ST_STORE_SOFFSET
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rc, rv ? c_lane[h] : ST_OOB, (unsigned)t * c_tile, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(obits, rc, rv ? c_lane[h] : ST_OOB, (unsigned)t * c_tile, 0);
 #else
       // round 5: the tile offset is added to the vector offset (soffset 0).  With the scalar offset the hazard above is NOT bounded by
       // two instructions: at M = 12544, N = 3456, K = 192 (the 7x7 expand, store queue backed up) the first data dword of a store was
       // replaced by a value written to that register ~28 instructions later (the next store's offset), 4 lanes at a time, ~4000 of 43 M
       // outputs per launch, different ones in every run (tools/gemmcheck.py, profiles/r05_st_store_hazard.txt).
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), rc, rv ? c_lane[h] + (unsigned)t * c_tile : ST_OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(obits, rc, rv ? c_lane[h] + (unsigned)t * c_tile : ST_OOB, 0, 0);
 #endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x2 o = f32x2{(float)ob[2 * i], (float)ob[2 * i + 1]};   // statistics see the stored value
+        const f32x2 o = bf16_pair_f32(obits[i]);   // statistics see the stored value
         s1[4 * h + i] += o;
         s2[4 * h + i] += EPK == ST_FWD ? o * o : o * f32x2{zv[8 * h + 2 * i], zv[8 * h + 2 * i + 1]};
         // the accumulation happens HERE: left to itself, instruction selection collects the statistics updates of all unrolled tiles at
         // the end of the loop body, with the 16 stored values of every tile live until then (about 20 registers per unrolled tile)
         asm volatile("" : "+v"(s1[4 * h + i]), "+v"(s2[4 * h + i]));
       }
-      asm volatile("" ::"v"(__builtin_bit_cast(u32x4, ob)));
+      asm volatile("" ::"v"(obits));
     }
   };
   auto load_a = [&](int t, int ks) {
@@ -1441,13 +1444,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_sw(const bf16_t* __restrict_
       if (row < M && c0 < N) {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = (bf16_t)acc[t][r];
-          const float f = (float)o[r];   // statistics see the stored value
-          ssum[t][r] += f;
-          ssq[t][r] += f * f;
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[t][r];
+        u32x2 ob = __builtin_bit_cast(u32x2, o);
+        asm volatile("" : "+v"(ob));
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const f32x2 f = bf16_pair_f32(ob[r2]);   // statistics see the stored value
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            ssum[t][2 * r2 + r] += f[r];
+            ssq[t][2 * r2 + r] += f[r] * f[r];
+          }
         }
-        *reinterpret_cast<bf16x4*>(cout + row * ldc + c0) = o;
+        *reinterpret_cast<u32x2*>(cout + row * ldc + c0) = ob;
       }
     }
   }
@@ -1700,13 +1709,19 @@ __global__ __launch_bounds__(NWV * 64, WGPC) void k_gemm_nt_swg(const bf16_t* __
       if (row < M && c0 < N) {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = (bf16_t)acc[t][r];
-          const float f = (float)o[r];
-          ssum[t][r] += f;
-          ssq[t][r] += f * f;
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[t][r];
+        u32x2 ob = __builtin_bit_cast(u32x2, o);
+        asm volatile("" : "+v"(ob));
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const f32x2 f = bf16_pair_f32(ob[r2]);   // statistics see the stored value
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            ssum[t][2 * r2 + r] += f[r];
+            ssq[t][2 * r2 + r] += f[r] * f[r];
+          }
         }
-        *reinterpret_cast<bf16x4*>(cout + row * ldc + c0) = o;
+        *reinterpret_cast<u32x2*>(cout + row * ldc + c0) = ob;
       }
     }
   }

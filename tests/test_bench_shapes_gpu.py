@@ -141,8 +141,23 @@ def margin(ctx, M, C, scale_vec, shift_vec, dtype, amp=1.0, gap=0.05):
     return z.float()
 
 
+# ATOMNAS_SWEEP_DIGESTS=<file>: every checked output / statistics row of every replayed launch is also written there as a SHA-1 of its
+# bytes (the inputs are seeded per row), so that two builds of the library can be compared BIT FOR BIT over the step's launches:
+#   ATOMNAS_HIP_LIB=old.so ATOMNAS_SWEEP_DIGESTS=a.txt pytest tests/test_bench_shapes_gpu.py -m gpu; ... new ...; diff a.txt b.txt
+DIGESTS = os.environ.get("ATOMNAS_SWEEP_DIGESTS")
+_CUR = [""]
+
+
+def _digest(name, t):
+    if DIGESTS:
+        import hashlib
+        with open(DIGESTS, "a") as f:
+            f.write("%s %s %s\n" % (_CUR[0], name, hashlib.sha1(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()))
+
+
 def check(name, got, ref, rtol=1.2e-2, afrac=1e-2, outliers=0):
     """every element: |got - ref| <= rtol |ref| + afrac * rms(ref)"""
+    _digest(name, got)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     assert bool(torch.isfinite(got).all()), "%s: non-finite outputs (unwritten or corrupted elements)" % name
     rms = float(ref.float().pow(2).mean().sqrt())
@@ -157,6 +172,7 @@ def check(name, got, ref, rtol=1.2e-2, afrac=1e-2, outliers=0):
 def check_sums(name, stat_row, terms, rtol=1e-4, afrac=1e-5):
     """a statistics value against the fp64 column sums of `terms` (computed from what the kernel stored): error budget relative to
     the sum of the absolute terms (fp32 partial sums in a fixed order)"""
+    _digest(name, stat_row)
     ref = terms.double().sum(0)
     mag = terms.double().abs().sum(0)
     bad = ~((stat_row.double() - ref).abs() <= rtol * ref.abs() + afrac * mag + 1e-30)
@@ -802,6 +818,7 @@ def test_table_is_present_and_covers_the_step():
 def test_bench_size_launch(gpu_lib, row):
     seed = zlib.crc32(json.dumps({k: v for k, v in row.items() if k != "nets"}, sort_keys=True).encode()) & 0x7FFFFFFF
     ctx = Ctx(seed)
+    _CUR[0] = _id(row)
     RUNNERS[row["entry"]](ctx, row)
     torch.cuda.empty_cache()
 

@@ -1,7 +1,6 @@
 cd /root/repo
-timeout 900 python -m pytest tests -q -m gpu -x -k "kernels or late_stages or bench_shapes or xbwd or fused" -p no:cacheprovider 2>&1 | tail -4
 OLD=/root/repo/atomnas_amd/csrc/build/variants/libold.so
-for i in 1 2; do
-echo "== old"; ATOMNAS_HIP_LIB=$OLD timeout 300 python tools/bringup.py 256 2>&1 | grep -E "graph ms|atomnas_pw|atomnas_expand|atomnas_project|atomnas_bn|atomnas_act"
-echo "== new"; timeout 300 python tools/bringup.py 256 2>&1 | grep -E "graph ms|atomnas_pw|atomnas_expand|atomnas_project|atomnas_bn|atomnas_act"
-done
+rm -f gpurun_out/dig_old.txt gpurun_out/dig_new.txt
+ATOMNAS_HIP_LIB=$OLD ATOMNAS_SWEEP_DIGESTS=gpurun_out/dig_old.txt timeout 600 python -m pytest tests/test_bench_shapes_gpu.py -q -m gpu -k "pw_gemm or expand_bwd or project_bwd" -p no:cacheprovider 2>&1 | tail -2
+ATOMNAS_SWEEP_DIGESTS=gpurun_out/dig_new.txt timeout 600 python -m pytest tests/test_bench_shapes_gpu.py -q -m gpu -k "pw_gemm or expand_bwd or project_bwd" -p no:cacheprovider 2>&1 | tail -2
+diff gpurun_out/dig_old.txt gpurun_out/dig_new.txt | grep "^>" | awk '{print $2, $3}' | sort | uniq -c | sort -rn | head -60
