@@ -279,7 +279,9 @@ template <int KSTEPS, int EPK> struct StCfg {
   static constexpr int BT = EPK == ST_PBWD ? (KSTEPS == 1 ? ST_PB_BT1 : ST_PB_BT2)   // registers: + the weight-gradient accumulators
                                             : KSTEPS == 1 ? ST_BT1 : KSTEPS == 2 ? ST_BT2 : KSTEPS == 3 ? ST_BT3 : ST_BT6;
   static constexpr int PD = BT > 0 ? (BT >= 2 ? 2 : 1) : 2;
-  static constexpr int WPE = EPK == ST_PBWD ? 1 : 2;
+  // two waves per EU cap the allocation at 256 registers: the compiler then lets the MFMAs write VGPRs (no v_accvgpr_read per output:
+  // -19 % instructions in the expand forward's loop, round 6); the six-k-step and the fused instances need more than 256
+  static constexpr int WPE = EPK == ST_PBWD || KSTEPS == 6 ? 1 : 2;
   static constexpr bool SH = ST_SHARED && BT > 0 && BT % 4 == 0 && EPK != ST_PBWD;   // bursts shared by the workgroup's four waves
   static constexpr int BTP = KSTEPS <= 3 ? BT : 0;   // burst tiles of the private (per-wave) form
 };

@@ -221,54 +221,103 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
   // per work unit, loop-invariant: the row pair, the byte-free element offset of (row 0, channel group) and the row multiplier of each
   // stream.  Computed per load (layout branch, 64-bit products) the address arithmetic was ~20 instructions and two branches per
   // load, 20 loads per slab.
-  int v_rp[NVU], u_rp[NUU];
-  long v_c1[NVU], v_c2[V2 ? NVU : 1], u_c1[NUU], u_c2[U2 ? NUU : 1];
   const long v_m1 = V.ss1 ? 16 : V.ld1, v_m2 = V.ss2 ? 16 : V.ld2, u_m1 = U.ss1 ? 16 : U.ld1, u_m2 = U.ss2 ? 16 : U.ld2;
-#pragma unroll
-  for (int i = 0; i < NVU; ++i) {
+  // (row pair, element offsets of (row 0, channel group) in the two streams) of work unit i: needed when the running pointers are set up
+  // and in the clamped form of the loads -- not kept in registers across the slab loop
+  auto v_unit = [&](int i, int& rp, long& c1, long& c2) {
     int cg;
     const int idx = tid + 256 * i;
-    unit(idx < (ROWS / 2) * (VW / 8) ? idx : 0, VW / 8, vslab, cg, v_rp[i]);
+    unit(idx < (ROWS / 2) * (VW / 8) ? idx : 0, VW / 8, vslab, cg, rp);
     int k = v0 + cg * 8;
     k = k < NV ? k : K8V - 8;
-    v_c1[i] = lay_off(0, k, V.ld1, V.ss1);
-    if constexpr (V2) v_c2[i] = lay_off(0, k, V.ld2, V.ss2);
+    c1 = lay_off(0, k, V.ld1, V.ss1);
+    c2 = V2 ? lay_off(0, k, V.ld2, V.ss2) : 0;
+  };
+  auto u_unit = [&](int i, int& rp, long& c1, long& c2) {
+    int cg;
+    const int idx = tid + 256 * i;
+    unit(idx < (ROWS / 2) * ugroups ? idx : 0, ugroups, uslab, cg, rp);
+    int k = u0 + cg * 8;
+    k = k < NU ? k : K8U - 8;
+    c1 = lay_off(0, k, U.ld1, U.ss1);
+    c2 = U2 ? lay_off(0, k, U.ld2, U.ss2) : 0;
+  };
+  // Round 6: the loads of a slab that lies entirely inside the tensor (all but the last one or two) go through RUNNING pointers -- one
+  // 64-bit add per load and one per unit and slab -- instead of a clamped row, a 64-bit product and two sums per load (~12 instructions
+  // each, 20-30 loads per slab: the kernel issues ~3,000 instructions per slab at two waves per SIMD and is bound by that).  Slabs that
+  // touch row M take the clamped form below.
+  constexpr bool RUNP = !(U2 && UTT >= 20);   // (twenty two-stream pointers more than that instance has registers for: it spills)
+  const T* pv1[NVU]; const T* pv2[V2 ? NVU : 1]; const T* pu1[NUU]; const T* pu2[U2 ? NUU : 1];
+#pragma unroll
+  for (int i = 0; i < NVU; ++i) {
+    int rp; long c1, c2;
+    v_unit(i, rp, c1, c2);
+    pv1[i] = reinterpret_cast<const T*>(V.p1) + ((r_beg + 2 * rp) * v_m1 + c1);
+    if constexpr (V2) pv2[i] = reinterpret_cast<const T*>(V.p2) + ((r_beg + 2 * rp) * v_m2 + c2);
   }
 #pragma unroll
   for (int i = 0; i < NUU; ++i) {
-    int cg;
-    const int idx = tid + 256 * i;
-    unit(idx < (ROWS / 2) * ugroups ? idx : 0, ugroups, uslab, cg, u_rp[i]);
-    int k = u0 + cg * 8;
-    k = k < NU ? k : K8U - 8;
-    u_c1[i] = lay_off(0, k, U.ld1, U.ss1);
-    if constexpr (U2) u_c2[i] = lay_off(0, k, U.ld2, U.ss2);
+    int rp; long c1, c2;
+    u_unit(i, rp, c1, c2);
+    pu1[i] = reinterpret_cast<const T*>(U.p1) + ((r_beg + 2 * rp) * u_m1 + c1);
+    if constexpr (U2) pu2[i] = reinterpret_cast<const T*>(U.p2) + ((r_beg + 2 * rp) * u_m2 + c2);
   }
+  long r_run = r_beg;   // the slab the running pointers stand at
   auto issue = [&](long r0) {
+    if (RUNP && r0 == r_run && r0 + ROWS <= M) {   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NVU; ++i) {
+        rva[i][0] = *reinterpret_cast<const bf16x8*>(pv1[i]);
+        rva[i][1] = *reinterpret_cast<const bf16x8*>(pv1[i] + v_m1);
+        pv1[i] += ROWS * v_m1;
+        if constexpr (V2) {
+          rvx[i][0] = *reinterpret_cast<const bf16x8*>(pv2[i]);
+          rvx[i][1] = *reinterpret_cast<const bf16x8*>(pv2[i] + v_m2);
+          pv2[i] += ROWS * v_m2;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NUU; ++i) {
+        rua[i][0] = *reinterpret_cast<const bf16x8*>(pu1[i]);
+        rua[i][1] = *reinterpret_cast<const bf16x8*>(pu1[i] + u_m1);
+        pu1[i] += ROWS * u_m1;
+        if constexpr (U2) {
+          rux[i][0] = *reinterpret_cast<const bf16x8*>(pu2[i]);
+          rux[i][1] = *reinterpret_cast<const bf16x8*>(pu2[i] + u_m2);
+          pu2[i] += ROWS * u_m2;
+        }
+      }
+      r_run = r0 + ROWS;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NVU; ++i) {
+      int rp; long c1, c2;
+      v_unit(i, rp, c1, c2);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        long r = r0 + 2 * v_rp[i] + h;
+        long r = r0 + 2 * rp + h;
         r = r < M ? r : M - 1;
-        rva[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p1) + (r * v_m1 + v_c1[i]));
-        if constexpr (V2) rvx[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p2) + (r * v_m2 + v_c2[i]));
+        rva[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p1) + (r * v_m1 + c1));
+        if constexpr (V2) rvx[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(V.p2) + (r * v_m2 + c2));
       }
     }
 #pragma unroll
     for (int i = 0; i < NUU; ++i) {
+      int rp; long c1, c2;
+      u_unit(i, rp, c1, c2);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        long r = r0 + 2 * u_rp[i] + h;
+        long r = r0 + 2 * rp + h;
         r = r < M ? r : M - 1;
-        rua[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p1) + (r * u_m1 + u_c1[i]));
-        if constexpr (U2) rux[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p2) + (r * u_m2 + u_c2[i]));
+        rua[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p1) + (r * u_m1 + c1));
+        if constexpr (U2) rux[i][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(U.p2) + (r * u_m2 + c2));
       }
     }
   };
   // prologue of 8 raw channels of one row (coefficients from LDS; entries of channels >= K are zero), zero where invalid
-  auto xform = [&](auto mode_tag, const Operand& o, const bf16x8& ra, const bf16x8& rx, bool valid, const float* lc1, const float* lc2,
-                   const float* lc3, float (&v)[8]) {
+  auto xform = [&](auto mode_tag, const Operand& o, const bf16x8& ra, const bf16x8& rx, bool guard, bool valid, const float* lc1,
+                   const float* lc2, const float* lc3, float (&v)[8]) {
     constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)ra[e];
@@ -287,10 +336,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = a1[e] * v[e] + a2[e] * (float)rx[e] + a3[e];
     }
+    if (guard) {   // wave-uniform: the slab reaches past the chunk, or a raw operand's tile past its last channel
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = valid ? v[e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = valid ? v[e] : 0.f;
+    }
   };
+  // the prologues turn the clamped channels past NV / NU into zeros by themselves (their staged coefficients are zero): only a raw
+  // operand needs the channel test; rows need theirs in the last slab of the chunk
+  const bool v_tail = VMODE == PRO_NONE && v0 + VW > NV, u_tail = UMODE == PRO_NONE && u0 + 16 * UTT > NU;
   auto stage = [&](long r0) {
+    const bool row_guard = r0 + ROWS > r_end;
 #pragma unroll
     for (int i = 0; i < NVU; ++i) {
       int cg, rp;
@@ -300,8 +355,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       float a[8], bb[8];
       const float* lc = s_cv + cg * 8;
       const bool kv = v0 + cg * 8 < NV;
-      xform(std::integral_constant<int, VMODE>{}, V, rva[i][0], rvx[V2 ? i : 0][0], kv && (r0 + 2 * rp) < r_end, lc, lc + VW, lc + 2 * VW, a);
-      xform(std::integral_constant<int, VMODE>{}, V, rva[i][1], rvx[V2 ? i : 0][1], kv && (r0 + 2 * rp + 1) < r_end, lc, lc + VW, lc + 2 * VW, bb);
+      xform(std::integral_constant<int, VMODE>{}, V, rva[i][0], rvx[V2 ? i : 0][0], row_guard || v_tail, kv && (r0 + 2 * rp) < r_end, lc, lc + VW, lc + 2 * VW, a);
+      xform(std::integral_constant<int, VMODE>{}, V, rva[i][1], rvx[V2 ? i : 0][1], row_guard || v_tail, kv && (r0 + 2 * rp + 1) < r_end, lc, lc + VW, lc + 2 * VW, bb);
       const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
       if (active) {
         if constexpr (TR) {
@@ -329,8 +384,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(Operand U, int NU, Operand V, 
       float a[8], bb[8];
       const float* lc = s_cu + cg * 8;
       const bool kv = u0 + cg * 8 < NU;
-      xform(std::integral_constant<int, UMODE>{}, U, rua[i][0], rux[U2 ? i : 0][0], kv && (r0 + 2 * rp) < r_end, lc, lc + 16 * UTT, lc + 32 * UTT, a);
-      xform(std::integral_constant<int, UMODE>{}, U, rua[i][1], rux[U2 ? i : 0][1], kv && (r0 + 2 * rp + 1) < r_end, lc, lc + 16 * UTT, lc + 32 * UTT, bb);
+      xform(std::integral_constant<int, UMODE>{}, U, rua[i][0], rux[U2 ? i : 0][0], row_guard || u_tail, kv && (r0 + 2 * rp) < r_end, lc, lc + 16 * UTT, lc + 32 * UTT, a);
+      xform(std::integral_constant<int, UMODE>{}, U, rua[i][1], rux[U2 ? i : 0][1], row_guard || u_tail, kv && (r0 + 2 * rp + 1) < r_end, lc, lc + 16 * UTT, lc + 32 * UTT, bb);
       const int rot = TN2_COALESCED ? 2 * (cg >> 1) : 0;
       if (active) {
         if constexpr (TR) {
