@@ -97,34 +97,46 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Operand A, const T* __restrict_
 }
 
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
 // ------------------------------------------------------------------------------------------------ gemm_nt, narrow (N <= 64, K <= 64)
 // The stem and the first (non-expanding) block: 3.2e6 rows of 16..32 channels on either side.  The row-stationary kernel spends
 // 4-8 weight-fragment loads and 128 cross-lane statistics operations on every 16-row tile that moves 1-2 KiB, and waits for each
 // tile's activations before it starts the next.  Here the weight fragments and prologue coefficients of the lane's k positions
 // stay in registers, the next tile's activations are in flight while the current one is computed, and the statistics are
 // accumulated per lane and reduced once at the end (as in the column-stationary kernel).
-template <int MODE, int KST>
+// Round 6, NT > 0 (N a multiple of 4, bf16 output): the output tile of a lane is 4 channels x NT column tiles instead of 16 consecutive
+// channels.  With the 16-channel form a lane group q owns channels 16 q .. 16 q + 15, so at N = 16 / 32 -- the only widths this kernel
+// sees in the network -- a quarter / half of the lanes ran the epilogue (bias, residual, mask, rounding, statistics: most of the kernel's
+// vector instructions, and the kernel issues 0.2 instructions per SIMD and cycle, close to what its waves can issue) while the others
+// idled, and the wave computed four MFMA tiles of which one / two held outputs.  Now weight row 16 t + j feeds tile t, a lane holds
+// channels 16 t + 4 q .. + 3 of pixel j (8-byte accesses, 512 contiguous bytes per wave and tile), only the NT tiles that exist are
+// computed, and the per-channel vectors of the epilogue are read once.  Per channel the statistics add the same values in the same order
+// (lane j over the row tiles, then the butterfly over j): bit-identical to NT = 0.
+template <int MODE, int KST, int NT = 0>
 __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* __restrict__ Wp, int ldw, Epilogue ep, long M, int N, int K) {
   using T = bf16_t;
   using MM = Mma<T>;
   constexpr int SWD = 64;
+  constexpr int WT = NT > 0 ? NT : 4;   // MFMA tiles per k-step
   extern __shared__ float s_stat[];  // [4 waves][2][64] when statistics are taken
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & 15;
-  const int wrow = 16 * (j >> 2) + (j & 3);
+  const int wrow = NT > 0 ? j : 16 * (j >> 2) + (j & 3);
   const bool do_stats = ep.stats != nullptr && ep.stat_mode != STAT_NONE;
   if (do_stats) {
     for (int i = tid; i < 8 * SWD; i += 256) s_stat[i] = 0.f;
     __syncthreads();
   }
-  bf16x8 wf[KST][4];
+  bf16x8 wf[KST][WT];
   float p1[KST][8], p2[KST][8], p3[KST][8];
 #pragma unroll
   for (int ks = 0; ks < KST; ++ks) {
     const int k = ks * 32 + 8 * q;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wf[ks][t] = MM::raw(Wp + (long)(wrow + 4 * t) * ldw + k);
+    for (int t = 0; t < WT; ++t) wf[ks][t] = MM::raw(Wp + (long)(wrow + (NT > 0 ? 16 : 4) * t) * ldw + k);
 #pragma unroll
     for (int e = 0; e < 8; ++e) p1[ks][e] = p2[ks][e] = p3[ks][e] = 0.f;
     if constexpr (MODE != PRO_NONE) {
@@ -159,6 +171,20 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* 
   float s1[16], s2[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+  // NT > 0: per-channel vectors of the lane's channels 16 t + 4 q + r (zero where the epilogue has none / past N)
+  float e_bias[WT][4], e_zs[WT][4], e_zh[WT][4];
+  const Act e_act = act_of(ep.mask);
+  if constexpr (NT > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * t + 4 * q + r;
+        e_bias[t][r] = (ep.bias && n < N) ? ep.bias[n] : 0.f;
+        e_zs[t][r] = (ep.mask && n < N) ? ep.zscale[n] : 0.f;
+        e_zh[t][r] = (ep.mask && n < N) ? ep.zshift[n] : 0.f;
+      }
+  }
 
   long mt = (long)blockIdx.x * 4 + wave;
   if (mt < mtiles) fetch(mt);
@@ -169,9 +195,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* 
     if (mt + stride < mtiles) fetch(mt + stride);
     const long row = mt * 16 + j;
     const bool rowvalid = row < M;
-    f32x4 acc[4];
+    f32x4 acc[WT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < WT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KST; ++ks) {
       const int k = ks * 32 + 8 * q;
@@ -189,15 +215,60 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* 
         if (!rowvalid || k + e >= K) v[e] = 0.f;
       const bf16x8 af = MM::pack(v);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
+      for (int t = 0; t < WT; ++t) acc[t] = MM::mma(wf[ks][t], af, acc[t]);
     }
-    float c[16], zv[16];
-    nt_epilogue_core<T>(ep, acc, row, rowvalid, 16 * q, N, c, zv);
-    if (do_stats) {
+    if constexpr (NT > 0) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s1[i] += c[i];
-        s2[i] += (ep.stat_mode == STAT_SQ) ? c[i] * c[i] : c[i] * zv[i];
+      for (int t = 0; t < NT; ++t) {
+        const int c0 = 16 * t + 4 * q;
+        float c[4], zv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = 0.f;
+        if (rowvalid && c0 < N) {   // (N is a multiple of 4: the lane's four channels are valid together)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = acc[t][r] + e_bias[t][r];
+          if (ep.add) {
+            const bf16x4 ad = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const T*>(ep.add) + row * ep.ldadd + c0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] += (float)ad[r];
+          }
+          if (ep.z) {
+            const bf16x4 zb = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const T*>(ep.z) + lay_off(row, c0, ep.ldz, ep.zss));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zv[r] = (float)zb[r];
+            if (ep.mask) {
+              float a4[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) a4[r] = zv[r] * e_zs[t][r] + e_zh[t][r];
+              act_bwd_v<4>(c, a4, e_act);
+            }
+          }
+          bf16x4 ob;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)c[r];
+          u32x2 bits = __builtin_bit_cast(u32x2, ob);
+          asm volatile("" : "+v"(bits));
+          const f32x2 lo = bf16_pair_f32(bits[0]), hi = bf16_pair_f32(bits[1]);   // statistics see the stored values
+          c[0] = lo[0]; c[1] = lo[1]; c[2] = hi[0]; c[3] = hi[1];
+          *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(ep.c) + lay_off(row, c0, ep.ldc, ep.css)) = bits;
+        }
+        if (do_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[4 * t + r] += c[r];
+            s2[4 * t + r] += (ep.stat_mode == STAT_SQ) ? c[r] * c[r] : c[r] * zv[r];
+          }
+        }
+      }
+    } else {
+      float c[16], zv[16];
+      nt_epilogue_core<T>(ep, acc, row, rowvalid, 16 * q, N, c, zv);
+      if (do_stats) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s1[i] += c[i];
+          s2[i] += (ep.stat_mode == STAT_SQ) ? c[i] * c[i] : c[i] * zv[i];
+        }
       }
     }
   }
@@ -205,15 +276,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(Operand A, const bf16_t* 
     float* sw = s_stat + wave * 2 * SWD;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+      if (NT > 0 && i >= 4 * NT) continue;
       float a = s1[i], b = s2[i];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) {
         a += __shfl_xor(a, o, 64);
         b += __shfl_xor(b, o, 64);
       }
-      if (j == 0 && 16 * q + i < N) {
-        sw[16 * q + i] = a;
-        sw[SWD + 16 * q + i] = b;
+      const int ch = NT > 0 ? 16 * (i >> 2) + 4 * q + (i & 3) : 16 * q + i;
+      if (j == 0 && ch < N) {
+        sw[ch] = a;
+        sw[SWD + ch] = b;
       }
     }
     nt_flush_stats(ep, s_stat, SWD, 0, N, blockIdx.x, gridDim.x, tid);
@@ -285,8 +358,6 @@ template <int KSTEPS, int EPK> struct StCfg {
   static constexpr bool SH = ST_SHARED && BT > 0 && BT % 4 == 0 && EPK != ST_PBWD;   // bursts shared by the workgroup's four waves
   static constexpr int BTP = KSTEPS <= 3 ? BT : 0;   // burst tiles of the private (per-wave) form
 };
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 constexpr unsigned ST_OOB = 0x80000000u;   // >= num_records of every resource below
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* p) {
@@ -1838,9 +1909,13 @@ static int launch_nt(int mode, const Operand& A, const void* Wp, int ldw, const 
       const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
       const size_t lds = do_stats ? (size_t)8 * 64 * sizeof(float) : 0;
       const bf16_t* W = (const bf16_t*)Wp;
+      // lanes own 4 channels x NT tiles where the output allows it (bf16, N a multiple of 4); ATOMNAS_NT_SMALL_NARROW=0: the 16-channel form
+      static const int narrow_on = getenv("ATOMNAS_NT_SMALL_NARROW") ? atoi(getenv("ATOMNAS_NT_SMALL_NARROW")) : 1;
+      const int ntile = (narrow_on && !ep.out_f32 && N % 4 == 0) ? (N <= 16 ? 1 : N <= 32 ? 2 : 4) : 0;
 #define SM_LAUNCH(MODE, KSTV)                                                                                  \
   {                                                                                                            \
-    auto kern = k_gemm_nt_small<MODE, KSTV>;                                                                   \
+    auto kern = ntile == 1 ? k_gemm_nt_small<MODE, KSTV, 1> : ntile == 2 ? k_gemm_nt_small<MODE, KSTV, 2>      \
+              : ntile == 4 ? k_gemm_nt_small<MODE, KSTV, 4> : k_gemm_nt_small<MODE, KSTV, 0>;                  \
     long R = (long)num_cus() * resident_per_cu(kern, 256, lds);                                                \
     if (R > (mtiles + 3) / 4) R = (mtiles + 3) / 4;                                                            \
     if (do_stats && R > ep.stat_rows) R = ep.stat_rows;                                                        \
