@@ -1851,8 +1851,10 @@ static int launch_nt_swg(int mode, const Operand& A, const void* Wp, int ldw, co
   static const int on = getenv("ATOMNAS_NT_SWG") ? atoi(getenv("ATOMNAS_NT_SWG")) : 1;   // experiment switch (0: k_gemm_nt_ws)
   const bool do_stats = ep.stats && ep.stat_mode != STAT_NONE;
   // measured (r04 prototype, r05 in situ): gains at 14 x 14 and 7 x 7 (M <= 50176), none at 28 x 28 (M = 200704: every stage moves
-  // 12 KB of weights from L2 for 8 KB of activations)
-  if (!on || mode != PRO_BNRELU || A.ss1 <= 0 || N % 8 != 0 || N > 320 || K < 256 || K % 4 != 0 || M < 8192 || M > 100000 || ldw < 64 || ldw % 8 != 0 ||
+  // 12 KB of weights from L2 for 8 KB of activations) -- until round 6 took two thirds of the prologue's instructions out (common.h: Act):
+  // since then 0.098 -> 0.077 ms at M = 200704, N = 40, K = 720 (tools/pwbench.py project), and the row limit is 262144
+  static const long maxm = getenv("ATOMNAS_NT_SWG_MAXM") ? atol(getenv("ATOMNAS_NT_SWG_MAXM")) : 262144;   // experiment switch
+  if (!on || mode != PRO_BNRELU || A.ss1 <= 0 || N % 8 != 0 || N > 320 || K < 256 || K % 4 != 0 || M < 8192 || M > maxm || ldw < 64 || ldw % 8 != 0 ||
       ep.out_f32 || ep.css != 0 || ep.add || ep.z || ep.mask || ep.bias || (do_stats && ep.stat_mode != STAT_SQ) || !A.c1 || !A.c2)
     return -1;
   const int ut = (N + 15) / 16;
