@@ -95,6 +95,22 @@ __device__ __forceinline__ float cw_act_bwd(float c, float a, int in_relu, int A
   return (in_relu && !(a > 0.f)) ? 0.f : c;
 }
 
+// Activation followed by the clamp to the fp16 range that the matrix-core forward kernels apply to their operand (dwconv_mm.hip,
+// dwconv_mm2.hip): ONE v_med3_f32 for none / ReLU / ReLU6 (round 6: was v_max + v_med3 per element of the commit phase, the phase those
+// kernels spend their issue slots in; same values for every non-NaN input).
+// `ok` (the piece lies inside the image; one flag for its 8 channels) rides in the bounds: an invalid piece is clamped to [0, 0], which
+// replaces a select per element by two per piece.  (The values of an invalid piece come from a clamped address: finite.)
+struct CwClamp { float lo, hi; };
+__device__ __forceinline__ CwClamp cw_clamp16_bounds(bool ok, int in_relu, int AM) {
+  const float lo = (AM == ACT_RELU || AM == ACT_RELU6 || (AM == 0 && in_relu)) ? 0.f : -65504.f;
+  const float hi = AM == ACT_RELU6 ? 6.f : 65504.f;
+  return CwClamp{ok ? lo : 0.f, ok ? hi : 0.f};
+}
+__device__ __forceinline__ float cw_act_clamp16(float a, CwClamp b, int AM) {
+  if (AM == ACT_SWISH) a = swish_f(a);
+  return __builtin_amdgcn_fmed3f(a, b.lo, b.hi);
+}
+
 // Sum over the 64 lanes of a wave with DPP adds only (no LDS traffic): quad butterflies, half-row and row mirrors leave every
 // lane with the sum of its 16-lane row; row_bcast15 / row_bcast31 then carry the row sums upwards.  The total is valid in
 // lanes 48..63 (lane 63 is read); the order of the additions is fixed.

@@ -149,14 +149,14 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm(const bf16_t* __restrict__ 
     float q1[8], q2[8];
     VecIO<float, 8>::load(s_cf + cg * 8, q1);
     VecIO<float, 8>::load(s_cf + 16 + cg * 8, q2);
+    const CwClamp cb = cw_clamp16_bounds(ok, in_relu, AM);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const pair_t xq = X::pair(p, qq);
       float a0 = X::lo(xq) * q1[2 * qq] + q2[2 * qq], a1 = X::hi(xq) * q1[2 * qq + 1] + q2[2 * qq + 1];
-      a0 = cw_act(a0, in_relu, AM); a1 = cw_act(a1, in_relu, AM);
-      if (AM != ACT_RELU6) { a0 = mm_clamp16(a0); a1 = mm_clamp16(a1); }   // (ReLU6: [0, 6])
-      d[(2 * qq) * g.plane] = ok ? (f16_t)a0 : (f16_t)0.f;
-      d[(2 * qq + 1) * g.plane] = ok ? (f16_t)a1 : (f16_t)0.f;
+      a0 = cw_act_clamp16(a0, cb, AM); a1 = cw_act_clamp16(a1, cb, AM);   // activation, then into the fp16 range (0 for an invalid piece)
+      d[(2 * qq) * g.plane] = (f16_t)a0;
+      d[(2 * qq + 1) * g.plane] = (f16_t)a1;
     }
   };
   auto commit = [&](int base) {
