@@ -164,10 +164,14 @@ __global__ __launch_bounds__(256, WPS) void k_dwf_mm2(const bf16_t* __restrict__
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const pair_t xq = X::pair(p, qq);
-      float a0 = X::lo(xq) * q1[2 * qq] + q2[2 * qq], a1 = X::hi(xq) * q1[2 * qq + 1] + q2[2 * qq + 1];
+      const f32x2 bn = __builtin_elementwise_fma(f32x2{X::lo(xq), X::hi(xq)}, f32x2{q1[2 * qq], q1[2 * qq + 1]}, f32x2{q2[2 * qq], q2[2 * qq + 1]});   // v_pk_fma_f32
+      float a0 = bn[0], a1 = bn[1];
       a0 = cw_act_clamp16(a0, cb, AM); a1 = cw_act_clamp16(a1, cb, AM);   // activation, then into the fp16 range (0 for an invalid piece)
-      d[(2 * qq) * g.plane] = (f16_t)a0;
-      d[(2 * qq + 1) * g.plane] = (f16_t)a1;
+      // one packed conversion for the pair (v_cvt_pk_f16_f32), the halves stored by ds_write_b16 / ds_write_b16_d16_hi
+      typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+      const f16x2_t pk = __builtin_convertvector(f32x2{a0, a1}, f16x2_t);
+      d[(2 * qq) * g.plane] = (f16_t)pk[0];
+      d[(2 * qq + 1) * g.plane] = (f16_t)pk[1];
     }
   };
   auto commit = [&](int base) {
